@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: d[k] for k in d.files}
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b| -- the 'relative fp32' measure used by every parity gate."""
+    a = a.detach().double().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
+    b = b.detach().double().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))

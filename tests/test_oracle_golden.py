@@ -1,0 +1,144 @@
+"""CPU: pins oracle/pdae_oracle.py against the vectors emitted by the reference
+itself (tests/golden/make_fixtures.py).  Tolerance: 1e-5 relative (both sides are
+torch-CPU fp32; only op grouping differs)."""
+import numpy as np
+import torch
+
+from tests.conftest import load_golden, T, rel_err
+from tests.golden import make_fixtures_cfg as C
+from oracle import pdae_oracle as O
+
+TOL = 2e-5
+
+
+def test_schedules_and_respacing():
+    g = load_golden("schedules")
+    s = O.Schedules(1000, "linear")
+    for n in ["alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+              "sqrt_recip_alphas_cumprod_m1", "posterior_variance", "posterior_log_variance_clipped",
+              "x_0_posterior_mean_x_0_coef", "x_0_posterior_mean_x_t_coef", "noise_posterior_mean_x_t_coef",
+              "noise_posterior_mean_noise_coef", "shift_coef", "weight"]:
+        assert np.array_equal(getattr(s, n).numpy(), g["lin_" + n]), n
+    sc = O.Schedules(1000, "cosine")
+    for n in ["alphas_cumprod", "shift_coef", "weight"]:
+        assert np.array_equal(getattr(sc, n).numpy(), g["cos_" + n]), n
+    for style in ["ddim10", "ddim20", "ddim100", "ddim1000"]:
+        d = O.DDIMTables(s, style)
+        assert np.array_equal(d.timestep_map.numpy(), g[style + "_map"])
+        for n in ["alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_one_minus_alphas_cumprod",
+                  "sqrt_recip_alphas_cumprod", "sqrt_recip_alphas_cumprod_m1"]:
+            assert np.array_equal(getattr(d, n).numpy(), g[style + "_" + n]), (style, n)
+    assert O.DDIMTables(s, "ddim1000").timesteps == 999          # duplicates collapse
+    assert list(g["ddim100_map"][:3]) == [0, 9, 19] and g["ddim100_map"][-1] == 999
+    t = T(g["temb_t"])
+    assert np.array_equal(O.timestep_embedding(t, 32).numpy(), g["temb_32"])
+    assert np.array_equal(O.timestep_embedding(t, 128).numpy(), g["temb_128"])
+
+
+def _unet_case(tag, cfg):
+    g = load_golden(tag)
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), int(g["seed"]))
+    for v in sd.values():
+        v.requires_grad_(True)
+    s = O.Schedules()
+    x0, noise, t = T(g["x0"]), T(g["noise"]), T(g["t"])
+    cond = T(g["cond"]) if g["cond"].size else None
+    x_t = O.q_sample(s, x0, t, noise)
+    assert rel_err(x_t, g["x_t"]) < 1e-6
+    out = O.unet_forward(sd, cfg, x_t, t, cond)
+    assert rel_err(out, g["out"]) < TOL
+    loss = O.p_loss(noise, out)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    keys = [str(k) for k in g["grad_keys"]]
+    for k, (gs, gn, gm) in zip(keys, g["grad_summary"]):
+        gr = sd[k].grad
+        assert gr is not None, k
+        assert abs(float(gr.double().norm()) - gn) <= 1e-4 * gn + 1e-9, k
+    for k in g:
+        if k.startswith("g__"):
+            assert rel_err(sd[k[3:]].grad, g[k]) < 1e-4, k
+
+
+def test_unet_class_cond_new_attention_order():
+    _unet_case("unet_a", C.CFG_UNET_A)
+
+
+def test_unet_no_attention_three_levels():
+    _unet_case("unet_b", C.CFG_UNET_B)
+
+
+def test_shift_unet_and_ddim_trajectories():
+    g = load_golden("shift_tiny")
+    cfg = C.CFG_SHIFT_T
+    latent = int(g["latent"])
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=latent), int(g["seed"]))
+    s = O.Schedules()
+    with torch.no_grad():
+        eps, shift = O.shift_unet_forward(sd, cfg, T(g["x"]), T(g["t"]), T(g["z"]))
+        assert rel_err(eps, g["eps"]) < TOL and rel_err(shift, g["shift"]) < TOL
+        z, x0 = T(g["z"]), T(g["x0"])
+        traj = []
+        x_T = O.shift_ddim_encode_loop(s, "ddim20", sd, cfg, z, x0, trajectory=traj)
+        got = torch.stack(traj[:3] + traj[-1:])
+        assert rel_err(got, g["enc_traj"]) < 1e-4
+        assert rel_err(x_T, g["x_T"]) < 1e-4
+        x_rec = O.shift_ddim_sample_loop(s, "ddim10", sd, cfg, z, T(g["x_T"]))
+        assert rel_err(x_rec, g["x_rec"]) < 1e-4
+        x_rs = O.shift_ddim_sample_loop(s, "ddim10", sd, cfg, z, T(g["x_T"]), stop_percent=0.3)
+        assert rel_err(x_rs, g["x_rec_stop"]) < 1e-4
+        n0, n1 = (x0 + 1) / 2, (T(g["x_rec"]) + 1) / 2
+        assert np.allclose(O.ssim(n0, n1).numpy(), g["ssim_10"], atol=1e-6)
+        assert np.allclose(O.mse(n0, n1).numpy(), g["mse_10"], rtol=1e-5)
+
+
+def test_rl_train_step_loss_grads_adam_ema():
+    g = load_golden("rl_step")
+    cfg = C.CFG_SHIFT_64
+    enc_sd = O.synth_state_dict(O.encoder_param_shapes("CELEBA64Encoder", 512), int(g["seed_enc"]))
+    dec_sd = O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=512), int(g["seed_dec"]))
+    s = O.Schedules()
+    x0 = T(g["x0"])
+    train = {"enc::" + k: v for k, v in enc_sd.items()}
+    train.update({"dec::" + k: v for k, v in dec_sd.items() if O.shift_unet_trainable(k)})
+    m = {k: torch.zeros_like(v) for k, v in train.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in train.items()}
+    ema = {k: v.clone() for k, v in train.items()}
+    for step in range(3):
+        for p in train.values():
+            p.requires_grad_(True)
+            p.grad = None
+        loss = O.rl_loss(s, enc_sd, "CELEBA64Encoder", dec_sd, cfg, x0, T(g[f"t{step}"]), T(g[f"noise{step}"]))
+        assert abs(float(loss) - float(g[f"loss{step}"])) < 2e-5 * abs(float(g[f"loss{step}"])), step
+        loss.backward()
+        if step == 0:
+            keys = [str(k) for k in g["grad_keys"]]
+            assert sorted(train.keys()) == keys
+            for k, (gs, gn, gm) in zip(keys, g["grad_summary"]):
+                assert abs(float(train[k].grad.double().norm()) - gn) <= 2e-4 * gn + 1e-10, k
+            for k in g:
+                if k.startswith("g__"):
+                    assert rel_err(train[k[3:]].grad, g[k]) < 2e-4, k
+        with torch.no_grad():
+            for k, p in train.items():
+                pn, m[k], v2[k] = O.adam_step(p.detach(), p.grad, m[k], v2[k], step + 1, 1e-4)
+                p.requires_grad_(False)
+                p.copy_(pn)
+                ema[k] = O.ema_update(ema[k], p, 0.9999)
+        if step in (0, 2):
+            for k in g:
+                if k.startswith(f"p{step + 1}__"):
+                    kk = k.split("__", 1)[1]
+                    assert rel_err(train[kk], g[k]) < 2e-6, k
+                    assert rel_err(ema[kk], g[f"ema{step + 1}__" + kk]) < 2e-6, k
+
+
+def test_encoder_ffhq_mlp_metrics():
+    g = load_golden("misc")
+    enc_sd = O.synth_state_dict(O.encoder_param_shapes("FFHQEncoder", 512), 41)
+    with torch.no_grad():
+        assert rel_err(O.encoder_forward(enc_sd, "FFHQEncoder", T(g["enc_x0"])), g["enc_z"]) < TOL
+        sd = O.synth_state_dict(O.mlp_skip_net_param_shapes(C.CFG_MLP), 42)
+        assert rel_err(O.mlp_skip_net_forward(sd, C.CFG_MLP, T(g["mlp_z"]), T(g["mlp_t"])), g["mlp_out"]) < TOL
+    assert np.allclose(O.ssim(T(g["m_a"]), T(g["m_b"])).numpy(), g["ssim"], atol=1e-6)
+    assert np.allclose(O.mse(T(g["m_a"]), T(g["m_b"])).numpy(), g["mse"], rtol=1e-6)
