@@ -1,0 +1,129 @@
+/* libpdae_hip.so -- C ABI of the MI355X-native (gfx950) PDAE hot path.
+ *
+ * The reference (ckczzj/PDAE) has no FFI / operator plug-in interface: its hot path is the set of
+ * torch.nn / ATen calls issued by model/module.py, model/unet.py, model/shift_unet.py,
+ * diffusion/gaussian_diffusion.py and diffusion/ddim.py.  Each entry point below
+ * replaces one fused group of those calls and cites them (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = invalid argument, >0 = hipError_t; the message of the
+ *     last failure on the calling thread is returned by pdae_last_error();
+ *   - all buffers are caller-owned DEVICE pointers (fp32 unless noted, int64 for timesteps/labels);
+ *     no allocation, no host synchronisation inside; workspaces are sized by the *_workspace_bytes queries;
+ *   - the HIP stream is always explicit; functions are re-entrant (usable from the autograd thread);
+ *   - activations are NHWC ("channels last"), contiguous: [N][H][W][C];
+ *   - 2-D conv weights are [Cout][KH][KW][Cin] == the memory of a torch (Cout,Cin,KH,KW) tensor in
+ *     channels_last format, so a reference state-dict loads without repacking;
+ *   - "x0/C0, x1/C1" is a virtual channel concat [x0 | x1] (torch.cat(...,dim=1) in unet.py:200,
+ *     shift_unet.py:278,281) that is never materialised; pass x1 = NULL, C1 = 0 for a single tensor.
+ */
+#ifndef PDAE_HIP_H
+#define PDAE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pdae_stream_t; /* hipStream_t */
+
+const char* pdae_last_error(void);
+int pdae_abi_version(void);
+
+/* ---- convolution (F.conv2d / conv1d k=1: module.py:242,265,276,412,420; unet.py:62,174; encoder/ffhq.py:12-30) */
+typedef struct pdae_conv_desc {
+  int32_t N, Hi, Wi;      /* stored input spatial size */
+  int32_t C0, C1;         /* input channels: virtual concat of two tensors */
+  int32_t Ho, Wo, Cout;   /* output size */
+  int32_t KH, KW, stride, pad;
+  int32_t up;             /* 1: the conv reads the nearest-x2 upsample of the stored input (F.interpolate, module.py:169) */
+} pdae_conv_desc;
+
+/* y[N,Ho,Wo,Cout] = conv(x) + bias (+ res).  res_mode: 0 none, 1 res[N,Ho,Wo,Cout], 2 res stored at half resolution
+ * (the x_upd(x) skip of an up-ResBlock, module.py:279-284,297).  tile: 0 = auto, 64 or 128. */
+int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const float* bias, const float* res,
+                    int res_mode, float* y, int tile, pdae_stream_t stream);
+/* dx[N,Hl,Wl,ci_cnt] (+)= dL/d(conv input channels ci_off..ci_off+ci_cnt) on the LOGICAL input grid (Hl = 2*Hi when up). */
+int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, float* dx, int ci_off, int ci_cnt, int accumulate, int tile,
+                      pdae_stream_t stream);
+/* dw[Cout][KH][KW][Cin] (+)= sum over pixels; split-K over pixels through the workspace, reduced in fixed order. */
+size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d);
+int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, int accumulate, void* ws,
+                      size_t ws_bytes, pdae_stream_t stream);
+
+/* ---- strided-batched GEMM (F.linear, torch.einsum of module.py:450-457 / 479-488, and their backward)
+ * C[b][m][n] (+)= alpha * sum_k opA[b][m][k] * opB[b][k][n] + bias[n];  opA = A[m*lda+k] (transA=0) | A[k*lda+m] (1);
+ * opB = B[k*ldb+n] (transB=0) | B[n*ldb+k] (1).  batch b = bo*batch_inner + bi -> offset bo*s?o + bi*s?i.  (1,1) unsupported. */
+int pdae_gemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda, int64_t sAo, int64_t sAi, const float* B,
+              int64_t ldb, int64_t sBo, int64_t sBi, float* C, int64_t ldc, int64_t sCo, int64_t sCi, int batch_outer, int batch_inner,
+              const float* bias, int accumulate, pdae_stream_t stream);
+
+/* ---- GroupNorm(32,C) + AdaGN + SiLU (+Dropout, +AvgPool2d) : module.py:56-63,241,257-263,279-284,293-294,379-381 */
+size_t pdae_gn_workspace_bytes(int N, int C);
+int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, void* ws,
+                  pdae_stream_t stream);
+/* coef[3][N][C] = (mu, a, b) such that v = a*(x-mu)+b equals (1+zs)*((GN(x))*(1+s)+sh)+zsh; ss/zss = [N][2C] (scale|shift) or NULL */
+int pdae_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss,
+                 const float* zss, float* coef, pdae_stream_t stream);
+/* y = act(v) * dropmask; act: 0 identity, 1 SiLU.  mode 0: same size; mode 1: y (and xpool = raw x) are 2x2 average pooled. */
+int pdae_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, const float* coef, int act, int mode, float* y,
+                  float* xpool, float drop_p, uint64_t seed, uint64_t offset, pdae_stream_t stream);
+/* backward of stats+coef+apply.  dA = grad wrt y (mode 0: [N,H,W,C]; 1: [N,H/2,W/2,C]; 2: [N,2H,2W,C] when the consumer read y upsampled).
+ * add (optional, resampled like dA) is added into dx (identity skip path).  dx0/dx1 receive the two concat halves (NULL = skip). */
+int pdae_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
+                const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p,
+                uint64_t seed, uint64_t offset, const float* add, float* dx0, int acc0, float* dx1, int acc1, float* dgamma, float* dbeta,
+                int acc_param, float* dss, float* dzss, void* ws, pdae_stream_t stream);
+
+/* ---- small elementwise pieces */
+int pdae_timestep_embedding(const int64_t* t, const float* freqs, int N, int dim, float* out, pdae_stream_t stream); /* module.py:66-84 */
+int pdae_silu(const float* x, float* y, size_t n, pdae_stream_t stream);
+int pdae_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int accumulate, pdae_stream_t stream);
+int pdae_axpby(const float* x, float* y, size_t n, float alpha, float beta, pdae_stream_t stream);
+int pdae_embedding(const float* table, const int64_t* idx, int N, int D, float* out, int accumulate, pdae_stream_t stream); /* unet.py:190-192 */
+int pdae_embedding_bwd(const float* dout, const int64_t* idx, int N, int D, float* dtable, pdae_stream_t stream);
+int pdae_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int N, int C, int H, int W, float* y, pdae_stream_t stream);
+int pdae_from_nhwc(const float* x, int N, int C, int H, int W, float* y, int64_t sn, int64_t sc, int64_t sh, int64_t sw, pdae_stream_t stream);
+int pdae_softmax(float* s, int64_t rows, int T, pdae_stream_t stream);                         /* module.py:455 */
+int pdae_softmax_bwd(const float* p, float* dp, int64_t rows, int T, pdae_stream_t stream);
+size_t pdae_colsum_workspace_bytes(int64_t M, int C);
+int pdae_colsum(const float* x, int64_t M, int C, float* out, int accumulate, void* ws, pdae_stream_t stream); /* bias gradients */
+
+/* ---- diffusion (gaussian_diffusion.py / ddim.py) */
+int pdae_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac, int N, size_t per_sample,
+                  float* xt, pdae_stream_t stream);                                             /* gaussian_diffusion.py:98-103 */
+/* loss = scale*mean(w[t]*(noise-(eps+c[t]*g))^2) (or |.| when l1); deps/dg = dloss/d(eps|g) or NULL; ws >= 4 KiB */
+int pdae_loss(const float* noise, const float* eps, const float* g, const int64_t* t, const float* shift_coef, const float* weight, int N,
+              size_t per_sample, int l1, float scale, float* loss, float* deps, float* dg, void* ws, pdae_stream_t stream); /* :166-175,246-251 */
+int pdae_ddim_step(const float* x, const float* eps, const float* g, size_t total, float c_shift, float sqrt_recip_ac, float sqrt_recip_ac_m1,
+                   float sqrt_ac_to, float sqrt_1m_ac_to, int clamp, float* out, pdae_stream_t stream);    /* ddim.py:46-55,94-107,126-138 */
+int pdae_ddpm_step(const float* x, const float* eps, const float* g, const float* z, size_t total, float cx, float ce, float cs, float sigma,
+                   float* out, pdae_stream_t stream);                                            /* gaussian_diffusion.py:112-126 */
+
+/* ---- optimizer: torch.optim.Adam / AdamW + EMA (train_representation_learning.py:58-70,192-212) over a flat segment */
+int pdae_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, pdae_stream_t stream);
+
+/* ---- planned-graph executor: a network pass is a static array of ops, issued back-to-back on one stream
+ * with a single host call (replaces the per-module Python dispatch of TimestepSequential, module.py:131-140). */
+enum {
+  PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
+  PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
+  PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY
+};
+typedef struct pdae_op {
+  int32_t kind;
+  int32_t reserved;
+  void* p[20];     /* pointer arguments, in the order of the corresponding function's pointer parameters */
+  int64_t i[24];   /* integer arguments, in order (a pdae_conv_desc is flattened to its 13 fields) */
+  double f[12];    /* floating-point arguments, in order */
+} pdae_op;
+/* returns 0, or the first failing op's status (its index is in pdae_last_error()). */
+int pdae_run_ops(const pdae_op* ops, int n, pdae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,302 @@
+// C ABI of libpdae_hip.so (see include/pdae_hip.h): argument validation, GEMM parameter blocks for the
+// convolution entry points, and the planned-graph executor.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pdae_hip.h"
+#include "common.h"
+#include "igemm.h"
+#include "kernels.h"
+
+static thread_local char g_err[512] = "";
+
+void pdae_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* pdae_last_error(void) { return g_err; }
+extern "C" int pdae_abi_version(void) { return 1; }
+
+static inline hipStream_t S(pdae_stream_t s) { return (hipStream_t)s; }
+
+static int check_desc(const pdae_conv_desc* d) {
+  PDAE_CHECK_ARG(d && d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad dims");
+  PDAE_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2");
+  PDAE_CHECK_ARG(!(d->up && d->stride != 1), "conv: up with stride!=1");
+  int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
+  PDAE_CHECK_ARG(d->Ho == (Hl + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (Wl + 2 * d->pad - d->KW) / d->stride + 1,
+                 "conv: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d->Ho, d->Wo, Hl, Wl, d->KH, d->stride, d->pad);
+  PDAE_CHECK_ARG((long long)d->N * Hl * Wl < (1ll << 31) && (long long)d->N * d->Ho * d->Wo < (1ll << 31), "conv: too many pixels");
+  return PDAE_OK;
+}
+
+static void fwd_geom(ConvGeom& g, const pdae_conv_desc* d, const float* x0, const float* x1) {
+  g.src0 = x0; g.src1 = x1; g.C0 = d->C0; g.C1 = d->C1; g.Cin = d->C0 + d->C1;
+  g.Hs = d->Hi; g.Ws = d->Wi; g.Hl = d->up ? 2 * d->Hi : d->Hi; g.Wl = d->up ? 2 * d->Wi : d->Wi;
+  g.Ho = d->Ho; g.Wo = d->Wo; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.up = d->up; g.dil = 0;
+}
+
+extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const float* bias, const float* res,
+                               int res_mode, float* y, int tile, pdae_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
+  PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd: res_mode without res");
+  PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd: res_mode 2 needs even output");
+  GemmParams P;
+  memset(&P, 0, sizeof(P));
+  fwd_geom(P.a.g, d, x0, x1);
+  P.M = d->N * d->Ho * d->Wo; P.N = d->Cout; P.K = d->KH * d->KW * (d->C0 + d->C1);
+  P.splitk = 1; P.kchunk = P.K; P.Bi = 1;
+  P.b.p = w; P.b.ld = P.K;
+  P.C = y; P.ldc = d->Cout; P.bias = bias; P.res = res_mode ? res : nullptr; P.ldr = d->Cout; P.res_mode = res_mode;
+  P.rHo = d->Ho; P.rWo = d->Wo; P.alpha = 1.0f; P.accumulate = 0;
+  return igemm_conv_fwd(P, tile, S(stream));
+}
+
+extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, float* dx, int ci_off, int ci_cnt, int accumulate,
+                                 int tile, pdae_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  const int Cin = d->C0 + d->C1;
+  PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
+  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
+  PDAE_CHECK_ARG(d->stride == 1 || (Hl == 2 * d->Ho && Wl == 2 * d->Wo), "conv2d_dgrad: stride 2 needs even input");
+  GemmParams P;
+  memset(&P, 0, sizeof(P));
+  ConvGeom& g = P.a.g;
+  g.src0 = dy; g.src1 = nullptr; g.C0 = d->Cout; g.C1 = 0; g.Cin = d->Cout;
+  g.Hs = d->Ho; g.Ws = d->Wo; g.dil = d->stride == 2; g.up = 0;
+  g.Hl = g.dil ? 2 * d->Ho : d->Ho; g.Wl = g.dil ? 2 * d->Wo : d->Wo;
+  g.Ho = Hl; g.Wo = Wl; g.KH = d->KH; g.KW = d->KW; g.stride = 1; g.pad = d->KH - 1 - d->pad;
+  PDAE_CHECK_ARG(d->KH == d->KW, "conv2d_dgrad: square kernels only");
+  P.M = d->N * Hl * Wl; P.N = ci_cnt; P.K = d->KH * d->KW * d->Cout;
+  P.splitk = 1; P.kchunk = P.K; P.Bi = 1;
+  P.b.p = w; P.b.dgT = d->KH * d->KW; P.b.dgCout = d->Cout; P.b.dgWCin = Cin; P.b.dgCiOff = ci_off;
+  P.C = dx; P.ldc = ci_cnt; P.alpha = 1.0f; P.accumulate = accumulate;
+  return igemm_conv_dgrad(P, tile, S(stream));
+}
+
+static void wgrad_plan(const pdae_conv_desc* d, int& tile, int& splits, int& kchunk) {
+  const long long M = d->Cout, N = (long long)d->KH * d->KW * (d->C0 + d->C1), K = (long long)d->N * d->Ho * d->Wo;
+  tile = (M >= 96 && N >= 96) ? 128 : 64;
+  long long tiles = (long long)cdiv(M, tile) * cdiv(N, tile);
+  long long want = cdiv(768, tiles);
+  long long maxs = K / 256; if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want > 256) want = 256;
+  kchunk = (int)(((K + want - 1) / want + 31) / 32 * 32);
+  splits = cdiv(K, kchunk);
+}
+
+extern "C" size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d) {
+  int tile, splits, kchunk;
+  wgrad_plan(d, tile, splits, kchunk);
+  if (splits <= 1) return 16;
+  return (size_t)splits * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
+}
+
+extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, int accumulate, void* ws,
+                                 size_t ws_bytes, pdae_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  PDAE_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "conv2d_wgrad: null pointer");
+  int tile, splits, kchunk;
+  wgrad_plan(d, tile, splits, kchunk);
+  GemmParams P;
+  memset(&P, 0, sizeof(P));
+  fwd_geom(P.b.g, d, x0, x1);
+  P.M = d->Cout; P.N = d->KH * d->KW * (d->C0 + d->C1); P.K = d->N * d->Ho * d->Wo;
+  P.a.p = dy; P.a.ld = d->Cout;
+  P.Bi = 1; P.alpha = 1.0f;
+  const long long MN = (long long)P.M * P.N;
+  if (splits <= 1) {
+    P.splitk = 1; P.kchunk = P.K; P.C = dw; P.ldc = P.N; P.accumulate = accumulate;
+    return igemm_conv_wgrad(P, tile, 1, S(stream));
+  }
+  PDAE_CHECK_ARG(ws && ws_bytes >= (size_t)splits * MN * sizeof(float), "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes,
+                 (size_t)splits * MN * sizeof(float));
+  P.splitk = splits; P.kchunk = kchunk; P.split_stride = MN; P.C = (float*)ws; P.ldc = P.N; P.accumulate = 0;
+  if (int e = igemm_conv_wgrad(P, tile, splits, S(stream))) return e;
+  return igemm_splitk_reduce((const float*)ws, dw, MN, splits, accumulate, S(stream));
+}
+
+extern "C" int pdae_gemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda, int64_t sAo, int64_t sAi,
+                         const float* B, int64_t ldb, int64_t sBo, int64_t sBi, float* C, int64_t ldc, int64_t sCo, int64_t sCi, int batch_outer,
+                         int batch_inner, const float* bias, int accumulate, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch_outer > 0 && batch_inner > 0, "gemm: bad arguments");
+  GemmParams P;
+  memset(&P, 0, sizeof(P));
+  P.M = M; P.N = N; P.K = K; P.splitk = 1; P.kchunk = K; P.Bi = batch_inner;
+  P.a.p = A; P.a.ld = lda; P.a.so = sAo; P.a.si = sAi;
+  P.b.p = B; P.b.ld = ldb; P.b.so = sBo; P.b.si = sBi;
+  P.C = C; P.ldc = ldc; P.sCo = sCo; P.sCi = sCi; P.bias = bias; P.alpha = alpha; P.accumulate = accumulate;
+  return igemm_dense(transA, transB, P, batch_outer * batch_inner, S(stream));
+}
+
+// ---- GroupNorm family
+extern "C" size_t pdae_gn_workspace_bytes(int N, int C) { return k_gn_workspace_floats(N, C) * sizeof(float); }
+extern "C" int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, void* ws,
+                             pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x0 && mean && rstd && ws && (C1 == 0 || x1), "gn_stats: null pointer");
+  return k_gn_stats(x0, C0, x1, C1, N, HW, G, eps, mean, rstd, (float*)ws, S(stream));
+}
+extern "C" int pdae_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss,
+                            const float* zss, float* coef, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(mean && rstd && gamma && beta && coef && C % G == 0, "gn_coef: bad arguments");
+  return k_gn_coef(N, C, G, mean, rstd, gamma, beta, ss, zss, coef, S(stream));
+}
+extern "C" int pdae_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, const float* coef, int act, int mode, float* y,
+                             float* xpool, float drop_p, uint64_t seed, uint64_t offset, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x0 && coef && y && (C1 == 0 || x1), "gn_apply: null pointer");
+  return k_gn_apply(x0, C0, x1, C1, N, H, W, coef, act, mode, y, xpool, drop_p, seed, offset, S(stream));
+}
+extern "C" int pdae_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
+                           const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode,
+                           float drop_p, uint64_t seed, uint64_t offset, const float* add, float* dx0, int acc0, float* dx1, int acc1,
+                           float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, void* ws, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x0 && coef && rstd && gamma && beta && dA && ws && (C1 == 0 || x1), "gn_bwd: null pointer");
+  PDAE_CHECK_ARG(mode >= 0 && mode <= 2 && (mode != 1 || ((H % 2) == 0 && (W % 2) == 0)), "gn_bwd: bad mode");
+  PDAE_CHECK_ARG((!dss || ss) && (!dzss || zss) && (!dgamma || dbeta), "gn_bwd: gradient requested for an absent input");
+  return k_gn_bwd(x0, C0, x1, C1, N, H, W, G, coef, rstd, gamma, beta, ss, zss, dA, act, mode, drop_p, seed, offset, add, dx0, acc0, dx1, acc1,
+                  dgamma, dbeta, acc_param, dss, dzss, (float*)ws, S(stream));
+}
+
+// ---- elementwise
+extern "C" int pdae_timestep_embedding(const int64_t* t, const float* freqs, int N, int dim, float* out, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(t && freqs && out && N > 0 && dim > 1, "timestep_embedding: bad arguments");
+  return k_timestep_embedding((const long long*)t, freqs, N, dim, out, S(stream));
+}
+extern "C" int pdae_silu(const float* x, float* y, size_t n, pdae_stream_t stream) { return k_silu(x, y, n, S(stream)); }
+extern "C" int pdae_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int acc, pdae_stream_t stream) {
+  return k_silu_bwd(x, dy, dx, n, acc, S(stream));
+}
+extern "C" int pdae_axpby(const float* x, float* y, size_t n, float alpha, float beta, pdae_stream_t stream) {
+  return k_axpby(x, y, n, alpha, beta, S(stream));
+}
+extern "C" int pdae_embedding(const float* table, const int64_t* idx, int N, int D, float* out, int acc, pdae_stream_t stream) {
+  return k_embedding(table, (const long long*)idx, N, D, out, acc, S(stream));
+}
+extern "C" int pdae_embedding_bwd(const float* dout, const int64_t* idx, int N, int D, float* dtable, pdae_stream_t stream) {
+  return k_embedding_bwd(dout, (const long long*)idx, N, D, dtable, S(stream));
+}
+extern "C" int pdae_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int N, int C, int H, int W, float* y,
+                            pdae_stream_t stream) {
+  return k_to_nhwc(x, sn, sc, sh, sw, N, C, H, W, y, S(stream));
+}
+extern "C" int pdae_from_nhwc(const float* x, int N, int C, int H, int W, float* y, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                              pdae_stream_t stream) {
+  return k_from_nhwc(x, N, C, H, W, y, sn, sc, sh, sw, S(stream));
+}
+extern "C" int pdae_softmax(float* s, int64_t rows, int T, pdae_stream_t stream) { return k_softmax(s, rows, T, S(stream)); }
+extern "C" int pdae_softmax_bwd(const float* p, float* dp, int64_t rows, int T, pdae_stream_t stream) {
+  return k_softmax_bwd(p, dp, rows, T, S(stream));
+}
+extern "C" size_t pdae_colsum_workspace_bytes(int64_t M, int C) { return k_colsum_workspace_floats(M, C) * sizeof(float); }
+extern "C" int pdae_colsum(const float* x, int64_t M, int C, float* out, int acc, void* ws, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x && out && ws && M > 0 && C > 0, "colsum: bad arguments");
+  return k_colsum(x, M, C, out, acc, (float*)ws, S(stream));
+}
+extern "C" int pdae_q_sample(const float* x0, const float* noise, const int64_t* t, const float* ta, const float* tb, int N, size_t per, float* xt,
+                             pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x0 && noise && t && ta && tb && xt, "q_sample: null pointer");
+  return k_q_sample(x0, noise, (const long long*)t, ta, tb, N, per, xt, S(stream));
+}
+extern "C" int pdae_loss(const float* noise, const float* eps, const float* g, const int64_t* t, const float* tc, const float* tw, int N, size_t per,
+                         int l1, float scale, float* loss, float* deps, float* dg, void* ws, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(noise && eps && loss && ws && (!g || (t && tc)) && (!tw || t), "loss: bad arguments");
+  return k_loss(noise, eps, g, (const long long*)t, tc, tw, N, per, l1, scale, loss, deps, dg, (float*)ws, S(stream));
+}
+extern "C" int pdae_ddim_step(const float* x, const float* eps, const float* g, size_t total, float c_shift, float ra, float rm1, float sab,
+                              float s1ab, int clamp, float* out, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x && eps && out, "ddim_step: null pointer");
+  return k_ddim_step(x, eps, g, total, c_shift, ra, rm1, sab, s1ab, clamp, out, S(stream));
+}
+extern "C" int pdae_ddpm_step(const float* x, const float* eps, const float* g, const float* z, size_t total, float cx, float ce, float cs,
+                              float sigma, float* out, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x && eps && out, "ddpm_step: null pointer");
+  return k_ddpm_step(x, eps, g, z, total, cx, ce, cs, sigma, out, S(stream));
+}
+extern "C" int pdae_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+                             int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(p && g && m && v, "adam_ema: null pointer");
+  return k_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay, S(stream));
+}
+
+// ---- planned-graph executor
+static void desc_from(const int64_t* i, pdae_conv_desc& d) {
+  d.N = (int)i[0]; d.Hi = (int)i[1]; d.Wi = (int)i[2]; d.C0 = (int)i[3]; d.C1 = (int)i[4]; d.Ho = (int)i[5]; d.Wo = (int)i[6]; d.Cout = (int)i[7];
+  d.KH = (int)i[8]; d.KW = (int)i[9]; d.stride = (int)i[10]; d.pad = (int)i[11]; d.up = (int)i[12];
+}
+
+static int run_one(const pdae_op& o, pdae_stream_t st) {
+  void* const* p = o.p; const int64_t* i = o.i; const double* f = o.f;
+#define F(k) ((const float*)p[k])
+#define FM(k) ((float*)p[k])
+  pdae_conv_desc d;
+  switch (o.kind) {
+    case PDAE_OP_CONV_FWD: desc_from(i, d); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), F(3), F(4), (int)i[13], FM(5), (int)i[14], st);
+    case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), FM(2), (int)i[13], (int)i[14], (int)i[15], (int)i[16], st);
+    case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), (int)i[13], p[4], (size_t)i[14], st);
+    case PDAE_OP_GEMM:
+      return pdae_gemm((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), i[5], i[6], i[7], F(1), i[8], i[9], i[10], FM(2),
+                       i[11], i[12], i[13], (int)i[14], (int)i[15], F(3), (int)i[16], st);
+    case PDAE_OP_GN_STATS: return pdae_gn_stats(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], FM(2), FM(3), p[4], st);
+    case PDAE_OP_GN_COEF: return pdae_gn_coef((int)i[0], (int)i[1], (int)i[2], F(0), F(1), F(2), F(3), F(4), F(5), FM(6), st);
+    case PDAE_OP_GN_APPLY:
+      return pdae_gn_apply(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], F(2), (int)i[5], (int)i[6], FM(3), FM(4), (float)f[0],
+                           (uint64_t)i[7], (uint64_t)i[8], st);
+    case PDAE_OP_GN_BWD:
+      return pdae_gn_bwd(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], F(2), F(3), F(4), F(5), F(6), F(7), F(8),
+                         (int)i[6], (int)i[7], (float)f[0], (uint64_t)i[11], (uint64_t)i[12], F(9), FM(10), (int)i[8], FM(11), (int)i[9], FM(12),
+                         FM(13), (int)i[10], FM(14), FM(15), p[16], st);
+    case PDAE_OP_TEMB: return pdae_timestep_embedding((const int64_t*)p[0], F(1), (int)i[0], (int)i[1], FM(2), st);
+    case PDAE_OP_SILU: return pdae_silu(F(0), FM(1), (size_t)i[0], st);
+    case PDAE_OP_SILU_BWD: return pdae_silu_bwd(F(0), F(1), FM(2), (size_t)i[0], (int)i[1], st);
+    case PDAE_OP_AXPBY: return pdae_axpby(F(0), FM(1), (size_t)i[0], (float)f[0], (float)f[1], st);
+    case PDAE_OP_EMBEDDING: return pdae_embedding(F(0), (const int64_t*)p[1], (int)i[0], (int)i[1], FM(2), (int)i[2], st);
+    case PDAE_OP_EMBEDDING_BWD: return pdae_embedding_bwd(F(0), (const int64_t*)p[1], (int)i[0], (int)i[1], FM(2), st);
+    case PDAE_OP_TO_NHWC: return pdae_to_nhwc(F(0), i[0], i[1], i[2], i[3], (int)i[4], (int)i[5], (int)i[6], (int)i[7], FM(1), st);
+    case PDAE_OP_FROM_NHWC: return pdae_from_nhwc(F(0), (int)i[4], (int)i[5], (int)i[6], (int)i[7], FM(1), i[0], i[1], i[2], i[3], st);
+    case PDAE_OP_Q_SAMPLE: return pdae_q_sample(F(0), F(1), (const int64_t*)p[2], F(3), F(4), (int)i[0], (size_t)i[1], FM(5), st);
+    case PDAE_OP_LOSS:
+      return pdae_loss(F(0), F(1), F(2), (const int64_t*)p[3], F(4), F(5), (int)i[0], (size_t)i[1], (int)i[2], (float)f[0], FM(6), FM(7), FM(8), p[9], st);
+    case PDAE_OP_DDIM_STEP:
+      return pdae_ddim_step(F(0), F(1), F(2), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (int)i[1], FM(3), st);
+    case PDAE_OP_DDPM_STEP:
+      return pdae_ddpm_step(F(0), F(1), F(2), F(3), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], FM(4), st);
+    case PDAE_OP_ADAM_EMA:
+      return pdae_adam_ema(FM(0), F(1), FM(2), FM(3), FM(4), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (int)i[1],
+                           (float)f[5], (float)f[6], (float)f[7], (float)f[8], st);
+    case PDAE_OP_SOFTMAX: return pdae_softmax(FM(0), i[0], (int)i[1], st);
+    case PDAE_OP_SOFTMAX_BWD: return pdae_softmax_bwd(F(0), FM(1), i[0], (int)i[1], st);
+    case PDAE_OP_COLSUM: return pdae_colsum(F(0), i[0], (int)i[1], FM(1), (int)i[2], p[2], st);
+    case PDAE_OP_MEMSET: {
+      hipError_t e = hipMemsetAsync(p[0], 0, (size_t)i[0], S(st));
+      if (e != hipSuccess) { pdae_set_error("memset: %s", hipGetErrorString(e)); return (int)e; }
+      return PDAE_OK;
+    }
+    case PDAE_OP_COPY: {
+      hipError_t e = hipMemcpyAsync(p[1], p[0], (size_t)i[0], hipMemcpyDeviceToDevice, S(st));
+      if (e != hipSuccess) { pdae_set_error("copy: %s", hipGetErrorString(e)); return (int)e; }
+      return PDAE_OK;
+    }
+    default: pdae_set_error("run_ops: unknown op kind %d", o.kind); return PDAE_EINVAL;
+  }
+#undef F
+#undef FM
+}
+
+extern "C" int pdae_run_ops(const pdae_op* ops, int n, pdae_stream_t stream) {
+  for (int k = 0; k < n; ++k) {
+    int e = run_one(ops[k], stream);
+    if (e != PDAE_OK) {
+      char msg[400];
+      snprintf(msg, sizeof(msg), "%s", g_err);
+      pdae_set_error("op %d (kind %d): %s", k, ops[k].kind, msg);
+      return e;
+    }
+  }
+  return PDAE_OK;
+}

@@ -1,0 +1,301 @@
+// HBM-bound elementwise / reduction kernels of the PDAE hot path (fp32).
+//
+// Reference ops replaced (file:line in ckczzj/PDAE):
+//   timestep_embedding            model/module.py:66-84
+//   q_sample                      diffusion/gaussian_diffusion.py:98-103
+//   weighted-L2 / L1 loss (+grad) diffusion/gaussian_diffusion.py:166-175, 246-251
+//   DDIM update                   diffusion/ddim.py:46-55, 69-79, 94-107, 126-138
+//   DDPM ancestral update         diffusion/gaussian_diffusion.py:112-126
+//   Adam / AdamW + EMA            trainer/train_representation_learning.py:58-70, 192-212
+//   softmax (attention)           model/module.py:455
+//   NCHW<->NHWC at the boundary, bias-gradient column sums, SiLU on embedding vectors
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ float siluf(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float dsiluf(float v) {
+  float sg = 1.0f / (1.0f + expf(-v));
+  return sg * (1.0f + v * (1.0f - sg));
+}
+static int ew_grid(size_t total, int per = 1) { size_t b = (total + 256 * per - 1) / (256 * per); if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+
+// ---------------------------------------------------------------------------------------------
+__global__ void temb_kernel(const long long* __restrict__ t, const float* __restrict__ freqs, int N, int half, int dim, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * dim) return;
+  int n = i / dim, j = i - n * dim;
+  float tv = (float)t[n];
+  float v = 0.f;
+  if (j < half) v = cosf(tv * freqs[j]);
+  else if (j < 2 * half) v = sinf(tv * freqs[j - half]);
+  out[i] = v;
+}
+int k_timestep_embedding(const long long* t, const float* freqs, int N, int dim, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(temb_kernel, dim3(cdiv((long long)N * dim, 256)), dim3(256), 0, st, t, freqs, N, dim / 2, dim, out);
+  return pdae_launch_status("timestep_embedding");
+}
+
+// y = silu(x) ; dx (+)= dy * silu'(x)
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = siluf(x[i]);
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, size_t n, int acc) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float v = dy[i] * dsiluf(x[i]);
+    dx[i] = acc ? dx[i] + v : v;
+  }
+}
+int k_silu(const float* x, float* y, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(silu_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, y, n);
+  return pdae_launch_status("silu");
+}
+int k_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int acc, hipStream_t st) {
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, dy, dx, n, acc);
+  return pdae_launch_status("silu_bwd");
+}
+
+// y = alpha*x + beta*y
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float alpha, float beta) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = alpha * x[i] + (beta != 0.f ? beta * y[i] : 0.f);
+}
+int k_axpby(const float* x, float* y, size_t n, float alpha, float beta, hipStream_t st) {
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, y, n, alpha, beta);
+  return pdae_launch_status("axpby");
+}
+
+// out[n, :] (+)= table[idx[n], :]   (nn.Embedding row gather, model/unet.py:190-192)  and its scatter-add backward
+__global__ void embedding_kernel(const float* __restrict__ table, const long long* __restrict__ idx, int N, int D, float* __restrict__ out, int acc) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D) return;
+  int n = i / D, j = i - n * D;
+  float v = table[(size_t)idx[n] * D + j];
+  out[i] = acc ? out[i] + v : v;
+}
+__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ idx, int N, int D, float* __restrict__ dtable) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per column, rows visited in order: deterministic
+  if (j >= D) return;
+  for (int n = 0; n < N; ++n) dtable[(size_t)idx[n] * D + j] += dout[(size_t)n * D + j];
+}
+int k_embedding(const float* table, const long long* idx, int N, int D, float* out, int acc, hipStream_t st) {
+  hipLaunchKernelGGL(embedding_kernel, dim3(cdiv((long long)N * D, 256)), dim3(256), 0, st, table, idx, N, D, out, acc);
+  return pdae_launch_status("embedding");
+}
+int k_embedding_bwd(const float* dout, const long long* idx, int N, int D, float* dtable, hipStream_t st) {
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(cdiv(D, 128)), dim3(128), 0, st, dout, idx, N, D, dtable);
+  return pdae_launch_status("embedding_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout: strided [N,C,H,W] view <-> packed NHWC.  sn/sc/sh/sw are element strides of the 4-D view.
+// ---------------------------------------------------------------------------------------------
+__global__ void to_nhwc_kernel(const float* __restrict__ x, long long sn, long long sc, long long sh, long long sw, int N, int C, int H, int W,
+                               float* __restrict__ y) {
+  size_t total = (size_t)N * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % C); size_t p = i / C; int w = (int)(p % W); p /= W; int h = (int)(p % H); int n = (int)(p / H);
+    y[i] = x[n * sn + c * sc + h * sh + w * sw];
+  }
+}
+__global__ void from_nhwc_kernel(const float* __restrict__ x, int N, int C, int H, int W, float* __restrict__ y, long long sn, long long sc,
+                                 long long sh, long long sw) {
+  size_t total = (size_t)N * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    // iterate in destination-friendly order when the destination is NCHW-contiguous (sw == 1): i = ((n*C + c)*H + h)*W + w
+    int w = (int)(i % W); size_t p = i / W; int h = (int)(p % H); p /= H; int c = (int)(p % C); int n = (int)(p / C);
+    y[n * sn + c * sc + h * sh + w * sw] = x[(((size_t)n * H + h) * W + w) * C + c];
+  }
+}
+int k_to_nhwc(const float* x, long long sn, long long sc, long long sh, long long sw, int N, int C, int H, int W, float* y, hipStream_t st) {
+  hipLaunchKernelGGL(to_nhwc_kernel, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, st, x, sn, sc, sh, sw, N, C, H, W, y);
+  return pdae_launch_status("to_nhwc");
+}
+int k_from_nhwc(const float* x, int N, int C, int H, int W, float* y, long long sn, long long sc, long long sh, long long sw, hipStream_t st) {
+  hipLaunchKernelGGL(from_nhwc_kernel, dim3(ew_grid((size_t)N * C * H * W)), dim3(256), 0, st, x, N, C, H, W, y, sn, sc, sh, sw);
+  return pdae_launch_status("from_nhwc");
+}
+
+// ---------------------------------------------------------------------------------------------
+// diffusion elementwise.  `per` = elements per sample; tables are device fp32 arrays indexed by t[n].
+// ---------------------------------------------------------------------------------------------
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
+                                const float* __restrict__ ta, const float* __restrict__ tb, size_t per, size_t total, float* __restrict__ xt) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    long long ti = t[i / per];
+    xt[i] = ta[ti] * x0[i] + tb[ti] * noise[i];
+  }
+}
+int k_q_sample(const float* x0, const float* noise, const long long* t, const float* ta, const float* tb, int N, size_t per, float* xt, hipStream_t st) {
+  hipLaunchKernelGGL(q_sample_kernel, dim3(ew_grid(per * N)), dim3(256), 0, st, x0, noise, t, ta, tb, per, per * N, xt);
+  return pdae_launch_status("q_sample");
+}
+
+// loss = scale * mean( w[t] * f(noise - (eps + c[t]*g)) ), f = square (l2) or abs (l1); grads of the same.
+// tc/tw/g may be null (plain eps-prediction loss).  Two-stage deterministic reduction.
+__global__ void __launch_bounds__(256) loss_kernel(const float* __restrict__ noise, const float* __restrict__ eps, const float* __restrict__ g,
+                                                   const long long* __restrict__ t, const float* __restrict__ tc, const float* __restrict__ tw,
+                                                   size_t per, size_t total, int l1, float scale, float* __restrict__ deps, float* __restrict__ dg,
+                                                   float* __restrict__ partial) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  const float inv = scale / (float)total;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    long long ti = t ? t[i / per] : 0;
+    float c = (g && tc) ? tc[ti] : 0.f;
+    float w = tw ? tw[ti] : 1.f;
+    float pred = eps[i] + (g ? c * g[i] : 0.f);
+    float d = noise[i] - pred;
+    float gr;
+    if (l1) { acc += w * fabsf(d); gr = -w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv; }
+    else { acc += w * d * d; gr = -2.0f * w * d * inv; }
+    if (deps) deps[i] = gr;
+    if (dg) dg[i] = gr * c;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void loss_final_kernel(const float* __restrict__ partial, int n, float inv, float* __restrict__ out) {
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] * inv);
+}
+int k_loss(const float* noise, const float* eps, const float* g, const long long* t, const float* tc, const float* tw, int N, size_t per, int l1,
+           float scale, float* loss, float* deps, float* dg, float* ws, hipStream_t st) {
+  size_t total = per * N;
+  int nb = ew_grid(total, 4); if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(loss_kernel, dim3(nb), dim3(256), 0, st, noise, eps, g, t, tc, tw, per, total, l1, scale, deps, dg, ws);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, ws, nb, scale / (float)total, loss);
+  return pdae_launch_status("loss");
+}
+
+// DDIM update (eta = 0) with x0 clamp and eps re-derivation; all samples share the step, so the five
+// schedule values arrive as scalars.  use_shift: eps -= c_shift * g  (ddim.py:94-96).
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ g, size_t total,
+                                 float c_shift, float ra, float rm1, float sab, float s1ab, int clamp, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float e = eps[i];
+    if (g) e = e - c_shift * g[i];
+    float rx = ra * x[i];
+    float x0 = rx - rm1 * e;
+    float ne = e;
+    if (clamp) { x0 = fminf(fmaxf(x0, -1.0f), 1.0f); ne = (rx - x0) / rm1; }
+    out[i] = x0 * sab + s1ab * ne;
+  }
+}
+int k_ddim_step(const float* x, const float* eps, const float* g, size_t total, float c_shift, float ra, float rm1, float sab, float s1ab,
+                int clamp, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, eps, g, total, c_shift, ra, rm1, sab, s1ab, clamp, out);
+  return pdae_launch_status("ddim_step");
+}
+
+// DDPM ancestral step: out = cx*x - ce*(eps + cs*g) + sigma*z   (gaussian_diffusion.py:112-126, 268-269)
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ g, const float* __restrict__ z,
+                                 size_t total, float cx, float ce, float cs, float sigma, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float e = eps[i] + (g ? cs * g[i] : 0.f);
+    out[i] = cx * x[i] - ce * e + (z ? sigma * z[i] : 0.f);
+  }
+}
+int k_ddpm_step(const float* x, const float* eps, const float* g, const float* z, size_t total, float cx, float ce, float cs, float sigma,
+                float* out, hipStream_t st) {
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, eps, g, z, total, cx, ce, cs, sigma, out);
+  return pdae_launch_status("ddpm_step");
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused Adam/AdamW + EMA over a flat parameter segment.  step_size = lr/bc1, inv_sqrt_bc2 = 1/sqrt(bc2)
+// computed on the host in double.  grad_scale folds the 1/world_size of the all-reduce(sum).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                       float* __restrict__ ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                                       int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float pi = p[i], gi = g[i] * grad_scale;
+    if (decoupled) pi *= (1.0f - lr * wd);
+    else if (wd != 0.f) gi += wd * pi;
+    float mi = m[i] * b1 + (1.0f - b1) * gi;
+    float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (ema) ema[i] = ema[i] * ema_decay + pi * (1.0f - ema_decay);
+  }
+}
+int k_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
+               int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, hipStream_t st) {
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, st, p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size,
+                     inv_sqrt_bc2, grad_scale, ema_decay);
+  return pdae_launch_status("adam_ema");
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax over rows of length T (one wave per row), and its backward  dS = P*(dP - sum(dP*P))
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+
+__global__ void __launch_bounds__(256) softmax_kernel(float* __restrict__ s, long long rows, int T) {
+  long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float* r = s + row * T;
+  float mx = -INFINITY;
+  for (int j = lane; j < T; j += 64) mx = fmaxf(mx, r[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < T; j += 64) { float e = expf(r[j] - mx); r[j] = e; sum += e; }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < T; j += 64) r[j] *= inv;
+}
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp, long long rows, int T) {
+  long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* pr = p + row * T; float* dr = dp + row * T;
+  float dot = 0.f;
+  for (int j = lane; j < T; j += 64) dot += pr[j] * dr[j];
+  dot = wave_sum(dot);
+  for (int j = lane; j < T; j += 64) dr[j] = pr[j] * (dr[j] - dot);
+}
+int k_softmax(float* s, long long rows, int T, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s, rows, T);
+  return pdae_launch_status("softmax");
+}
+int k_softmax_bwd(const float* p, float* dp, long long rows, int T, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, p, dp, rows, T);
+  return pdae_launch_status("softmax_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums of a row-major [M][C] matrix (bias gradients), two deterministic stages
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, long long M, int C, int rows_per, float* __restrict__ part) {
+  // block handles rows [b*rows_per, ...), thread handles columns c = threadIdx.x + 256*k
+  long long r0 = (long long)blockIdx.x * rows_per, r1 = r0 + rows_per; if (r1 > M) r1 = M;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (long long r = r0; r < r1; ++r) a += x[r * C + c];
+    part[(size_t)blockIdx.x * C + c] = a;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out, int acc) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int b = 0; b < nb; ++b) a += part[(size_t)b * C + c];
+  out[c] = acc ? out[c] + a : a;
+}
+size_t k_colsum_workspace_floats(long long M, int C) { return (size_t)1024 * C; }
+int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws, hipStream_t st) {
+  int nb = (int)(M < 1024 ? M : 1024);
+  int rows_per = cdiv(M, nb); nb = cdiv(M, rows_per);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, M, C, rows_per, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, nb, C, out, acc);
+  return pdae_launch_status("colsum");
+}

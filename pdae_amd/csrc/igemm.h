@@ -1,0 +1,49 @@
+// Parameter blocks of the f32-MFMA implicit-GEMM kernel family (internal; the C ABI is include/pdae_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { OP_CONV_KC = 0, OP_DENSE_KC = 1, OP_DENSE_OC = 2, OP_DGRAD_OC = 3, OP_GATHER_OC = 4 };
+
+// Gather geometry over NHWC activations (optionally a virtual channel-concat of two tensors).
+struct ConvGeom {
+  const float* src0;
+  const float* src1;
+  int C0, C1, Cin;   // channels of src0 / src1, Cin = C0 + C1
+  int Hs, Ws;        // stored spatial size
+  int Hl, Wl;        // logical size seen by the taps (2x when `up` or `dil`)
+  int Ho, Wo;        // spatial size of the GEMM rows (output pixels)
+  int KH, KW, stride, pad;
+  int up;            // logical = nearest-upsample x2 of stored
+  int dil;           // logical = zero-dilation x2 of stored (dgrad of a stride-2 conv)
+};
+
+struct OpParams {
+  const float* p;    // dense / dgrad base pointer
+  long long ld;      // leading dimension (dense)
+  long long so, si;  // outer / inner batch strides (dense)
+  ConvGeom g;        // CONV_KC / GATHER_OC
+  int dgT, dgCout, dgWCin, dgCiOff;   // DGRAD_OC: taps, Cout, weight Cin, first input channel
+};
+
+struct GemmParams {
+  int M, N, K;
+  int splitk, kchunk;          // split-K over blockIdx.z when splitk > 1 (kchunk multiple of 32)
+  long long split_stride;      // workspace stride between splits (= M*N)
+  int Bi;                      // inner batch count when splitk == 1 (blockIdx.z = bo*Bi + bi)
+  OpParams a, b;
+  float* C;
+  long long ldc, sCo, sCi;
+  const float* bias;           // [N] or null
+  const float* res;            // residual or null
+  long long ldr;
+  int res_mode;                // 0 none, 1 same row index, 2 residual stored at half resolution (nearest-up)
+  int rHo, rWo;                // output spatial dims for res_mode 2
+  float alpha;
+  int accumulate;              // C += ...
+};
+
+int igemm_conv_fwd(const GemmParams& P, int tile, hipStream_t s);
+int igemm_conv_dgrad(const GemmParams& P, int tile, hipStream_t s);
+int igemm_conv_wgrad(const GemmParams& P, int tile, int splits, hipStream_t s);
+int igemm_splitk_reduce(const float* ws, float* out, long long n, int splits, int accumulate, hipStream_t s);
+int igemm_dense(int transA, int transB, const GemmParams& P, int zdim, hipStream_t s);

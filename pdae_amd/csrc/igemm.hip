@@ -1,0 +1,437 @@
+// f32-MFMA implicit-GEMM family for gfx950 (CDNA4).
+//
+// One kernel template serves every GEMM-shaped op on the PDAE hot path:
+//   conv fwd   : A = im2col gather of NHWC activations (K-contiguous), B = weights [Cout][KH*KW*Cin]
+//   conv dgrad : A = gather of dY (flipped taps, zero-dilated for stride 2), B = weights read "N-contiguous"
+//   conv wgrad : A = dY^T (M-contiguous), B = gather of activations (N-contiguous), split-K over pixels
+//   dense GEMM : NT / NN / TN strided-batched (attention QK^T, PV, their grads; Linear fwd/bwd)
+//
+// Arithmetic is exact fp32: v_mfma_f32_32x32x2_f32 (one rounding per product, fmaf chain,
+// MI355X_MICROARCH.md "Matrix cores").  That instruction issues once per 64 cycles per SIMD, which
+// leaves ample slack for the gather/predication VALU work, so the tiles are staged global->reg->LDS
+// with the next tile's global loads in flight under the current tile's MFMAs (guide T14).
+//
+// Reference ops replaced: F.conv2d / F.conv1d(k=1) / F.linear / torch.einsum in
+// model/module.py:242,265,276,412,420,450-457 and their autograd backward.
+#include "common.h"
+#include "igemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32
+#define LDK 36          // K-contiguous LDS row stride (floats): 16 rows hit 16 distinct 4-bank slots for ds_read_b128
+
+__device__ __forceinline__ bool map_pix(const ConvGeom& g, int ly, int lx, int& sy, int& sx) {
+  if ((unsigned)ly >= (unsigned)g.Hl || (unsigned)lx >= (unsigned)g.Wl) return false;
+  if (g.up) { sy = ly >> 1; sx = lx >> 1; return true; }
+  if (g.dil) { if ((ly | lx) & 1) return false; sy = ly >> 1; sx = lx >> 1; return true; }
+  sy = ly; sx = lx; return true;
+}
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int MODE, bool VEC, int BO> struct Op;
+
+// ---------------------------------------------------------------------------------------------
+// A = im2col gather, K-contiguous tile [BO rows][32 k]; k = tap*Cin + ci (ci fastest, NHWC)
+// ---------------------------------------------------------------------------------------------
+template <bool VEC, int BO> struct Op<OP_CONV_KC, VEC, BO> {
+  static constexpr int R = BO / 32;
+  static constexpr bool KC = true;
+  int iy0[R], ix0[R], nb[R];
+  float4 v[R];
+  int kq, row0;
+  __device__ __forceinline__ void init(const OpParams& p, long long, int o0, int O, int t) {
+    const ConvGeom& g = p.g;
+    kq = t & 7; row0 = t >> 3;
+    const int hw = g.Ho * g.Wo;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int m = o0 + row0 + 32 * r;
+      if (m < O) {
+        int n = m / hw; int rem = m - n * hw; int oy = rem / g.Wo; int ox = rem - oy * g.Wo;
+        iy0[r] = oy * g.stride - g.pad; ix0[r] = ox * g.stride - g.pad; nb[r] = n * g.Hs * g.Ws;
+      } else { nb[r] = -1; iy0[r] = 0; ix0[r] = 0; }
+    }
+  }
+  __device__ __forceinline__ void load(const OpParams& p, int k0, int kend) {
+    const ConvGeom& g = p.g;
+    if constexpr (VEC) {
+      int tap = k0 / g.Cin; int ci0 = k0 - tap * g.Cin; int dy = tap / g.KW; int dx = tap - dy * g.KW;
+      const float* src; int Cs; int ci = ci0 + kq * 4;
+      if (ci0 < g.C0) { src = g.src0; Cs = g.C0; } else { src = g.src1; Cs = g.C1; ci -= g.C0; }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        v[r] = f4zero();
+        int sy, sx;
+        if (nb[r] >= 0 && map_pix(g, iy0[r] + dy, ix0[r] + dx, sy, sx))
+          v[r] = *reinterpret_cast<const float4*>(src + ((size_t)(nb[r] + sy * g.Ws + sx) * Cs + ci));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          e[j] = 0.f;
+          int k = k0 + kq * 4 + j;
+          if (k < kend && nb[r] >= 0) {
+            int tap = k / g.Cin; int ci = k - tap * g.Cin; int dy = tap / g.KW; int dx = tap - dy * g.KW;
+            int sy, sx;
+            if (map_pix(g, iy0[r] + dy, ix0[r] + dx, sy, sx)) {
+              size_t pix = (size_t)(nb[r] + sy * g.Ws + sx);
+              e[j] = (ci < g.C0) ? g.src0[pix * g.C0 + ci] : g.src1[pix * g.C1 + (ci - g.C0)];
+            }
+          }
+        }
+        v[r] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* s) const {
+#pragma unroll
+    for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(&s[(row0 + 32 * r) * LDK + kq * 4]) = v[r];
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// dense, K-contiguous: elem(o,k) = p[o*ld + k]
+// ---------------------------------------------------------------------------------------------
+template <bool VEC, int BO> struct Op<OP_DENSE_KC, VEC, BO> {
+  static constexpr int R = BO / 32;
+  static constexpr bool KC = true;
+  const float* ptr[R];
+  float4 v[R];
+  int kq, row0;
+  __device__ __forceinline__ void init(const OpParams& p, long long boff, int o0, int O, int t) {
+    kq = t & 7; row0 = t >> 3;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int o = o0 + row0 + 32 * r;
+      ptr[r] = (o < O) ? p.p + boff + (long long)o * p.ld : nullptr;
+    }
+  }
+  __device__ __forceinline__ void load(const OpParams&, int k0, int kend) {
+    int k = k0 + kq * 4;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if constexpr (VEC) {
+        v[r] = (ptr[r] && k < kend) ? *reinterpret_cast<const float4*>(ptr[r] + k) : f4zero();
+      } else {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = (ptr[r] && (k + j) < kend) ? ptr[r][k + j] : 0.f;
+        v[r] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* s) const {
+#pragma unroll
+    for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(&s[(row0 + 32 * r) * LDK + kq * 4]) = v[r];
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// outer-contiguous family: LDS tile [32 k][BO + 4]
+//   DENSE_OC : elem(o,k) = p[k*ld + o]
+//   DGRAD_OC : k = tap'*Cout + co -> W[co][T-1-tap'][ciOff + o]           (conv dgrad weights)
+//   GATHER_OC: k = output pixel, o = tap*Cin + ci -> activation gather     (conv wgrad)
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool VEC, int BO> struct OpOC {
+  static constexpr int R = BO / 32;
+  static constexpr int CPR = BO / 4;           // float4 chunks per k-row
+  static constexpr int KSTEP = 256 / CPR;      // k rows covered per pass
+  static constexpr bool KC = false;
+  float4 v[R];
+  int krow0, oq, o, O_;
+  const float* base;
+  // GATHER_OC per-column state
+  int dy[4], dx[4], cc[4], sel[4];
+  __device__ __forceinline__ void init(const OpParams& p, long long boff, int o0, int O, int t) {
+    krow0 = t / CPR; oq = t - krow0 * CPR; o = o0 + oq * 4; O_ = O; base = p.p + boff;
+    if constexpr (MODE == OP_GATHER_OC) {
+      const ConvGeom& g = p.g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int n = o + j; if (n >= O) n = O - 1;
+        int tap = n / g.Cin; int ci = n - tap * g.Cin;
+        dy[j] = tap / g.KW; dx[j] = tap - dy[j] * g.KW;
+        sel[j] = ci >= g.C0; cc[j] = sel[j] ? ci - g.C0 : ci;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(const OpParams& p, int k0, int kend) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int k = k0 + krow0 + KSTEP * r;
+      v[r] = f4zero();
+      if (k >= kend || o >= O_) continue;
+      if constexpr (MODE == OP_GATHER_OC) {
+        const ConvGeom& g = p.g;
+        const int hw = g.Ho * g.Wo;
+        int n = k / hw; int rem = k - n * hw; int oy = rem / g.Wo; int ox = rem - oy * g.Wo;
+        int by = oy * g.stride - g.pad, bx = ox * g.stride - g.pad; int nb = n * g.Hs * g.Ws;
+        if constexpr (VEC) {
+          int sy, sx;
+          if (map_pix(g, by + dy[0], bx + dx[0], sy, sx)) {
+            size_t pix = (size_t)(nb + sy * g.Ws + sx);
+            v[r] = sel[0] ? *reinterpret_cast<const float4*>(g.src1 + pix * g.C1 + cc[0])
+                          : *reinterpret_cast<const float4*>(g.src0 + pix * g.C0 + cc[0]);
+          }
+        } else {
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            e[j] = 0.f; int sy, sx;
+            if (o + j < O_ && map_pix(g, by + dy[j], bx + dx[j], sy, sx)) {
+              size_t pix = (size_t)(nb + sy * g.Ws + sx);
+              e[j] = sel[j] ? g.src1[pix * g.C1 + cc[j]] : g.src0[pix * g.C0 + cc[j]];
+            }
+          }
+          v[r] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      } else {
+        const float* row;
+        if constexpr (MODE == OP_DGRAD_OC) {
+          int tap = k / p.dgCout; int co = k - tap * p.dgCout;
+          row = base + ((size_t)co * p.dgT + (p.dgT - 1 - tap)) * p.dgWCin + p.dgCiOff;
+        } else {
+          row = base + (long long)k * p.ld;
+        }
+        if constexpr (VEC) {
+          v[r] = *reinterpret_cast<const float4*>(row + o);
+        } else {
+          float e[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = (o + j < O_) ? row[o + j] : 0.f;
+          v[r] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* s) const {
+#pragma unroll
+    for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(&s[(krow0 + KSTEP * r) * (BO + 4) + oq * 4]) = v[r];
+  }
+};
+template <bool VEC, int BO> struct Op<OP_DENSE_OC, VEC, BO> : OpOC<OP_DENSE_OC, VEC, BO> {};
+template <bool VEC, int BO> struct Op<OP_DGRAD_OC, VEC, BO> : OpOC<OP_DGRAD_OC, VEC, BO> {};
+template <bool VEC, int BO> struct Op<OP_GATHER_OC, VEC, BO> : OpOC<OP_GATHER_OC, VEC, BO> {};
+
+// ---------------------------------------------------------------------------------------------
+// the kernel: 256 threads = 4 waves (WM x WN), each wave owns TM x TN tiles of 32x32
+// ---------------------------------------------------------------------------------------------
+template <int AM, bool AV, int BMODE, bool BV, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) igemm_kernel(const GemmParams P) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  using LA = Op<AM, AV, BM>;
+  using LB = Op<BMODE, BV, BN>;
+  constexpr int SA = LA::KC ? BM * LDK : BK * (BM + 4);
+  constexpr int SB = LB::KC ? BN * LDK : BK * (BN + 4);
+  __shared__ __attribute__((aligned(16))) float smem[SA + SB];
+  float* sA = smem;
+  float* sB = smem + SA;
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, h = lane >> 5;
+  const int wm = w / WN, wn = w - wm * WN;
+
+  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles so
+  // neighbouring output rows (shared halo) and the weight panel stay in one L2 (guide T1, bijective form)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  const int tmi = tid / tiles_n, tni = tid - tmi * tiles_n;
+  const int m0 = tmi * BM, n0 = tni * BN;
+
+  int kbeg = 0, kend = P.K;
+  long long aoff = 0, boff = 0, coff = 0;
+  const int z = blockIdx.z;
+  if (P.splitk > 1) {
+    kbeg = z * P.kchunk; kend = min(P.K, kbeg + P.kchunk); coff = (long long)z * P.split_stride;
+  } else {
+    int bo = z / P.Bi, bi = z - bo * P.Bi;
+    aoff = bo * P.a.so + bi * P.a.si; boff = bo * P.b.so + bi * P.b.si; coff = bo * P.sCo + bi * P.sCi;
+  }
+
+  LA la; LB lb;
+  la.init(P.a, aoff, m0, P.M, t);
+  lb.init(P.b, boff, n0, P.N, t);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) { la.load(P.a, kbeg, kend); lb.load(P.b, kbeg, kend); }
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    la.store(sA); lb.store(sB);
+    __syncthreads();
+    if (kt + 1 < nk) { la.load(P.a, kbeg + (kt + 1) * BK, kend); lb.load(P.b, kbeg + (kt + 1) * BK, kend); }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      // MFMA k-slot convention: step s of group kk consumes k = kk*8 + h*4 + s on lane half h
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int row = (wm * TM + a) * 32 + li;
+        if constexpr (LA::KC) {
+          float4 x = *reinterpret_cast<const float4*>(&sA[row * LDK + kk * 8 + h * 4]);
+          af[a][0] = x.x; af[a][1] = x.y; af[a][2] = x.z; af[a][3] = x.w;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) af[a][s] = sA[(kk * 8 + h * 4 + s) * (BM + 4) + row];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = (wn * TN + b) * 32 + li;
+        if constexpr (LB::KC) {
+          float4 x = *reinterpret_cast<const float4*>(&sB[col * LDK + kk * 8 + h * 4]);
+          bf[b][0] = x.x; bf[b][1] = x.y; bf[b][2] = x.z; bf[b][3] = x.w;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bf[b][s] = sB[(kk * 8 + h * 4 + s) * (BN + 4) + col];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* Cb = P.C + coff;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row >= P.M) continue;
+      long long rrow = row;                     // residual row
+      if (P.res_mode == 2) {
+        int hw = P.rHo * P.rWo; int n = row / hw; int rem = row - n * hw; int oy = rem / P.rWo; int ox = rem - oy * P.rWo;
+        rrow = ((long long)n * (P.rHo >> 1) + (oy >> 1)) * (P.rWo >> 1) + (ox >> 1);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + (wn * TN + b) * 32 + li;
+        if (col >= P.N) continue;
+        float val = P.alpha * acc[a][b][r];
+        if (P.bias) val += P.bias[col];
+        if (P.res_mode) val += P.res[rrow * P.ldr + col];
+        float* dst = Cb + (long long)row * P.ldc + col;
+        if (P.accumulate) val += *dst;
+        *dst = val;
+      }
+    }
+  }
+}
+
+// sums split-K slabs: out[i] = (acc ? out[i] : 0) + sum_s ws[s*n + i]   (fixed order => deterministic)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n,
+                                                             int splits, int accumulate) {
+  long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  if (i4 + 3 < n) {
+    float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i4) : f4zero();
+    for (int k = 0; k < splits; ++k) {
+      float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * n + i4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i4) = s;
+  } else {
+    for (long long i = i4; i < n; ++i) {
+      float s = accumulate ? out[i] : 0.f;
+      for (int k = 0; k < splits; ++k) s += ws[(long long)k * n + i];
+      out[i] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------
+template <int AM, bool AV, int BMODE, bool BV>
+static int launch_tiles(int tile, const GemmParams& P, int zdim, hipStream_t s) {
+  if (tile == 128) {
+    dim3 grid(cdiv(P.M, 128) * cdiv(P.N, 128), 1, zdim);
+    hipLaunchKernelGGL((igemm_kernel<AM, AV, BMODE, BV, 128, 128, 2, 2>), grid, dim3(256), 0, s, P);
+  } else {
+    dim3 grid(cdiv(P.M, 64) * cdiv(P.N, 64), 1, zdim);
+    hipLaunchKernelGGL((igemm_kernel<AM, AV, BMODE, BV, 64, 64, 2, 2>), grid, dim3(256), 0, s, P);
+  }
+  return pdae_launch_status("igemm");
+}
+
+static int pick_tile(long long M, long long N) {
+  // 128x128 tiles once they fill the 256 CUs at least twice; otherwise 64x64 for occupancy
+  long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128);
+  return (t128 >= 512 && N >= 96) ? 128 : 64;
+}
+
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int igemm_conv_fwd(const GemmParams& P, int tile, hipStream_t s) {
+  const ConvGeom& g = P.a.g;
+  bool vec = (g.Cin % 32 == 0) && (g.C0 % 32 == 0) && al16(g.src0) && (g.C1 == 0 || al16(g.src1)) && al16(P.b.p);
+  if (tile == 0) tile = pick_tile(P.M, P.N);
+  if (vec) return launch_tiles<OP_CONV_KC, true, OP_DENSE_KC, true>(tile, P, 1, s);
+  return launch_tiles<OP_CONV_KC, false, OP_DENSE_KC, false>(tile, P, 1, s);
+}
+
+int igemm_conv_dgrad(const GemmParams& P, int tile, hipStream_t s) {
+  const ConvGeom& g = P.a.g;
+  bool avec = (g.Cin % 32 == 0) && al16(g.src0);
+  bool bvec = (P.b.dgWCin % 4 == 0) && (P.b.dgCiOff % 4 == 0) && (P.N % 4 == 0) && al16(P.b.p);
+  if (tile == 0) tile = pick_tile(P.M, P.N);
+  if (avec && bvec) return launch_tiles<OP_CONV_KC, true, OP_DGRAD_OC, true>(tile, P, 1, s);
+  if (!avec && bvec) return launch_tiles<OP_CONV_KC, false, OP_DGRAD_OC, true>(tile, P, 1, s);
+  return launch_tiles<OP_CONV_KC, false, OP_DGRAD_OC, false>(tile, P, 1, s);
+}
+
+int igemm_conv_wgrad(const GemmParams& P, int tile, int splits, hipStream_t s) {
+  const ConvGeom& g = P.b.g;
+  bool avec = (P.M % 4 == 0) && (P.a.ld % 4 == 0) && al16(P.a.p);
+  bool bvec = (g.Cin % 4 == 0) && (g.C0 % 4 == 0) && al16(g.src0) && (g.C1 == 0 || al16(g.src1));
+  if (avec && bvec) return launch_tiles<OP_DENSE_OC, true, OP_GATHER_OC, true>(tile, P, splits, s);
+  if (avec && !bvec) return launch_tiles<OP_DENSE_OC, true, OP_GATHER_OC, false>(tile, P, splits, s);
+  if (!avec && bvec) return launch_tiles<OP_DENSE_OC, false, OP_GATHER_OC, true>(tile, P, splits, s);
+  return launch_tiles<OP_DENSE_OC, false, OP_GATHER_OC, false>(tile, P, splits, s);
+}
+
+int igemm_splitk_reduce(const float* ws, float* out, long long n, int splits, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, s, ws, out, n, splits, accumulate);
+  return pdae_launch_status("splitk_reduce");
+}
+
+int igemm_dense(int transA, int transB, const GemmParams& P, int zdim, hipStream_t s) {
+  auto m4 = [](long long v) { return (v & 3) == 0; };
+  const int tile = 64;
+  if (!transA && transB) {          // NT: A[m][k], B[n][k]
+    bool vec = m4(P.K) && m4(P.a.ld) && m4(P.b.ld) && m4(P.a.so) && m4(P.a.si) && m4(P.b.so) && m4(P.b.si) && al16(P.a.p) && al16(P.b.p);
+    if (vec) return launch_tiles<OP_DENSE_KC, true, OP_DENSE_KC, true>(tile, P, zdim, s);
+    return launch_tiles<OP_DENSE_KC, false, OP_DENSE_KC, false>(tile, P, zdim, s);
+  }
+  if (!transA && !transB) {         // NN: A[m][k], B[k][n]
+    bool vec = m4(P.K) && m4(P.N) && m4(P.a.ld) && m4(P.b.ld) && m4(P.a.so) && m4(P.a.si) && m4(P.b.so) && m4(P.b.si) && al16(P.a.p) && al16(P.b.p);
+    if (vec) return launch_tiles<OP_DENSE_KC, true, OP_DENSE_OC, true>(tile, P, zdim, s);
+    return launch_tiles<OP_DENSE_KC, false, OP_DENSE_OC, false>(tile, P, zdim, s);
+  }
+  if (transA && !transB) {          // TN: A[k][m], B[k][n]
+    bool vec = m4(P.M) && m4(P.N) && m4(P.a.ld) && m4(P.b.ld) && m4(P.a.so) && m4(P.a.si) && m4(P.b.so) && m4(P.b.si) && al16(P.a.p) && al16(P.b.p);
+    if (vec) return launch_tiles<OP_DENSE_OC, true, OP_DENSE_OC, true>(tile, P, zdim, s);
+    return launch_tiles<OP_DENSE_OC, false, OP_DENSE_OC, false>(tile, P, zdim, s);
+  }
+  pdae_set_error("pdae_gemm: transA=1,transB=1 is not used on this path and not built");
+  return PDAE_EINVAL;
+}

@@ -1,0 +1,37 @@
+// internal launcher prototypes (norm.hip / elementwise.hip); the public C ABI is include/pdae_hip.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+size_t k_gn_workspace_floats(int N, int C);
+int k_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, float* ws, hipStream_t st);
+int k_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss, const float* zss,
+              float* coef, hipStream_t st);
+int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, const float* coef, int act, int mode, float* y, float* xpool,
+               float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t st);
+int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd, const float* gamma,
+             const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p, unsigned long long seed,
+             unsigned long long offset, const float* add, float* dx0, int acc0, float* dx1, int acc1, float* dgamma, float* dbeta, int acc_param,
+             float* dss, float* dzss, float* ws, hipStream_t st);
+
+int k_timestep_embedding(const long long* t, const float* freqs, int N, int dim, float* out, hipStream_t st);
+int k_silu(const float* x, float* y, size_t n, hipStream_t st);
+int k_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int acc, hipStream_t st);
+int k_axpby(const float* x, float* y, size_t n, float alpha, float beta, hipStream_t st);
+int k_embedding(const float* table, const long long* idx, int N, int D, float* out, int acc, hipStream_t st);
+int k_embedding_bwd(const float* dout, const long long* idx, int N, int D, float* dtable, hipStream_t st);
+int k_to_nhwc(const float* x, long long sn, long long sc, long long sh, long long sw, int N, int C, int H, int W, float* y, hipStream_t st);
+int k_from_nhwc(const float* x, int N, int C, int H, int W, float* y, long long sn, long long sc, long long sh, long long sw, hipStream_t st);
+int k_q_sample(const float* x0, const float* noise, const long long* t, const float* ta, const float* tb, int N, size_t per, float* xt, hipStream_t st);
+int k_loss(const float* noise, const float* eps, const float* g, const long long* t, const float* tc, const float* tw, int N, size_t per, int l1,
+           float scale, float* loss, float* deps, float* dg, float* ws, hipStream_t st);
+int k_ddim_step(const float* x, const float* eps, const float* g, size_t total, float c_shift, float ra, float rm1, float sab, float s1ab, int clamp,
+                float* out, hipStream_t st);
+int k_ddpm_step(const float* x, const float* eps, const float* g, const float* z, size_t total, float cx, float ce, float cs, float sigma, float* out,
+                hipStream_t st);
+int k_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int decoupled,
+               float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, hipStream_t st);
+int k_softmax(float* s, long long rows, int T, hipStream_t st);
+int k_softmax_bwd(const float* p, float* dp, long long rows, int T, hipStream_t st);
+size_t k_colsum_workspace_floats(long long M, int C);
+int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws, hipStream_t st);

@@ -1,0 +1,382 @@
+// GroupNorm(32,C) + AdaGN + SiLU family on NHWC fp32 (HBM-bound kernels).
+//
+// Replaces nn.GroupNorm / SiLU / Dropout / AvgPool2d / the AdaGN arithmetic of
+// model/module.py:56-63, 241, 257-263, 279-284, 293-294, 379-381 and their autograd backward.
+//
+// Forward is split so that the only full-tensor passes are (1) one statistics read and (2) one
+// fused "apply" pass  v = a[n,c]*(x - mu[n,c]) + b[n,c];  y = silu(v) * dropmask  (optionally
+// 2x2-average-pooled, optionally also emitting the pooled raw x for the skip path, and reading a
+// virtual channel-concat of two tensors so torch.cat is never materialised).  The per-(n,c)
+// coefficients fold gamma/beta, the timestep (scale,shift) and the semantic (z_scale,z_shift) pairs.
+//
+// Backward needs only two reductions per (n,c):  S0 = sum dv,  S1 = sum dv*(x-mu);  every parameter
+// gradient (gamma, beta, scale/shift, z_scale/z_shift) and the GroupNorm input gradient derive from
+// them (see gn_bwd_finalize).
+#include "common.h"
+#include "kernels.h"
+
+struct Src2 { const float* x0; const float* x1; int C0, C1; };
+
+__device__ __forceinline__ float4 ld4(const Src2& s, size_t pix, int c) {
+  return c < s.C0 ? *reinterpret_cast<const float4*>(s.x0 + pix * s.C0 + c)
+                  : *reinterpret_cast<const float4*>(s.x1 + pix * s.C1 + (c - s.C0));
+}
+__device__ __forceinline__ float ld1(const Src2& s, size_t pix, int c) {
+  return c < s.C0 ? s.x0[pix * s.C0 + c] : s.x1[pix * s.C1 + (c - s.C0)];
+}
+__device__ __forceinline__ float siluf(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float dsiluf(float v) {
+  float sg = 1.0f / (1.0f + expf(-v));
+  return sg * (1.0f + v * (1.0f - sg));
+}
+
+// Philox4x32-10 counter RNG: the dropout keep-mask is a pure function of (seed, offset, element quad),
+// so backward regenerates it instead of storing a mask tensor.
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float4 drop_mask(unsigned long long seed, unsigned long long offset, unsigned long long quad, float p, float scale) {
+  uint4 r = philox4x32(make_uint4((unsigned)quad, (unsigned)(quad >> 32), (unsigned)offset, (unsigned)(offset >> 32)),
+                       make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+  const float u = 2.3283064365386963e-10f;   // 2^-32
+  return make_float4((r.x * u) >= p ? scale : 0.f, (r.y * u) >= p ? scale : 0.f, (r.z * u) >= p ? scale : 0.f, (r.w * u) >= p ? scale : 0.f);
+}
+
+// ----------------------------------------------------------------------------------------------
+// statistics: per (n, chunk) block, threads = channel quads x pixel lanes; shifted sums (shift =
+// first element of the group) keep E[x^2]-E[x]^2 benign; finalize combines chunks in double.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_stats_partial_kernel(Src2 s, int HW, int C, int G, int chunk, float* __restrict__ part) {
+  __shared__ float red[2 * 1024];            // [PL][C] x {s1,s2} with PL*C <= 1024
+  const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
+  const int NQ = C >> 2, PL = 256 / NQ, cg = C / G;
+  const int t = threadIdx.x, q = t % NQ, pl = t / NQ, c = q * 4;
+  const size_t base = (size_t)n * HW;
+  const int p0 = sidx * chunk, p1 = min(HW, p0 + chunk);
+  if (pl < PL) {
+    float K[4], s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) K[j] = ld1(s, base, ((c + j) / cg) * cg);
+    for (int p = p0 + pl; p < p1; p += PL) {
+      float4 v = ld4(s, base + p, c);
+      float d;
+      d = v.x - K[0]; s1[0] += d; s2[0] += d * d;
+      d = v.y - K[1]; s1[1] += d; s2[1] += d * d;
+      d = v.z - K[2]; s1[2] += d; s2[2] += d * d;
+      d = v.w - K[3]; s1[3] += d; s2[3] += d * d;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[(pl * C + c + j) * 2] = s1[j]; red[(pl * C + c + j) * 2 + 1] = s2[j]; }
+  }
+  __syncthreads();
+  if (t < G) {
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < PL; ++l)
+      for (int j = 0; j < cg; ++j) { a += red[(l * C + t * cg + j) * 2]; b += red[(l * C + t * cg + j) * 2 + 1]; }
+    float* o = part + (((size_t)n * S + sidx) * G + t) * 2;
+    o[0] = a; o[1] = b;
+  }
+}
+
+__global__ void gn_stats_finalize_kernel(Src2 s, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
+                                         float* __restrict__ mean, float* __restrict__ rstd) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * G) return;
+  int n = i / G, g = i - n * G, cg = C / G;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < S; ++k) { const float* o = part + (((size_t)n * S + k) * G + g) * 2; a += o[0]; b += o[1]; }
+  double cnt = (double)cg * HW;
+  double K = ld1(s, (size_t)n * HW, g * cg);
+  double m = a / cnt;
+  double var = b / cnt - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)(K + m);
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// coef[0]=mu, coef[1]=a, coef[2]=b, each [N][C]
+__global__ void gn_coef_kernel(int N, int C, int G, const float* __restrict__ mean, const float* __restrict__ rstd,
+                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ ss, const float* __restrict__ zss, float* __restrict__ coef) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  int n = i / C, c = i - n * C, g = c / (C / G);
+  float r = rstd[n * G + g];
+  float k = gamma[c] * r, b = beta[c];
+  if (ss) { float sc = 1.0f + ss[(size_t)n * 2 * C + c]; k *= sc; b = b * sc + ss[(size_t)n * 2 * C + C + c]; }
+  if (zss) { float sc = 1.0f + zss[(size_t)n * 2 * C + c]; k *= sc; b = b * sc + zss[(size_t)n * 2 * C + C + c]; }
+  coef[i] = mean[n * G + g];
+  coef[(size_t)N * C + i] = k;
+  coef[(size_t)2 * N * C + i] = b;
+}
+
+// ----------------------------------------------------------------------------------------------
+// apply: y = act(a*(x-mu)+b) [* dropmask]; mode 0 = same resolution, 1 = 2x2 average pool of y
+// (and of raw x into xpool when given).  One thread per output float4.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_apply_kernel(Src2 s, int N, int H, int W, int C, const float* __restrict__ coef, int act, int mode,
+                                                       float* __restrict__ y, float* __restrict__ xpool,
+                                                       float drop_p, unsigned long long seed, unsigned long long offset) {
+  const int NQ = C >> 2;
+  const int Ho = mode == 1 ? H >> 1 : H, Wo = mode == 1 ? W >> 1 : W;
+  const size_t total = (size_t)N * Ho * Wo * NQ;
+  const size_t NC = (size_t)N * C;
+  const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int q = (int)(i % NQ); size_t pix = i / NQ; int c = q * 4;
+    int n = (int)(pix / ((size_t)Ho * Wo));
+    const float4 mu = *reinterpret_cast<const float4*>(coef + (size_t)n * C + c);
+    const float4 a = *reinterpret_cast<const float4*>(coef + NC + (size_t)n * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(coef + 2 * NC + (size_t)n * C + c);
+    float4 o;
+    if (mode == 0) {
+      float4 x = ld4(s, pix, c);
+      o.x = a.x * (x.x - mu.x) + b.x; o.y = a.y * (x.y - mu.y) + b.y; o.z = a.z * (x.z - mu.z) + b.z; o.w = a.w * (x.w - mu.w) + b.w;
+      if (act) { o.x = siluf(o.x); o.y = siluf(o.y); o.z = siluf(o.z); o.w = siluf(o.w); }
+      if (drop_p > 0.f) { float4 m = drop_mask(seed, offset, i, drop_p, dscale); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
+    } else {
+      int rem = (int)(pix - (size_t)n * Ho * Wo); int oy = rem / Wo, ox = rem - oy * Wo;
+      o = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        size_t ip = ((size_t)n * H + (2 * oy + (d >> 1))) * W + 2 * ox + (d & 1);
+        float4 x = ld4(s, ip, c);
+        float4 v;
+        v.x = a.x * (x.x - mu.x) + b.x; v.y = a.y * (x.y - mu.y) + b.y; v.z = a.z * (x.z - mu.z) + b.z; v.w = a.w * (x.w - mu.w) + b.w;
+        if (act) { v.x = siluf(v.x); v.y = siluf(v.y); v.z = siluf(v.z); v.w = siluf(v.w); }
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        xs.x += x.x; xs.y += x.y; xs.z += x.z; xs.w += x.w;
+      }
+      o.x *= 0.25f; o.y *= 0.25f; o.z *= 0.25f; o.w *= 0.25f;
+      if (xpool) *reinterpret_cast<float4*>(xpool + pix * C + c) = make_float4(xs.x * 0.25f, xs.y * 0.25f, xs.z * 0.25f, xs.w * 0.25f);
+    }
+    *reinterpret_cast<float4*>(y + pix * C + c) = o;
+  }
+}
+
+// gradient wrt the activated tensor at input-resolution pixel (n,py,px):
+//   mode 0: dA[pix]; mode 1 (y was pooled): dA[pool pix]/4; mode 2 (consumer read y nearest-upsampled): sum of the 4 children
+__device__ __forceinline__ float4 fetch_da(const float* __restrict__ dA, int mode, int n, int py, int px, int H, int W, int C, int c) {
+  if (mode == 0) return *reinterpret_cast<const float4*>(dA + (((size_t)n * H + py) * W + px) * C + c);
+  if (mode == 1) {
+    float4 v = *reinterpret_cast<const float4*>(dA + (((size_t)n * (H >> 1) + (py >> 1)) * (W >> 1) + (px >> 1)) * C + c);
+    return make_float4(v.x * 0.25f, v.y * 0.25f, v.z * 0.25f, v.w * 0.25f);
+  }
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    float4 v = *reinterpret_cast<const float4*>(dA + (((size_t)n * 2 * H + 2 * py + (d >> 1)) * 2 * W + 2 * px + (d & 1)) * C + c);
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+  }
+  return o;
+}
+
+// dv = dA * act'(v) * dropmask, with v recomputed from x and the forward coefficients
+__device__ __forceinline__ float4 compute_dv(float4 da, float4 xm, float4 a, float4 b, int act, float drop_p, float dscale,
+                                             unsigned long long seed, unsigned long long offset, size_t quad) {
+  if (drop_p > 0.f) { float4 m = drop_mask(seed, offset, quad, drop_p, dscale); da.x *= m.x; da.y *= m.y; da.z *= m.z; da.w *= m.w; }
+  if (act) {
+    da.x *= dsiluf(a.x * xm.x + b.x); da.y *= dsiluf(a.y * xm.y + b.y); da.z *= dsiluf(a.z * xm.z + b.z); da.w *= dsiluf(a.w * xm.w + b.w);
+  }
+  return da;
+}
+
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(Src2 s, int H, int W, int C, int chunk, const float* __restrict__ coef, int N,
+                                                            const float* __restrict__ dA, int act, int mode, float drop_p,
+                                                            unsigned long long seed, unsigned long long offset, float* __restrict__ part) {
+  __shared__ float red[2 * 1024];
+  const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x, HW = H * W;
+  const int NQ = C >> 2, PL = 256 / NQ;
+  const int t = threadIdx.x, q = t % NQ, pl = t / NQ, c = q * 4;
+  const size_t NC = (size_t)N * C;
+  const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const int p0 = sidx * chunk, p1 = min(HW, p0 + chunk);
+  if (pl < PL) {
+    const float4 mu = *reinterpret_cast<const float4*>(coef + (size_t)n * C + c);
+    const float4 a = *reinterpret_cast<const float4*>(coef + NC + (size_t)n * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(coef + 2 * NC + (size_t)n * C + c);
+    float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    for (int p = p0 + pl; p < p1; p += PL) {
+      int py = p / W, px = p - py * W;
+      size_t pix = (size_t)n * HW + p;
+      float4 x = ld4(s, pix, c);
+      float4 xm = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
+      float4 dv = compute_dv(fetch_da(dA, mode, n, py, px, H, W, C, c), xm, a, b, act, drop_p, dscale, seed, offset, pix * NQ + q);
+      s0[0] += dv.x; s0[1] += dv.y; s0[2] += dv.z; s0[3] += dv.w;
+      s1[0] += dv.x * xm.x; s1[1] += dv.y * xm.y; s1[2] += dv.z * xm.z; s1[3] += dv.w * xm.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[(pl * C + c + j) * 2] = s0[j]; red[(pl * C + c + j) * 2 + 1] = s1[j]; }
+  }
+  __syncthreads();
+  for (int cc = t; cc < C; cc += 256) {
+    float u = 0.f, v = 0.f;
+    for (int l = 0; l < PL; ++l) { u += red[(l * C + cc) * 2]; v += red[(l * C + cc) * 2 + 1]; }
+    float* o = part + (((size_t)n * S + sidx) * C + cc) * 2;
+    o[0] = u; o[1] = v;
+  }
+}
+
+// one block per sample n.  Writes d(scale,shift) pairs, the per-(n,c) [c1,c2] apply coefficients and
+// the per-(n,c) gamma/beta contributions (summed over n by gn_bwd_param_kernel).
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(int N, int HW, int C, int G, int S, const float* __restrict__ part,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ ss,
+                                                              const float* __restrict__ zss, float* __restrict__ dss,
+                                                              float* __restrict__ dzss, float* __restrict__ c12, float* __restrict__ pgb) {
+  __shared__ float g1[1024], g2[1024], m1[64], m2[64];
+  const int n = blockIdx.x, cg = C / G, t = threadIdx.x;
+  for (int c = t; c < C; c += 256) {
+    float S0 = 0.f, S1 = 0.f;
+    for (int k = 0; k < S; ++k) { const float* o = part + (((size_t)n * S + k) * C + c) * 2; S0 += o[0]; S1 += o[1]; }
+    const float r = rstd[n * G + c / cg], gm = gamma[c], bt = beta[c];
+    float sc = 1.f, sh = 0.f, zsc = 1.f;
+    if (ss) { sc = 1.0f + ss[(size_t)n * 2 * C + c]; sh = ss[(size_t)n * 2 * C + C + c]; }
+    if (zss) zsc = 1.0f + zss[(size_t)n * 2 * C + c];
+    const float rS1 = r * S1;
+    if (dzss) { dzss[(size_t)n * 2 * C + c] = sc * gm * rS1 + (sc * bt + sh) * S0; dzss[(size_t)n * 2 * C + C + c] = S0; }
+    if (dss) { dss[(size_t)n * 2 * C + c] = zsc * (gm * rS1 + bt * S0); dss[(size_t)n * 2 * C + C + c] = zsc * S0; }
+    const float kp = sc * zsc;
+    pgb[((size_t)n * C + c) * 2] = kp * rS1;       // d gamma contribution
+    pgb[((size_t)n * C + c) * 2 + 1] = kp * S0;    // d beta contribution
+    g1[c] = gm * kp * S0; g2[c] = gm * kp * rS1;
+  }
+  __syncthreads();
+  if (t < G) {
+    float a = 0.f, b = 0.f;
+    for (int j = 0; j < cg; ++j) { a += g1[t * cg + j]; b += g2[t * cg + j]; }
+    const float inv = 1.0f / ((float)cg * (float)HW);
+    m1[t] = a * inv; m2[t] = b * inv;
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cg; const float r = rstd[n * G + g];
+    c12[((size_t)n * C + c) * 2] = r * m1[g];
+    c12[((size_t)n * C + c) * 2 + 1] = r * r * m2[g];
+  }
+}
+
+__global__ void gn_bwd_param_kernel(int N, int C, const float* __restrict__ pgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int n = 0; n < N; ++n) { a += pgb[((size_t)n * C + c) * 2]; b += pgb[((size_t)n * C + c) * 2 + 1]; }
+  if (accumulate) { a += dgamma[c]; b += dbeta[c]; }
+  dgamma[c] = a; dbeta[c] = b;
+}
+
+// dx = a*dv - c1 - (x-mu)*c2 (+ add, resampled like dA); split into the two concat sources.
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H, int W, int C, const float* __restrict__ coef,
+                                                           const float* __restrict__ c12, const float* __restrict__ dA, int act, int mode,
+                                                           float drop_p, unsigned long long seed, unsigned long long offset,
+                                                           const float* __restrict__ add, float* __restrict__ dx0, int acc0,
+                                                           float* __restrict__ dx1, int acc1) {
+  const int NQ = C >> 2, HW = H * W;
+  const size_t total = (size_t)N * HW * NQ, NC = (size_t)N * C;
+  const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int q = (int)(i % NQ); size_t pix = i / NQ; int c = q * 4;
+    int n = (int)(pix / HW); int p = (int)(pix - (size_t)n * HW); int py = p / W, px = p - py * W;
+    float* dst; int accf;
+    if (c < s.C0) { dst = dx0 ? dx0 + pix * s.C0 + c : nullptr; accf = acc0; }
+    else { dst = dx1 ? dx1 + pix * s.C1 + (c - s.C0) : nullptr; accf = acc1; }
+    if (!dst) continue;
+    const float4 mu = *reinterpret_cast<const float4*>(coef + (size_t)n * C + c);
+    const float4 a = *reinterpret_cast<const float4*>(coef + NC + (size_t)n * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(coef + 2 * NC + (size_t)n * C + c);
+    const float* cp = c12 + ((size_t)n * C + c) * 2;
+    const float4 ca = *reinterpret_cast<const float4*>(cp), cb = *reinterpret_cast<const float4*>(cp + 4);   // c1,c2 interleaved
+    float4 x = ld4(s, pix, c);
+    float4 xm = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
+    float4 dv = compute_dv(fetch_da(dA, mode, n, py, px, H, W, C, c), xm, a, b, act, drop_p, dscale, seed, offset, i);
+    float4 o;
+    o.x = a.x * dv.x - ca.x - xm.x * ca.y;
+    o.y = a.y * dv.y - ca.z - xm.y * ca.w;
+    o.z = a.z * dv.z - cb.x - xm.z * cb.y;
+    o.w = a.w * dv.w - cb.z - xm.w * cb.w;
+    if (add) { float4 ad = fetch_da(add, mode, n, py, px, H, W, C, c); o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w; }
+    if (accf) { float4 e = *reinterpret_cast<const float4*>(dst); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+    *reinterpret_cast<float4*>(dst) = o;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// host launchers
+// ----------------------------------------------------------------------------------------------
+static int stats_chunks(int HW, int C) {
+  long long el = (long long)HW * C;
+  int S = (int)(el / 16384); if (S < 1) S = 1; if (S > 64) S = 64; if (S > HW) S = HW;
+  return S;
+}
+
+static int check_c(int C0, int C1, int G) {
+  int C = C0 + C1;
+  PDAE_CHECK_ARG(C > 0 && C <= 1024 && (C % G) == 0 && (C0 % 4) == 0 && (C1 % 4) == 0 && G <= 64,
+                 "groupnorm: need C0%%4==0, C1%%4==0, C<=1024, C%%G==0 (got C0=%d C1=%d G=%d)", C0, C1, G);
+  return PDAE_OK;
+}
+
+size_t k_gn_workspace_floats(int N, int C) { return (size_t)N * 64 * C * 2 + (size_t)N * C * 4; }
+
+int k_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd,
+               float* ws, hipStream_t st) {
+  if (int e = check_c(C0, C1, G)) return e;
+  const int C = C0 + C1;
+  Src2 s{x0, x1, C0, C1};
+  int S = stats_chunks(HW, C), chunk = cdiv(HW, S);
+  S = cdiv(HW, chunk);
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, N), dim3(256), 0, st, s, HW, C, G, chunk, ws);
+  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cdiv(N * G, 128)), dim3(128), 0, st, s, N, HW, C, G, S, eps, ws, mean, rstd);
+  return pdae_launch_status("gn_stats");
+}
+
+int k_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss,
+              const float* zss, float* coef, hipStream_t st) {
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(cdiv((long long)N * C, 256)), dim3(256), 0, st, N, C, G, mean, rstd, gamma, beta, ss, zss, coef);
+  return pdae_launch_status("gn_coef");
+}
+
+static int ew_grid(size_t total) { size_t b = (total + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1; return (int)b; }
+
+int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, const float* coef, int act, int mode, float* y,
+               float* xpool, float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t st) {
+  if (int e = check_c(C0, C1, 1)) return e;
+  PDAE_CHECK_ARG(mode == 0 || (mode == 1 && (H % 2) == 0 && (W % 2) == 0 && drop_p == 0.f), "gn_apply: bad mode/shape");
+  const int C = C0 + C1;
+  Src2 s{x0, x1, C0, C1};
+  size_t total = (size_t)N * (mode ? (H / 2) * (W / 2) : H * W) * (C / 4);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, s, N, H, W, C, coef, act, mode, y, xpool, drop_p, seed, offset);
+  return pdae_launch_status("gn_apply");
+}
+
+int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
+             const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p,
+             unsigned long long seed, unsigned long long offset, const float* add, float* dx0, int acc0, float* dx1, int acc1,
+             float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, float* ws, hipStream_t st) {
+  if (int e = check_c(C0, C1, G)) return e;
+  const int C = C0 + C1, HW = H * W;
+  Src2 s{x0, x1, C0, C1};
+  int S = stats_chunks(HW, C), chunk = cdiv(HW, S);
+  S = cdiv(HW, chunk);
+  float* part = ws;                                   // [N][S][C][2]
+  float* c12 = ws + (size_t)N * 64 * C * 2;           // [N][C][2]
+  float* pgb = c12 + (size_t)N * C * 2;               // [N][C][2]
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb);
+  if (dgamma)
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, N, C, pgb, dgamma, dbeta, acc_param);
+  if (dx0 || dx1) {
+    size_t total = (size_t)N * HW * (C / 4);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, s, N, H, W, C, coef, c12, dA, act, mode, drop_p, seed, offset,
+                       add, dx0, acc0, dx1, acc1);
+  }
+  return pdae_launch_status("gn_bwd");
+}
