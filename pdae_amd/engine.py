@@ -1,0 +1,340 @@
+"""Planned-graph engine: a network pass is a static list of fused HIP stages over pre-allocated
+NHWC buffers, issued with ONE host call (pdae_run_ops).
+
+This replaces the per-module Python dispatch of the reference (TimestepSequential, model/module.py:131-140,
+and torch autograd) with a plan built once per (network, batch shape, mode):
+  * `Plan`     -- buffer pool + op records + shared workspace, compiled to a ctypes array;
+  * `Builder`  -- emitters for the fused stages (conv, GroupNorm/AdaGN/SiLU, linear, attention) and
+                  block-level forward / hand-derived backward graphs for ResBlock / ResBlockShift
+                  (model/module.py:205-384) and AttentionBlock (:387-428).
+Only what the path needs is differentiated: the frozen trunk / eps-branch of ShiftUNet emit no backward.
+"""
+import math
+from types import SimpleNamespace as NS
+
+import torch
+
+from . import hip as H
+
+GROUPS = 32       # normalization(channels) = GroupNorm(32, C)  (model/module.py:56-63)
+GN_EPS = 1e-5
+
+
+class Plan:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.recs = []
+        self.pool = {}
+        self.ws_bytes = 4096
+        self.arr = None
+        self.n = 0
+        self.ws = None
+        self.live = []          # every tensor ever allocated (keeps storage alive)
+        self.drop_ops = []      # indices of ops carrying a dropout (seed, offset)
+        self.bytes_alloc = 0
+
+    # ---- memory
+    def buf(self, *shape, dtype=torch.float32, zero=False):
+        n = 1
+        for s in shape:
+            n *= int(s)
+        key = (n, dtype)
+        lst = self.pool.get(key)
+        if lst:
+            t = lst.pop().view(*shape)
+        else:
+            t = torch.empty(n, dtype=dtype, device=self.device).view(*shape)
+            self.live.append(t)
+            self.bytes_alloc += n * t.element_size()
+        if zero:
+            self.emit(lambda ws, t=t: H.op_memset(t, t.numel() * t.element_size()))
+        return t
+
+    def free(self, *ts):
+        for t in ts:
+            if t is not None:
+                self.pool.setdefault((t.numel(), t.dtype), []).append(t)
+
+    def need_ws(self, nbytes):
+        self.ws_bytes = max(self.ws_bytes, int(nbytes))
+
+    # ---- ops
+    def emit(self, rec):
+        self.recs.append(rec)
+        return len(self.recs) - 1
+
+    def compile(self):
+        self.ws = torch.empty(self.ws_bytes // 4 + 64, dtype=torch.float32, device=self.device)
+        ops = [r(self.ws) for r in self.recs]
+        self.arr = H.ops_array(ops)
+        self.n = len(ops)
+        return self
+
+    def run(self, first=0, last=None, stream=None):
+        """Runs ops[first:last] on the current (or given) stream."""
+        if self.device.type != "cuda":
+            raise H.PdaeError("pdae_amd plans only execute on a ROCm device (no CPU fallback)")
+        last = self.n if last is None else last
+        if last > first:
+            import ctypes
+            sub = ctypes.cast(ctypes.addressof(self.arr) + first * ctypes.sizeof(H.PdaeOp), ctypes.POINTER(H.PdaeOp * (last - first))).contents
+            H.run_ops(sub, last - first, stream)
+
+    def set_dropout(self, seed, step):
+        for k, (idx, si, oi) in enumerate(self.drop_ops):
+            self.arr[idx].i[si] = int(seed)
+            self.arr[idx].i[oi] = int(step)
+
+
+class Builder:
+    """Emits fused stages into a Plan.  `grads` maps parameter name -> gradient tensor (same memory
+    layout as the parameter); presence of a name means that parameter is trained by this plan."""
+
+    def __init__(self, plan, params, grads=None, save=False, drop_p=0.0):
+        self.p = plan
+        self.P = params
+        self.Gr = grads or {}
+        self.save = save          # keep activations for backward (else buffers are recycled)
+        self.drop_p = drop_p
+        self.drop_layers = 0
+
+    # ------------------------------------------------------------------ primitives
+    def conv(self, x0, x1, wname, k, stride=1, up=False, res=None, res_mode=0, bias=True):
+        N, Hh, W, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[3]
+        w = self.P[wname + ".weight"]
+        b = self.P[wname + ".bias"] if bias else None
+        c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=k, stride=stride, up=up)
+        assert w.numel() == c.Cout * k * k * c.Cin, (wname, tuple(w.shape), c.Cin)
+        y = self.p.buf(N, c.Ho, c.Wo, c.Cout)
+        self.p.emit(lambda ws: H.op_conv_fwd(c, x0, x1, w, b, y, res=res, res_mode=res_mode))
+        return y, NS(c=c, x0=x0, x1=x1, wname=wname, y=y)
+
+    def conv_bwd_params(self, cx, dy):
+        """dW, db of a conv stage (only if the parameter is trained by this plan)."""
+        c = cx.c
+        gw = self.Gr.get(cx.wname + ".weight")
+        if gw is not None:
+            wsb = c.wgrad_ws_bytes()
+            self.p.need_ws(wsb)
+            self.p.emit(lambda ws: H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, ws, self.p.ws_bytes))
+        gb = self.Gr.get(cx.wname + ".bias")
+        if gb is not None:
+            M = c.N * c.Ho * c.Wo
+            self.p.need_ws(H.colsum_ws_bytes(M, c.Cout))
+            self.p.emit(lambda ws: H.op_colsum(dy, M, c.Cout, gb, ws))
+
+    def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0):
+        c = cx.c
+        ci_cnt = c.Cin if ci_cnt is None else ci_cnt
+        w = self.P[cx.wname + ".weight"]
+        dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
+        self.p.emit(lambda ws: H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate))
+        return dx
+
+    def linear(self, x, wname, pre_bias=True):
+        Nb, K = x.shape
+        w, b = self.P[wname + ".weight"], self.P[wname + ".bias"]
+        out = w.shape[0]
+        assert w.numel() == out * K, (wname, tuple(w.shape), K)
+        y = self.p.buf(Nb, out)
+        self.p.emit(lambda ws: H.op_gemm(0, 1, Nb, out, K, x, K, w, K, y, out, bias=b))
+        return y, NS(x=x, wname=wname, Nb=Nb, K=K, out=out)
+
+    def linear_bwd(self, lx, dy, dx=None, dx_acc=0):
+        """dW = dy^T x, db = colsum(dy), optionally dx (+)= dy W."""
+        Nb, K, out = lx.Nb, lx.K, lx.out
+        w = self.P[lx.wname + ".weight"]
+        gw, gb = self.Gr.get(lx.wname + ".weight"), self.Gr.get(lx.wname + ".bias")
+        if gw is not None:
+            self.p.emit(lambda ws: H.op_gemm(1, 0, out, K, Nb, dy, out, lx.x, K, gw, K))
+        if gb is not None:
+            self.p.need_ws(H.colsum_ws_bytes(Nb, out))
+            self.p.emit(lambda ws: H.op_colsum(dy, Nb, out, gb, ws))
+        if dx is not None:
+            self.p.emit(lambda ws: H.op_gemm(0, 0, Nb, K, out, dy, out, w, K, dx, K, accumulate=dx_acc))
+
+    def silu(self, x):
+        y = self.p.buf(*x.shape)
+        self.p.emit(lambda ws: H.op_silu(x, y, x.numel()))
+        return y
+
+    def gn(self, x0, x1, gname, ss=None, zss=None, act=1, mode=0, want_xpool=False, dropout=False):
+        """GroupNorm(32) [+AdaGN] [+SiLU] [+dropout] [+2x2 avg-pool].  Returns ctx with .y (.xpool)."""
+        N, Hh, W, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[3]
+        C = C0 + C1
+        gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]
+        pl = self.p
+        pl.need_ws(H.gn_ws_bytes(N, C))
+        mean, rstd, coef = pl.buf(N * GROUPS), pl.buf(N * GROUPS), pl.buf(3, N, C)
+        Ho, Wo = (Hh // 2, W // 2) if mode == 1 else (Hh, W)
+        y = pl.buf(N, Ho, Wo, C)
+        xpool = pl.buf(N, Ho, Wo, C) if (mode == 1 and want_xpool) else None
+        pl.emit(lambda ws: H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, mean, rstd, ws))
+        pl.emit(lambda ws: H.op_gn_coef(N, C, GROUPS, mean, rstd, gamma, beta, ss, zss, coef))
+        dp = self.drop_p if dropout else 0.0
+        layer = 0
+        if dp > 0:
+            self.drop_layers += 1
+            layer = self.drop_layers
+        idx = pl.emit(lambda ws: H.op_gn_apply(x0, C0, x1, C1, N, Hh, W, coef, act, mode, y, xpool=xpool, drop_p=dp, seed=layer, offset=0))
+        if dp > 0:
+            pl.drop_ops.append((idx, 7, 8))
+        ctx = NS(x0=x0, x1=x1, C0=C0, C1=C1, N=N, H=Hh, W=W, gname=gname, ss=ss, zss=zss, act=act, mode=mode, mean=mean, rstd=rstd,
+                 coef=coef, y=y, xpool=xpool, drop_p=dp, layer=layer)
+        if not self.save:
+            pl.free(mean, rstd, coef)
+        return ctx
+
+    def gn_bwd(self, g, dA, bmode, add=None, dx0=None, acc0=0, dx1=None, acc1=0, want_dss=False, want_dzss=False):
+        """Backward of a gn() stage.  bmode: 0 same, 1 y was pooled, 2 consumer read y upsampled."""
+        pl = self.p
+        C = g.C0 + g.C1
+        gamma, beta = self.P[g.gname + ".weight"], self.P[g.gname + ".bias"]
+        dgamma, dbeta = self.Gr.get(g.gname + ".weight"), self.Gr.get(g.gname + ".bias")
+        dss = pl.buf(g.N, 2 * C) if (want_dss and g.ss is not None) else None
+        dzss = pl.buf(g.N, 2 * C) if (want_dzss and g.zss is not None) else None
+        pl.need_ws(H.gn_ws_bytes(g.N, C))
+        idx = pl.emit(lambda ws: H.op_gn_bwd(g.x0, g.C0, g.x1, g.C1, g.N, g.H, g.W, GROUPS, g.coef, g.rstd, gamma, beta, g.ss, g.zss, dA, g.act,
+                                             bmode, ws, add=add, dx0=dx0, acc0=acc0, dx1=dx1, acc1=acc1, dgamma=dgamma, dbeta=dbeta, dss=dss,
+                                             dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0))
+        if g.drop_p > 0:
+            pl.drop_ops.append((idx, 11, 12))
+        return dss, dzss
+
+    # ------------------------------------------------------------------ ResBlock / ResBlockShift
+    def resblock(self, pre, x0, x1, ea, eza=None, up=False, down=False, dropout=False):
+        """model/module.py:278-297 / :361-384.  ea = SiLU(emb), eza = SiLU(shift_emb) (shared by all blocks)."""
+        pl = self.p
+        has_skip = (pre + ".skip_connection.weight") in self.P
+        assert not (has_skip and (up or down)), "channel-changing up/down ResBlocks do not occur on this path"
+        g1 = self.gn(x0, x1, pre + ".in_layers.0", act=1, mode=1 if down else 0, want_xpool=down)
+        h1, c1 = self.conv(g1.y, None, pre + ".in_layers.2", 3, up=up)
+        if not self.save:
+            pl.free(g1.y)
+        ss, l_ss = self.linear(ea, pre + ".emb_layers.1")
+        zss, l_zss = (None, None)
+        if eza is not None:
+            zss, l_zss = self.linear(eza, pre + ".emb_z_layers.1")
+        g2 = self.gn(h1, None, pre + ".out_layers.0", ss=ss, zss=zss, act=1, mode=0, dropout=dropout)
+        if not self.save:
+            pl.free(h1, ss, zss)
+        cs = None
+        if has_skip:
+            sk, cs = self.conv(x0, x1, pre + ".skip_connection", 1)
+            out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=sk, res_mode=1)
+            pl.free(sk)                      # never needed by backward
+        elif down:
+            out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=g1.xpool, res_mode=1)
+            pl.free(g1.xpool)
+        else:
+            out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=x0, res_mode=2 if up else 1)
+        if not self.save:
+            pl.free(g2.y)
+        return out, NS(pre=pre, g1=g1, c1=c1, l_ss=l_ss, l_zss=l_zss, g2=g2, c2=c2, cs=cs, up=up, down=down, has_skip=has_skip, h1=h1)
+
+    def resblock_bwd(self, r, dout, need_dx0=True, need_dx1=False, d_ea=None, d_eza=None):
+        """Returns (dx0, dx1).  d_ea / d_eza: accumulators [N,E] for d SiLU(emb) / d SiLU(shift_emb) (or None)."""
+        pl = self.p
+        g1, g2 = r.g1, r.g2
+        C0, C1 = g1.C0, g1.C1
+        # conv2
+        self.conv_bwd_params(r.c2, dout)
+        d_a2 = self.conv_dgrad(r.c2, dout)
+        # channel-changing skip: 1x1 conv over the raw (concat) input
+        dx0 = dx1 = None
+        if r.has_skip:
+            self.conv_bwd_params(r.cs, dout)
+            if need_dx0:
+                dx0 = self.conv_dgrad(r.cs, dout, ci_off=0, ci_cnt=C0)
+            if need_dx1:
+                dx1 = self.conv_dgrad(r.cs, dout, ci_off=C0, ci_cnt=C1)
+        # AdaGN + SiLU (+dropout)
+        dh1 = pl.buf(*r.h1.shape)
+        dss, dzss = self.gn_bwd(g2, d_a2, 0, dx0=dh1, want_dss=True, want_dzss=True)
+        pl.free(d_a2)
+        self.linear_bwd(r.l_ss, dss, dx=d_ea, dx_acc=1)
+        pl.free(dss)
+        if dzss is not None:
+            self.linear_bwd(r.l_zss, dzss, dx=d_eza, dx_acc=1)
+            pl.free(dzss)
+        # conv1
+        self.conv_bwd_params(r.c1, dh1)
+        trainable_gn1 = (g1.gname + ".weight") in self.Gr
+        if need_dx0 or need_dx1 or trainable_gn1:
+            d_a1 = self.conv_dgrad(r.c1, dh1)
+            bmode = 1 if r.down else (2 if r.up else 0)
+            if need_dx0 and dx0 is None:
+                dx0 = pl.buf(g1.N, g1.H, g1.W, C0)
+            if need_dx1 and dx1 is None:
+                dx1 = pl.buf(g1.N, g1.H, g1.W, C1)
+            self.gn_bwd(g1, d_a1, bmode, add=None if r.has_skip else dout, dx0=dx0 if need_dx0 else None, acc0=int(r.has_skip),
+                        dx1=dx1 if need_dx1 else None, acc1=int(r.has_skip))
+            pl.free(d_a1)
+        pl.free(dh1)
+        return dx0, dx1
+
+    # ------------------------------------------------------------------ AttentionBlock
+    def attention(self, pre, x, heads, new_order):
+        """model/module.py:422-428 with QKVAttentionLegacy (:431-457) or QKVAttention (:460-488)."""
+        pl = self.p
+        N, Hh, W, C = x.shape
+        T = Hh * W
+        ch = C // heads
+        gx = self.gn(x, None, pre + ".norm", act=0)
+        qkv, cq = self.conv(gx.y, None, pre + ".qkv", 1)
+        if not self.save:
+            pl.free(gx.y)
+        if new_order:       # [q(all heads) | k | v]
+            oq, ok, ov, hs = 0, C, 2 * C, ch
+        else:               # per head [q k v]
+            oq, ok, ov, hs = 0, ch, 2 * ch, 3 * ch
+        scale2 = 1.0 / math.sqrt(ch)          # (ch^-1/4)^2 : q and k are each scaled by ch^-1/4 (module.py:451-453)
+        Pm = pl.buf(N * heads, T, T)
+        o = pl.buf(N, Hh, W, C)
+        qp, kp, vp = qkv.data_ptr() + 4 * oq, qkv.data_ptr() + 4 * ok, qkv.data_ptr() + 4 * ov
+        pl.emit(lambda ws: H.op_gemm(0, 1, T, T, ch, qp, 3 * C, kp, 3 * C, Pm, T, alpha=scale2, batch_outer=N, batch_inner=heads,
+                                     sA=(T * 3 * C, hs), sB=(T * 3 * C, hs), sC=(heads * T * T, T * T)))
+        pl.emit(lambda ws: H.op_softmax(Pm, N * heads * T, T))
+        pl.emit(lambda ws: H.op_gemm(0, 0, T, ch, T, Pm, T, vp, 3 * C, o, C, batch_outer=N, batch_inner=heads,
+                                     sA=(heads * T * T, T * T), sB=(T * 3 * C, hs), sC=(T * C, ch)))
+        out, cp = self.conv(o, None, pre + ".proj_out", 1, res=x, res_mode=1)
+        if not self.save:
+            pl.free(qkv, Pm, o)
+        return out, NS(pre=pre, gx=gx, cq=cq, cp=cp, qkv=qkv, Pm=Pm, o=o, N=N, T=T, C=C, heads=heads, ch=ch, offs=(oq, ok, ov, hs), scale2=scale2,
+                       shape=(N, Hh, W, C))
+
+    def attention_bwd(self, a, dout, need_dx=True):
+        pl = self.p
+        N, T, C, heads, ch = a.N, a.T, a.C, a.heads, a.ch
+        oq, ok, ov, hs = a.offs
+        self.conv_bwd_params(a.cp, dout)
+        d_o = self.conv_dgrad(a.cp, dout)                          # [N,H,W,C]
+        dqkv = pl.buf(*a.qkv.shape)
+        dP = pl.buf(N * heads, T, T)
+        qp, kp, vp = a.qkv.data_ptr() + 4 * oq, a.qkv.data_ptr() + 4 * ok, a.qkv.data_ptr() + 4 * ov
+        dqp, dkp, dvp = dqkv.data_ptr() + 4 * oq, dqkv.data_ptr() + 4 * ok, dqkv.data_ptr() + 4 * ov
+        bA = (heads * T * T, T * T)
+        bQ = (T * 3 * C, hs)
+        bO = (T * C, ch)
+        # dV[s,c] = sum_t P[t,s] dO[t,c]
+        pl.emit(lambda ws: H.op_gemm(1, 0, T, ch, T, a.Pm, T, d_o, C, dvp, 3 * C, batch_outer=N, batch_inner=heads, sA=bA, sB=bO, sC=bQ))
+        # dP[t,s] = sum_c dO[t,c] v[s,c]
+        pl.emit(lambda ws: H.op_gemm(0, 1, T, T, ch, d_o, C, vp, 3 * C, dP, T, batch_outer=N, batch_inner=heads, sA=bO, sB=bQ, sC=bA))
+        pl.emit(lambda ws: H.op_softmax_bwd(a.Pm, dP, N * heads * T, T))
+        # dQ = scale2 * dS K ; dK = scale2 * dS^T Q
+        pl.emit(lambda ws: H.op_gemm(0, 0, T, ch, T, dP, T, kp, 3 * C, dqp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
+        pl.emit(lambda ws: H.op_gemm(1, 0, T, ch, T, dP, T, qp, 3 * C, dkp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
+        pl.free(d_o, dP)
+        self.conv_bwd_params(a.cq, dqkv)
+        dx = None
+        trainable_norm = (a.pre + ".norm.weight") in self.Gr
+        if need_dx or trainable_norm:
+            d_xn = self.conv_dgrad(a.cq, dqkv)
+            if need_dx:
+                dx = pl.buf(*a.shape)
+            self.gn_bwd(a.gx, d_xn, 0, add=dout, dx0=dx)
+            pl.free(d_xn)
+        pl.free(dqkv)
+        return dx

@@ -1,0 +1,257 @@
+"""ctypes binding of libpdae_hip.so (include/pdae_hip.h) + op-record builders.
+
+The product path has NO CPU fallback: importing this module on a machine where the
+library has not been built raises, and every launch raises on a non-zero status.
+PyTorch supplies device memory and streams only (tensor.data_ptr(), current stream).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
+
+(OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
+ OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
+ OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY) = range(1, 27)
+
+
+class PdaeOp(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("p", ctypes.c_void_p * 20),
+                ("i", ctypes.c_int64 * 24), ("f", ctypes.c_double * 12)]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("N", "Hi", "Wi", "C0", "C1", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad", "up")]
+
+
+class PdaeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library (once).  Raises if it is missing: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PdaeError(f"{LIB_PATH} is missing -- run `python -m pdae_amd.build` (hipcc, gfx950). "
+                            "pdae_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.pdae_last_error.restype = ctypes.c_char_p
+        L.pdae_run_ops.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.pdae_run_ops.restype = ctypes.c_int
+        L.pdae_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.pdae_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+        L.pdae_gn_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.pdae_gn_workspace_bytes.restype = ctypes.c_size_t
+        L.pdae_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
+        L.pdae_colsum_workspace_bytes.restype = ctypes.c_size_t
+        L.pdae_abi_version.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
+           "pdae_conv2d_wgrad", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_timestep_embedding", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
+           "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
+           "pdae_ddim_step", "pdae_ddpm_step", "pdae_adam_ema", "pdae_run_ops"]
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def make_op(kind, p=(), i=(), f=()):
+    o = PdaeOp()
+    o.kind = kind
+    for k, v in enumerate(p):
+        o.p[k] = _ptr(v)
+    for k, v in enumerate(i):
+        o.i[k] = int(v)
+    for k, v in enumerate(f):
+        o.f[k] = float(v)
+    return o
+
+
+def current_stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def run_ops(arr, n, stream=None):
+    """arr: ctypes array of PdaeOp (or a single PdaeOp with n == 1)."""
+    st = current_stream_ptr() if stream is None else stream
+    rc = lib().pdae_run_ops(ctypes.addressof(arr), n, ctypes.c_void_p(st))
+    if rc != 0:
+        raise PdaeError(f"pdae_run_ops failed (status {rc}): {lib().pdae_last_error().decode()}")
+
+
+def run(op, stream=None):
+    run_ops(op, 1, stream)
+
+
+def ops_array(ops):
+    arr = (PdaeOp * len(ops))()
+    for k, o in enumerate(ops):
+        ctypes.memmove(ctypes.addressof(arr) + k * ctypes.sizeof(PdaeOp), ctypes.addressof(o), ctypes.sizeof(PdaeOp))
+    return arr
+
+
+# ------------------------------------------------------------------------------------------
+# record builders: one per PDAE_OP_* (field order documented in include/pdae_hip.h / api.hip)
+# ------------------------------------------------------------------------------------------
+class Conv:
+    """Geometry of one convolution over NHWC activations (pdae_conv_desc)."""
+
+    def __init__(self, N, Hi, Wi, C0, C1, Cout, k=3, stride=1, pad=None, up=False):
+        pad = k // 2 if pad is None else pad
+        Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
+        self.N, self.Hi, self.Wi, self.C0, self.C1, self.Cout = N, Hi, Wi, C0, C1, Cout
+        self.KH = self.KW = k
+        self.stride, self.pad, self.up = stride, pad, int(up)
+        self.Ho = (Hl + 2 * pad - k) // stride + 1
+        self.Wo = (Wl + 2 * pad - k) // stride + 1
+        self.Hl, self.Wl = Hl, Wl
+
+    @property
+    def Cin(self):
+        return self.C0 + self.C1
+
+    def fields(self):
+        return [self.N, self.Hi, self.Wi, self.C0, self.C1, self.Ho, self.Wo, self.Cout, self.KH, self.KW, self.stride, self.pad, self.up]
+
+    def cdesc(self):
+        d = ConvDesc()
+        for n, v in zip([f[0] for f in ConvDesc._fields_], self.fields()):
+            setattr(d, n, v)
+        return d
+
+    def wgrad_ws_bytes(self):
+        d = self.cdesc()
+        return int(lib().pdae_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
+
+
+def op_conv_fwd(c, x0, x1, w, bias, y, res=None, res_mode=0, tile=0):
+    return make_op(OP_CONV_FWD, [x0, x1, w, bias, res, y], c.fields() + [res_mode, tile])
+
+
+def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0):
+    return make_op(OP_CONV_DGRAD, [dy, w, dx], c.fields() + [ci_off, c.Cin if ci_cnt is None else ci_cnt, accumulate, tile])
+
+
+def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0):
+    return make_op(OP_CONV_WGRAD, [x0, x1, dy, dw, ws], c.fields() + [accumulate, ws_bytes])
+
+
+def op_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=None, accumulate=0,
+            batch_outer=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0)):
+    return make_op(OP_GEMM, [A, B, C, bias],
+                   [transA, transB, M, N, K, lda, sA[0], sA[1], ldb, sB[0], sB[1], ldc, sC[0], sC[1], batch_outer, batch_inner, accumulate],
+                   [alpha])
+
+
+def op_gn_stats(x0, C0, x1, C1, N, HW, G, eps, mean, rstd, ws):
+    return make_op(OP_GN_STATS, [x0, x1, mean, rstd, ws], [C0, C1, N, HW, G], [eps])
+
+
+def op_gn_coef(N, C, G, mean, rstd, gamma, beta, ss, zss, coef):
+    return make_op(OP_GN_COEF, [mean, rstd, gamma, beta, ss, zss, coef], [N, C, G])
+
+
+def op_gn_apply(x0, C0, x1, C1, N, H, W, coef, act, mode, y, xpool=None, drop_p=0.0, seed=0, offset=0):
+    return make_op(OP_GN_APPLY, [x0, x1, coef, y, xpool], [C0, C1, N, H, W, act, mode, seed, offset], [drop_p])
+
+
+def op_gn_bwd(x0, C0, x1, C1, N, H, W, G, coef, rstd, gamma, beta, ss, zss, dA, act, mode, ws, add=None, dx0=None, acc0=0,
+              dx1=None, acc1=0, dgamma=None, dbeta=None, acc_param=0, dss=None, dzss=None, drop_p=0.0, seed=0, offset=0):
+    return make_op(OP_GN_BWD, [x0, x1, coef, rstd, gamma, beta, ss, zss, dA, add, dx0, dx1, dgamma, dbeta, dss, dzss, ws],
+                   [C0, C1, N, H, W, G, act, mode, acc0, acc1, acc_param, seed, offset], [drop_p])
+
+
+def op_temb(t, freqs, N, dim, out):
+    return make_op(OP_TEMB, [t, freqs, out], [N, dim])
+
+
+def op_silu(x, y, n):
+    return make_op(OP_SILU, [x, y], [n])
+
+
+def op_silu_bwd(x, dy, dx, n, acc=0):
+    return make_op(OP_SILU_BWD, [x, dy, dx], [n, acc])
+
+
+def op_axpby(x, y, n, alpha=1.0, beta=1.0):
+    return make_op(OP_AXPBY, [x, y], [n], [alpha, beta])
+
+
+def op_embedding(table, idx, N, D, out, acc=0):
+    return make_op(OP_EMBEDDING, [table, idx, out], [N, D, acc])
+
+
+def op_embedding_bwd(dout, idx, N, D, dtable):
+    return make_op(OP_EMBEDDING_BWD, [dout, idx, dtable], [N, D])
+
+
+def op_to_nhwc(x, strides, N, C, H, W, y):
+    return make_op(OP_TO_NHWC, [x, y], list(strides) + [N, C, H, W])
+
+
+def op_from_nhwc(x, N, C, H, W, y, strides):
+    return make_op(OP_FROM_NHWC, [x, y], list(strides) + [N, C, H, W])
+
+
+def op_q_sample(x0, noise, t, ta, tb, N, per, xt):
+    return make_op(OP_Q_SAMPLE, [x0, noise, t, ta, tb, xt], [N, per])
+
+
+def op_loss(noise, eps, g, t, tc, tw, N, per, loss, ws, deps=None, dg=None, l1=0, scale=1.0):
+    return make_op(OP_LOSS, [noise, eps, g, t, tc, tw, loss, deps, dg, ws], [N, per, l1], [scale])
+
+
+def op_ddim_step(x, eps, g, total, c_shift, ra, rm1, sab, s1ab, out, clamp=1):
+    return make_op(OP_DDIM_STEP, [x, eps, g, out], [total, clamp], [c_shift, ra, rm1, sab, s1ab])
+
+
+def op_ddpm_step(x, eps, g, z, total, cx, ce, cs, sigma, out):
+    return make_op(OP_DDPM_STEP, [x, eps, g, z, out], [total], [cx, ce, cs, sigma])
+
+
+def op_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay):
+    return make_op(OP_ADAM_EMA, [p, g, m, v, ema], [n, decoupled], [lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2, grad_scale, ema_decay])
+
+
+def op_softmax(s, rows, T):
+    return make_op(OP_SOFTMAX, [s], [rows, T])
+
+
+def op_softmax_bwd(p, dp, rows, T):
+    return make_op(OP_SOFTMAX_BWD, [p, dp], [rows, T])
+
+
+def op_colsum(x, M, C, out, ws, acc=0):
+    return make_op(OP_COLSUM, [x, out, ws], [M, C, acc])
+
+
+def op_memset(dst, nbytes):
+    return make_op(OP_MEMSET, [dst], [nbytes])
+
+
+def op_copy(src, dst, nbytes):
+    return make_op(OP_COPY, [src, dst], [nbytes])
+
+
+def gn_ws_bytes(N, C):
+    return int(lib().pdae_gn_workspace_bytes(N, C))
+
+
+def colsum_ws_bytes(M, C):
+    return int(lib().pdae_colsum_workspace_bytes(M, C))

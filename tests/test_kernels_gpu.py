@@ -1,0 +1,372 @@
+"""GPU: every HIP kernel of libpdae_hip.so, called through the C ABI (pdae_run_ops), against a plain
+torch CPU reference of the same op (fp64 where cheap).  Tolerance is the north-star's 1e-4 relative
+(max-abs error / max-abs reference) unless tightened below."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from pdae_amd import hip
+    hip.lib()
+    return hip
+
+
+def rn(seed, *shape, scale=1.0):
+    return torch.tensor(np.random.default_rng(seed).standard_normal(shape) * scale, dtype=torch.float32)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def ws(nbytes):
+    return torch.empty(max(int(nbytes), 16) // 4 + 4, dtype=torch.float32, device="cuda")
+
+
+def ref_conv(x, w, b, stride, pad, up):
+    if up:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    return F.conv2d(x.double(), w.double(), None if b is None else b.double(), stride=stride, padding=pad)
+
+
+CONV_CASES = [
+    # N, H, W, C0, C1, Cout, k, stride, up, res_mode, tile
+    (2, 12, 12, 64, 0, 96, 3, 1, 0, 0, 0),
+    (2, 12, 12, 64, 0, 96, 3, 1, 0, 1, 128),
+    (1, 10, 14, 32, 64, 64, 3, 1, 0, 0, 64),
+    (2, 8, 8, 32, 0, 32, 3, 1, 1, 2, 0),
+    (2, 16, 16, 3, 0, 64, 3, 2, 0, 0, 0),
+    (2, 16, 16, 64, 0, 128, 3, 2, 0, 0, 0),
+    (2, 9, 9, 64, 32, 32, 1, 1, 0, 1, 0),
+    (1, 16, 16, 32, 0, 3, 3, 1, 0, 0, 0),
+    (1, 16, 16, 1, 0, 32, 3, 1, 0, 0, 0),
+    (3, 32, 32, 128, 0, 128, 3, 1, 0, 0, 128),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(H, case):
+    N, Hh, W, C0, C1, Cout, k, stride, up, res_mode, tile = case
+    Cin = C0 + C1
+    x = rn(1, N, Cin, Hh, W)
+    w = rn(2, Cout, Cin, k, k, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rn(3, Cout, scale=0.1)
+    c = H.Conv(N, Hh, W, C0, C1, Cout, k=k, stride=stride, up=bool(up))
+    res = None
+    y_ref = ref_conv(x, w, b, stride, k // 2, up)
+    if res_mode == 1:
+        res = rn(4, N, Cout, c.Ho, c.Wo)
+        y_ref = y_ref + res.double()
+    elif res_mode == 2:
+        res = rn(4, N, Cout, c.Ho // 2, c.Wo // 2)
+        y_ref = y_ref + F.interpolate(res, scale_factor=2, mode="nearest").double()
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous()
+    x1 = xh[..., C0:].contiguous() if C1 else None
+    wd = nhwc(w).cuda()                      # [Cout][KH][KW][Cin]
+    bd = b.cuda()
+    resd = nhwc(res).cuda() if res is not None else None
+    y = torch.empty(N, c.Ho, c.Wo, Cout, device="cuda")
+    H.run(H.op_conv_fwd(c, x0, x1, wd, bd, y, res=resd, res_mode=res_mode, tile=tile))
+    assert rel_err(nchw(y), y_ref) < 1e-5
+
+    # backward references via autograd in fp64; the input gradient is taken wrt the LOGICAL (upsampled) conv input
+    wr = w.double().requires_grad_(True)
+    dy = rn(5, N, Cout, c.Ho, c.Wo)
+    xl = (F.interpolate(x, scale_factor=2, mode="nearest") if up else x).double().clone().requires_grad_(True)
+    (F.conv2d(xl, wr, None, stride=stride, padding=k // 2) * dy.double()).sum().backward()
+    dx_ref, dw_ref = xl.grad, wr.grad
+    dyd = nhwc(dy).cuda()
+    if Cin >= 4:        # image-channel convs never need an input gradient
+        dx = torch.empty(N, c.Hl, c.Wl, Cin, device="cuda")
+        H.run(H.op_conv_dgrad(c, dyd, wd, dx, tile=tile))
+        assert rel_err(nchw(dx), dx_ref) < 1e-5
+        if C1:          # only the first concat half, accumulated onto existing content
+            dx0 = torch.ones(N, c.Hl, c.Wl, C0, device="cuda")
+            H.run(H.op_conv_dgrad(c, dyd, wd, dx0, ci_off=0, ci_cnt=C0, accumulate=1))
+            assert rel_err(nchw(dx0) - 1.0, dx_ref[:, :C0]) < 1e-5
+            dx1 = torch.empty(N, c.Hl, c.Wl, C1, device="cuda")
+            H.run(H.op_conv_dgrad(c, dyd, wd, dx1, ci_off=C0, ci_cnt=C1))
+            assert rel_err(nchw(dx1), dx_ref[:, C0:]) < 1e-5
+    wsb = c.wgrad_ws_bytes()
+    wsp = ws(wsb)
+    dw = torch.empty_like(wd)
+    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, wsp, wsb))
+    assert rel_err(dw.permute(0, 3, 1, 2), dw_ref) < 2e-5
+    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, wsp, wsb, accumulate=1))
+    assert rel_err(dw.permute(0, 3, 1, 2), 2 * dw_ref) < 2e-5
+
+
+def test_conv_wgrad_splitk_large(H):
+    N, Hh, C, Cout = 4, 32, 32, 64
+    x, dy = rn(1, N, C, Hh, Hh), rn(2, N, Cout, Hh, Hh)
+    c = H.Conv(N, Hh, Hh, C, 0, Cout)
+    wr = torch.zeros(Cout, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), wr, padding=1) * dy.double()).sum().backward()
+    wsb = c.wgrad_ws_bytes()
+    assert wsb > 16            # really exercises the split-K path
+    dw = torch.empty(Cout, 3, 3, C, device="cuda")
+    H.run(H.op_conv_wgrad(c, nhwc(x).cuda(), None, nhwc(dy).cuda(), dw, ws(wsb), wsb))
+    assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2e-5
+
+
+GEMM_CASES = [  # transA, transB, M, N, K, bo, bi
+    (0, 1, 70, 50, 36, 2, 3), (0, 0, 64, 48, 100, 1, 2), (1, 0, 33, 65, 130, 2, 1),
+    (0, 1, 7, 5, 3, 1, 1), (0, 0, 5, 3, 9, 1, 1), (1, 0, 6, 10, 7, 1, 1), (0, 1, 256, 256, 64, 2, 4),
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm(H, case):
+    tA, tB, M, N, K, bo, bi = case
+    nb = bo * bi
+    A = rn(1, nb, *((K, M) if tA else (M, K)))
+    B = rn(2, nb, *((N, K) if tB else (K, N)))
+    bias = rn(3, N)
+    C0 = rn(4, nb, M, N)
+    opA = A.transpose(1, 2) if tA else A
+    opB = B.transpose(1, 2) if tB else B
+    ref = 0.5 * torch.bmm(opA.double(), opB.double()) + bias.double() + C0.double()
+    Ad, Bd, Cd = A.cuda(), B.cuda(), C0.clone().cuda()
+    sa, sb, sc = A.shape[1] * A.shape[2], B.shape[1] * B.shape[2], M * N
+    H.run(H.op_gemm(tA, tB, M, N, K, Ad, A.shape[2], Bd, B.shape[2], Cd, N, alpha=0.5, bias=bias.cuda(), accumulate=1,
+                    batch_outer=bo, batch_inner=bi, sA=(bi * sa, sa), sB=(bi * sb, sb), sC=(bi * sc, sc)))
+    assert rel_err(Cd, ref) < 1e-5
+
+
+def _gn_ref(x, gamma, beta, ss, zss, act, G=32):
+    y = F.group_norm(x, G, gamma, beta, 1e-5)
+    if ss is not None:
+        s, sh = ss[:, :, None, None].chunk(2, 1)
+        y = y * (1 + s) + sh
+    if zss is not None:
+        s, sh = zss[:, :, None, None].chunk(2, 1)
+        y = (1 + s) * y + sh
+    return F.silu(y) if act else y
+
+
+GN_CASES = [  # N, H, W, C0, C1, use_ss, use_zss, act, mode(0 same,1 down,2 up-consumer)
+    (2, 8, 8, 64, 0, 0, 0, 1, 0), (2, 8, 8, 64, 32, 1, 1, 1, 0), (2, 6, 10, 32, 0, 1, 0, 0, 0),
+    (2, 8, 8, 64, 0, 0, 0, 1, 1), (2, 4, 4, 96, 0, 0, 0, 1, 2), (1, 32, 32, 128, 128, 1, 1, 1, 0),
+    (2, 16, 16, 512, 384, 0, 0, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", GN_CASES)
+def test_groupnorm_family(H, case):
+    N, Hh, W, C0, C1, use_ss, use_zss, act, mode = case
+    C, G = C0 + C1, 32
+    x = (rn(1, N, C, Hh, W) * 1.5 + 0.7).double().requires_grad_(True)
+    gamma = (1 + 0.2 * rn(2, C)).double().requires_grad_(True)
+    beta = (0.2 * rn(3, C)).double().requires_grad_(True)
+    ss = (0.3 * rn(4, N, 2 * C)).double().requires_grad_(True) if use_ss else None
+    zss = (0.3 * rn(5, N, 2 * C)).double().requires_grad_(True) if use_zss else None
+    y_ref = _gn_ref(x, gamma, beta, ss, zss, act)
+    xp_ref = None
+    if mode == 1:
+        y_ref, xp_ref = F.avg_pool2d(y_ref, 2), F.avg_pool2d(x, 2)
+    y_used = F.interpolate(y_ref, scale_factor=2, mode="nearest") if mode == 2 else y_ref
+    dA = rn(6, *y_used.shape)
+    add = rn(7, *y_used.shape) if C1 == 0 else None
+    loss = (y_used * dA.double()).sum()
+    if add is not None:   # identity-skip path resampled the same way
+        xs = F.avg_pool2d(x, 2) if mode == 1 else (F.interpolate(x, scale_factor=2, mode="nearest") if mode == 2 else x)
+        loss = loss + (xs * add.double()).sum()
+    loss.backward()
+
+    f32 = lambda t: None if t is None else t.detach().float().cuda()
+    xh = nhwc(x.detach().float()).cuda()
+    x0 = xh[..., :C0].contiguous()
+    x1 = xh[..., C0:].contiguous() if C1 else None
+    mean = torch.empty(N * G, device="cuda"); rstd = torch.empty(N * G, device="cuda")
+    wsp = ws(H.gn_ws_bytes(N, C))
+    H.run(H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, G, 1e-5, mean, rstd, wsp))
+    xg = x.detach().reshape(N, G, -1)
+    assert rel_err(mean, xg.mean(-1).flatten()) < 1e-6
+    assert rel_err(rstd, 1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5).flatten()) < 1e-5
+    coef = torch.empty(3, N, C, device="cuda")
+    H.run(H.op_gn_coef(N, C, G, mean, rstd, f32(gamma), f32(beta), f32(ss), f32(zss), coef))
+    Ho, Wo = (Hh // 2, W // 2) if mode == 1 else (Hh, W)
+    y = torch.empty(N, Ho, Wo, C, device="cuda")
+    xp = torch.empty(N, Ho, Wo, C, device="cuda") if mode == 1 else None
+    H.run(H.op_gn_apply(x0, C0, x1, C1, N, Hh, W, coef, act, 1 if mode == 1 else 0, y, xpool=xp))
+    assert rel_err(nchw(y), y_ref) < 1e-5
+    if xp is not None:
+        assert rel_err(nchw(xp), xp_ref) < 1e-6
+
+    dx0 = torch.empty(N, Hh, W, C0, device="cuda")
+    dx1 = torch.empty(N, Hh, W, C1, device="cuda") if C1 else None
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dss = torch.empty(N, 2 * C, device="cuda") if use_ss else None
+    dzss = torch.empty(N, 2 * C, device="cuda") if use_zss else None
+    H.run(H.op_gn_bwd(x0, C0, x1, C1, N, Hh, W, G, coef, rstd, f32(gamma), f32(beta), f32(ss), f32(zss), nhwc(dA).cuda(), act, mode, wsp,
+                      add=None if add is None else nhwc(add).cuda(), dx0=dx0, dx1=dx1, dgamma=dg, dbeta=db, dss=dss, dzss=dzss))
+    dx = torch.cat([dx0, dx1], -1) if C1 else dx0
+    assert rel_err(nchw(dx), x.grad) < 2e-5
+    assert rel_err(dg, gamma.grad) < 2e-5 and rel_err(db, beta.grad) < 2e-5
+    if use_ss:
+        assert rel_err(dss, ss.grad) < 2e-5
+    if use_zss:
+        assert rel_err(dzss, zss.grad) < 2e-5
+
+
+def test_dropout_mask_consistency(H):
+    N, Hh, W, C, G, p = 2, 16, 16, 64, 32, 0.25
+    x = nhwc(rn(1, N, C, Hh, W)).cuda()
+    mean = torch.empty(N * G, device="cuda"); rstd = torch.empty(N * G, device="cuda")
+    wsp = ws(H.gn_ws_bytes(N, C))
+    gamma, beta = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    H.run(H.op_gn_stats(x, C, None, 0, N, Hh * W, G, 1e-5, mean, rstd, wsp))
+    coef = torch.empty(3, N, C, device="cuda")
+    H.run(H.op_gn_coef(N, C, G, mean, rstd, gamma, beta, None, None, coef))
+    y0 = torch.empty_like(x); y1 = torch.empty_like(x); y2 = torch.empty_like(x)
+    H.run(H.op_gn_apply(x, C, None, 0, N, Hh, W, coef, 0, 0, y0))
+    H.run(H.op_gn_apply(x, C, None, 0, N, Hh, W, coef, 0, 0, y1, drop_p=p, seed=1234, offset=7))
+    H.run(H.op_gn_apply(x, C, None, 0, N, Hh, W, coef, 0, 0, y2, drop_p=p, seed=1234, offset=7))
+    assert torch.equal(y1, y2)
+    keep = y1 != 0
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.02
+    assert rel_err(y1[keep], y0[keep] / (1 - p)) < 1e-6
+    # backward regenerates the same mask: with act=0, gamma=1 the input gradient of a masked element is pure GN-coupling
+    dA = torch.ones_like(x)
+    dx = torch.empty_like(x)
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    H.run(H.op_gn_bwd(x, C, None, 0, N, Hh, W, G, coef, rstd, gamma, beta, None, None, dA, 0, 0, wsp, dx0=dx, dgamma=dg, dbeta=db,
+                      drop_p=p, seed=1234, offset=7))
+    assert rel_err(db, (keep.float() / (1 - p)).sum((0, 1, 2))) < 1e-5
+
+
+def test_elementwise_diffusion(H):
+    from oracle import pdae_oracle as O
+    s = O.Schedules()
+    N, per = 3, 3 * 8 * 8
+    t = torch.tensor([0, 500, 999])
+    x0, noise, eps, g = rn(1, N, 3, 8, 8), rn(2, N, 3, 8, 8), rn(3, N, 3, 8, 8), rn(4, N, 3, 8, 8)
+    td = t.cuda()
+    # timestep embedding
+    for dim in (32, 128):
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).cuda()
+        out = torch.empty(N, dim, device="cuda")
+        H.run(H.op_temb(td, freqs, N, dim, out))
+        assert (out.cpu() - O.timestep_embedding(t, dim)).abs().max() < 2e-6
+    # q_sample
+    xt = torch.empty(N, 3, 8, 8, device="cuda")
+    H.run(H.op_q_sample(x0.cuda(), noise.cuda(), td, s.sqrt_alphas_cumprod.cuda(), s.sqrt_one_minus_alphas_cumprod.cuda(), N, per, xt))
+    assert rel_err(xt, O.q_sample(s, x0, t, noise)) < 1e-6
+    # weighted L2 loss + grads, plain L2, L1
+    er, gr = eps.clone().requires_grad_(True), g.clone().requires_grad_(True)
+    ref = O.p_loss(noise, er + O._at(s.shift_coef, t, x0) * gr, weight=O._at(s.weight, t, x0))
+    ref.backward()
+    loss = torch.empty(1, device="cuda"); deps = torch.empty(N, 3, 8, 8, device="cuda"); dg = torch.empty_like(deps)
+    wsp = ws(8192)
+    H.run(H.op_loss(noise.cuda(), eps.cuda(), g.cuda(), td, s.shift_coef.cuda(), s.weight.cuda(), N, per, loss, wsp, deps=deps, dg=dg))
+    assert abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item()) + 1e-9
+    assert rel_err(deps, er.grad) < 1e-5 and rel_err(dg, gr.grad) < 1e-5
+    er.grad = None
+    ref = O.p_loss(noise, er); ref.backward()
+    H.run(H.op_loss(noise.cuda(), eps.cuda(), None, None, None, None, N, per, loss, wsp, deps=deps))
+    assert abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item()) and rel_err(deps, er.grad) < 1e-5
+    er.grad = None
+    ref = O.p_loss(noise, er, loss_type="l1"); ref.backward()
+    H.run(H.op_loss(noise.cuda(), eps.cuda(), None, None, None, None, N, per, loss, wsp, deps=deps, l1=1))
+    assert abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item()) and rel_err(deps, er.grad) < 1e-5
+    # DDIM update, sample and encode direction, with and without shift
+    d = O.DDIMTables(s, "ddim20")
+    for i, encode, use_shift in [(20, False, True), (7, False, False), (0, True, True), (13, True, True)]:
+        tt = torch.full((N,), i, dtype=torch.long)
+        ref = O.ddim_update(d, x0 * 1.5, tt, eps, g, encode=encode, use_shift=use_shift)
+        ab = float((d.alphas_cumprod_next if encode else d.alphas_cumprod_prev)[i])
+        out = torch.empty(N, 3, 8, 8, device="cuda")
+        H.run(H.op_ddim_step((x0 * 1.5).cuda(), eps.cuda(), g.cuda() if use_shift else None, N * per,
+                             float(d.sqrt_one_minus_alphas_cumprod[i]), float(d.sqrt_recip_alphas_cumprod[i]),
+                             float(d.sqrt_recip_alphas_cumprod_m1[i]), float(np.sqrt(np.float32(ab))),
+                             float(np.sqrt(np.float32(1.0) - np.float32(ab))), out))
+        assert rel_err(out, ref) < 1e-5
+    # DDPM mean
+    tt = torch.full((N,), 400, dtype=torch.long)
+    ref = O.noise_p_sample_mean(s, x0, tt, eps + O._at(s.shift_coef, tt, x0) * g) + 0.3 * noise
+    out = torch.empty(N, 3, 8, 8, device="cuda")
+    H.run(H.op_ddpm_step(x0.cuda(), eps.cuda(), g.cuda(), noise.cuda(), N * per, float(s.noise_posterior_mean_x_t_coef[400]),
+                         float(s.noise_posterior_mean_noise_coef[400]), float(s.shift_coef[400]), 0.3, out))
+    assert rel_err(out, ref) < 1e-5
+
+
+def test_adam_ema_matches_torch_optim(H):
+    n = 5000
+    for cls, wd, dec in [(torch.optim.Adam, 0.0, 0), (torch.optim.AdamW, 0.01, 1), (torch.optim.Adam, 0.05, 0)]:
+        p = torch.nn.Parameter(rn(1, n))
+        opt = cls([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        pd, m, v = p.detach().clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        ema, ema_ref = pd.clone(), p.detach().clone()
+        for step in range(1, 4):
+            g = rn(10 + step, n)
+            p.grad = g.clone()
+            opt.step()
+            ema_ref.mul_(0.99).add_(p.detach(), alpha=0.01)
+            bc1, bc2 = 1 - 0.9 ** step, 1 - 0.999 ** step
+            H.run(H.op_adam_ema(pd, (g * 2).cuda(), m, v, ema, n, 1e-3, 0.9, 0.999, 1e-8, wd, dec, 1e-3 / bc1, 1.0 / math.sqrt(bc2), 0.5, 0.99))
+        assert rel_err(pd, p.detach()) < 2e-6 and rel_err(ema, ema_ref) < 2e-6
+
+
+def test_softmax_colsum_layout_misc(H):
+    rows, T = 37, 256
+    s = rn(1, rows, T, scale=3.0)
+    sd = s.clone().cuda()
+    H.run(H.op_softmax(sd, rows, T))
+    assert rel_err(sd, torch.softmax(s.double(), -1)) < 1e-6
+    sr = s.double().requires_grad_(True)
+    dp = rn(2, rows, T)
+    (torch.softmax(sr, -1) * dp.double()).sum().backward()
+    dpd = dp.clone().cuda()
+    H.run(H.op_softmax_bwd(sd, dpd, rows, T))
+    assert rel_err(dpd, sr.grad) < 1e-5
+    for M, C in [(1000, 96), (5000, 3), (7, 512)]:
+        x = rn(3, M, C)
+        out = torch.ones(C, device="cuda")
+        H.run(H.op_colsum(x.cuda(), M, C, out, ws(H.colsum_ws_bytes(M, C)), acc=1))
+        assert rel_err(out - 1, x.double().sum(0)) < 1e-5
+    x = rn(4, 2, 3, 5, 7)
+    y = torch.empty(2, 5, 7, 3, device="cuda")
+    xs = x.cuda()
+    H.run(H.op_to_nhwc(xs, xs.stride(), 2, 3, 5, 7, y))
+    assert torch.equal(y.cpu(), nhwc(x))
+    z = torch.empty(2, 3, 5, 7, device="cuda")
+    H.run(H.op_from_nhwc(y, 2, 3, 5, 7, z, z.stride()))
+    assert torch.equal(z.cpu(), x)
+    a = rn(5, 300)
+    ad = a.cuda(); o = torch.empty(300, device="cuda")
+    H.run(H.op_silu(ad, o, 300))
+    assert rel_err(o, F.silu(a.double())) < 1e-6
+    ar = a.double().requires_grad_(True); F.silu(ar).sum().backward()
+    dx = torch.ones(300, device="cuda")
+    H.run(H.op_silu_bwd(ad, torch.ones(300, device="cuda"), dx, 300, acc=1))
+    assert rel_err(dx - 1, ar.grad) < 1e-5
+    yb = torch.ones(300, device="cuda")
+    H.run(H.op_axpby(ad, yb, 300, alpha=2.0, beta=3.0))
+    assert rel_err(yb, 2 * a + 3) < 1e-6
+    table, idx = rn(6, 10, 16), torch.tensor([3, 3, 9])
+    out = torch.zeros(3, 16, device="cuda")
+    H.run(H.op_embedding(table.cuda(), idx.cuda(), 3, 16, out))
+    assert torch.equal(out.cpu(), table[idx])
+    dt = torch.zeros(10, 16, device="cuda")
+    H.run(H.op_embedding_bwd(out, idx.cuda(), 3, 16, dt))
+    ref = torch.zeros(10, 16); ref.index_add_(0, idx, table[idx])
+    assert rel_err(dt, ref) < 1e-6
+    buf = torch.ones(64, device="cuda"); dst = torch.zeros(64, device="cuda")
+    H.run(H.op_copy(buf, dst, 256)); H.run(H.op_memset(buf, 256))
+    assert dst.sum().item() == 64 and buf.sum().item() == 0
