@@ -10,6 +10,7 @@ and torch autograd) with a plan built once per (network, batch shape, mode):
 Only what the path needs is differentiated: the frozen trunk / eps-branch of ShiftUNet emit no backward.
 """
 import math
+import os
 from types import SimpleNamespace as NS
 
 import torch
@@ -24,6 +25,7 @@ class Plan:
     def __init__(self, device):
         self.device = torch.device(device)
         self.recs = []
+        self.ws_patch = []
         self.pool = {}
         self.ws_bytes = 4096
         self.arr = None
@@ -47,7 +49,7 @@ class Plan:
             self.live.append(t)
             self.bytes_alloc += n * t.element_size()
         if zero:
-            self.emit(lambda ws, t=t: H.op_memset(t, t.numel() * t.element_size()))
+            self.emit(H.op_memset(t, t.numel() * t.element_size()))
         return t
 
     def free(self, *ts):
@@ -59,15 +61,23 @@ class Plan:
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
 
     # ---- ops
-    def emit(self, rec):
-        self.recs.append(rec)
+    def emit(self, op, ws_slot=None, wsb_slot=None):
+        """Appends an op record (built eagerly: records hold raw device pointers, the tensors stay alive in
+        `self.live` / the parameter store).  ws_slot / wsb_slot: pointer / int slots that receive the shared
+        workspace pointer and its size when the plan is compiled."""
+        self.recs.append(op)
+        if ws_slot is not None:
+            self.ws_patch.append((len(self.recs) - 1, ws_slot, wsb_slot))
         return len(self.recs) - 1
 
     def compile(self):
         self.ws = torch.empty(self.ws_bytes // 4 + 64, dtype=torch.float32, device=self.device)
-        ops = [r(self.ws) for r in self.recs]
-        self.arr = H.ops_array(ops)
-        self.n = len(ops)
+        self.arr = H.ops_array(self.recs)
+        self.n = len(self.recs)
+        for idx, ws_slot, wsb_slot in self.ws_patch:
+            self.arr[idx].p[ws_slot] = self.ws.data_ptr()
+            if wsb_slot is not None:
+                self.arr[idx].i[wsb_slot] = self.ws_bytes
         return self
 
     def run(self, first=0, last=None, stream=None):
@@ -75,6 +85,13 @@ class Plan:
         if self.device.type != "cuda":
             raise H.PdaeError("pdae_amd plans only execute on a ROCm device (no CPU fallback)")
         last = self.n if last is None else last
+        if os.environ.get("PDAE_DEBUG_SYNC"):          # one op at a time, synchronised, index printed first
+            import sys
+            for k in range(first, last):
+                print(f"[pdae] op {k}/{self.n} kind {self.arr[k].kind} i={list(self.arr[k].i)[:17]}", file=sys.stderr, flush=True)
+                H.run_ops(self.arr[k], 1, stream)
+                torch.cuda.synchronize()
+            return
         if last > first:
             import ctypes
             sub = ctypes.cast(ctypes.addressof(self.arr) + first * ctypes.sizeof(H.PdaeOp), ctypes.POINTER(H.PdaeOp * (last - first))).contents
@@ -107,7 +124,7 @@ class Builder:
         c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=k, stride=stride, up=up)
         assert w.numel() == c.Cout * k * k * c.Cin, (wname, tuple(w.shape), c.Cin)
         y = self.p.buf(N, c.Ho, c.Wo, c.Cout)
-        self.p.emit(lambda ws: H.op_conv_fwd(c, x0, x1, w, b, y, res=res, res_mode=res_mode))
+        self.p.emit(H.op_conv_fwd(c, x0, x1, w, b, y, res=res, res_mode=res_mode))
         return y, NS(c=c, x0=x0, x1=x1, wname=wname, y=y)
 
     def conv_bwd_params(self, cx, dy):
@@ -117,19 +134,19 @@ class Builder:
         if gw is not None:
             wsb = c.wgrad_ws_bytes()
             self.p.need_ws(wsb)
-            self.p.emit(lambda ws: H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, ws, self.p.ws_bytes))
+            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0), ws_slot=4, wsb_slot=14)
         gb = self.Gr.get(cx.wname + ".bias")
         if gb is not None:
             M = c.N * c.Ho * c.Wo
             self.p.need_ws(H.colsum_ws_bytes(M, c.Cout))
-            self.p.emit(lambda ws: H.op_colsum(dy, M, c.Cout, gb, ws))
+            self.p.emit(H.op_colsum(dy, M, c.Cout, gb, None), ws_slot=2)
 
     def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0):
         c = cx.c
         ci_cnt = c.Cin if ci_cnt is None else ci_cnt
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
-        self.p.emit(lambda ws: H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate))
+        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate))
         return dx
 
     def linear(self, x, wname, pre_bias=True):
@@ -138,7 +155,7 @@ class Builder:
         out = w.shape[0]
         assert w.numel() == out * K, (wname, tuple(w.shape), K)
         y = self.p.buf(Nb, out)
-        self.p.emit(lambda ws: H.op_gemm(0, 1, Nb, out, K, x, K, w, K, y, out, bias=b))
+        self.p.emit(H.op_gemm(0, 1, Nb, out, K, x, K, w, K, y, out, bias=b))
         return y, NS(x=x, wname=wname, Nb=Nb, K=K, out=out)
 
     def linear_bwd(self, lx, dy, dx=None, dx_acc=0):
@@ -147,16 +164,16 @@ class Builder:
         w = self.P[lx.wname + ".weight"]
         gw, gb = self.Gr.get(lx.wname + ".weight"), self.Gr.get(lx.wname + ".bias")
         if gw is not None:
-            self.p.emit(lambda ws: H.op_gemm(1, 0, out, K, Nb, dy, out, lx.x, K, gw, K))
+            self.p.emit(H.op_gemm(1, 0, out, K, Nb, dy, out, lx.x, K, gw, K))
         if gb is not None:
             self.p.need_ws(H.colsum_ws_bytes(Nb, out))
-            self.p.emit(lambda ws: H.op_colsum(dy, Nb, out, gb, ws))
+            self.p.emit(H.op_colsum(dy, Nb, out, gb, None), ws_slot=2)
         if dx is not None:
-            self.p.emit(lambda ws: H.op_gemm(0, 0, Nb, K, out, dy, out, w, K, dx, K, accumulate=dx_acc))
+            self.p.emit(H.op_gemm(0, 0, Nb, K, out, dy, out, w, K, dx, K, accumulate=dx_acc))
 
     def silu(self, x):
         y = self.p.buf(*x.shape)
-        self.p.emit(lambda ws: H.op_silu(x, y, x.numel()))
+        self.p.emit(H.op_silu(x, y, x.numel()))
         return y
 
     def gn(self, x0, x1, gname, ss=None, zss=None, act=1, mode=0, want_xpool=False, dropout=False):
@@ -171,14 +188,14 @@ class Builder:
         Ho, Wo = (Hh // 2, W // 2) if mode == 1 else (Hh, W)
         y = pl.buf(N, Ho, Wo, C)
         xpool = pl.buf(N, Ho, Wo, C) if (mode == 1 and want_xpool) else None
-        pl.emit(lambda ws: H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, mean, rstd, ws))
-        pl.emit(lambda ws: H.op_gn_coef(N, C, GROUPS, mean, rstd, gamma, beta, ss, zss, coef))
+        pl.emit(H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, mean, rstd, None), ws_slot=4)
+        pl.emit(H.op_gn_coef(N, C, GROUPS, mean, rstd, gamma, beta, ss, zss, coef))
         dp = self.drop_p if dropout else 0.0
         layer = 0
         if dp > 0:
             self.drop_layers += 1
             layer = self.drop_layers
-        idx = pl.emit(lambda ws: H.op_gn_apply(x0, C0, x1, C1, N, Hh, W, coef, act, mode, y, xpool=xpool, drop_p=dp, seed=layer, offset=0))
+        idx = pl.emit(H.op_gn_apply(x0, C0, x1, C1, N, Hh, W, coef, act, mode, y, xpool=xpool, drop_p=dp, seed=layer, offset=0))
         if dp > 0:
             pl.drop_ops.append((idx, 7, 8))
         ctx = NS(x0=x0, x1=x1, C0=C0, C1=C1, N=N, H=Hh, W=W, gname=gname, ss=ss, zss=zss, act=act, mode=mode, mean=mean, rstd=rstd,
@@ -196,9 +213,9 @@ class Builder:
         dss = pl.buf(g.N, 2 * C) if (want_dss and g.ss is not None) else None
         dzss = pl.buf(g.N, 2 * C) if (want_dzss and g.zss is not None) else None
         pl.need_ws(H.gn_ws_bytes(g.N, C))
-        idx = pl.emit(lambda ws: H.op_gn_bwd(g.x0, g.C0, g.x1, g.C1, g.N, g.H, g.W, GROUPS, g.coef, g.rstd, gamma, beta, g.ss, g.zss, dA, g.act,
-                                             bmode, ws, add=add, dx0=dx0, acc0=acc0, dx1=dx1, acc1=acc1, dgamma=dgamma, dbeta=dbeta, dss=dss,
-                                             dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0))
+        idx = pl.emit(H.op_gn_bwd(g.x0, g.C0, g.x1, g.C1, g.N, g.H, g.W, GROUPS, g.coef, g.rstd, gamma, beta, g.ss, g.zss, dA, g.act,
+                                  bmode, None, add=add, dx0=dx0, acc0=acc0, dx1=dx1, acc1=acc1, dgamma=dgamma, dbeta=dbeta, dss=dss,
+                                  dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0), ws_slot=16)
         if g.drop_p > 0:
             pl.drop_ops.append((idx, 11, 12))
         return dss, dzss
@@ -294,10 +311,10 @@ class Builder:
         Pm = pl.buf(N * heads, T, T)
         o = pl.buf(N, Hh, W, C)
         qp, kp, vp = qkv.data_ptr() + 4 * oq, qkv.data_ptr() + 4 * ok, qkv.data_ptr() + 4 * ov
-        pl.emit(lambda ws: H.op_gemm(0, 1, T, T, ch, qp, 3 * C, kp, 3 * C, Pm, T, alpha=scale2, batch_outer=N, batch_inner=heads,
+        pl.emit(H.op_gemm(0, 1, T, T, ch, qp, 3 * C, kp, 3 * C, Pm, T, alpha=scale2, batch_outer=N, batch_inner=heads,
                                      sA=(T * 3 * C, hs), sB=(T * 3 * C, hs), sC=(heads * T * T, T * T)))
-        pl.emit(lambda ws: H.op_softmax(Pm, N * heads * T, T))
-        pl.emit(lambda ws: H.op_gemm(0, 0, T, ch, T, Pm, T, vp, 3 * C, o, C, batch_outer=N, batch_inner=heads,
+        pl.emit(H.op_softmax(Pm, N * heads * T, T))
+        pl.emit(H.op_gemm(0, 0, T, ch, T, Pm, T, vp, 3 * C, o, C, batch_outer=N, batch_inner=heads,
                                      sA=(heads * T * T, T * T), sB=(T * 3 * C, hs), sC=(T * C, ch)))
         out, cp = self.conv(o, None, pre + ".proj_out", 1, res=x, res_mode=1)
         if not self.save:
@@ -319,13 +336,13 @@ class Builder:
         bQ = (T * 3 * C, hs)
         bO = (T * C, ch)
         # dV[s,c] = sum_t P[t,s] dO[t,c]
-        pl.emit(lambda ws: H.op_gemm(1, 0, T, ch, T, a.Pm, T, d_o, C, dvp, 3 * C, batch_outer=N, batch_inner=heads, sA=bA, sB=bO, sC=bQ))
+        pl.emit(H.op_gemm(1, 0, T, ch, T, a.Pm, T, d_o, C, dvp, 3 * C, batch_outer=N, batch_inner=heads, sA=bA, sB=bO, sC=bQ))
         # dP[t,s] = sum_c dO[t,c] v[s,c]
-        pl.emit(lambda ws: H.op_gemm(0, 1, T, T, ch, d_o, C, vp, 3 * C, dP, T, batch_outer=N, batch_inner=heads, sA=bO, sB=bQ, sC=bA))
-        pl.emit(lambda ws: H.op_softmax_bwd(a.Pm, dP, N * heads * T, T))
+        pl.emit(H.op_gemm(0, 1, T, T, ch, d_o, C, vp, 3 * C, dP, T, batch_outer=N, batch_inner=heads, sA=bO, sB=bQ, sC=bA))
+        pl.emit(H.op_softmax_bwd(a.Pm, dP, N * heads * T, T))
         # dQ = scale2 * dS K ; dK = scale2 * dS^T Q
-        pl.emit(lambda ws: H.op_gemm(0, 0, T, ch, T, dP, T, kp, 3 * C, dqp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
-        pl.emit(lambda ws: H.op_gemm(1, 0, T, ch, T, dP, T, qp, 3 * C, dkp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
+        pl.emit(H.op_gemm(0, 0, T, ch, T, dP, T, kp, 3 * C, dqp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
+        pl.emit(H.op_gemm(1, 0, T, ch, T, dP, T, qp, 3 * C, dkp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
         pl.free(d_o, dP)
         self.conv_bwd_params(a.cq, dqkv)
         dx = None

@@ -1,0 +1,119 @@
+"""GPU: planned networks (UNet / ShiftUNet / encoders) through the HIP path against
+  (a) the committed golden vectors produced by the reference itself, and
+  (b) the CPU oracle on the same seeded weights.
+Tolerance: 1e-4 relative for network outputs and the loss (north_star), 1e-3 on gradient norms
+(reduction-order noise through ~50 layers), small gradients compared element-wise at 2e-3."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import load_golden, T, rel_err
+from tests.golden import make_fixtures_cfg as C
+from oracle import pdae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def load_into(net, sd):
+    net.load_state_dict({k: v for k, v in sd.items()})
+    return net
+
+
+def check_grads(G, g, prefix="", tol_norm=1e-3, tol_elem=2e-3):
+    keys = [str(k) for k in g["grad_keys"]]
+    # gradients that are analytically zero (a bias feeding a GroupNorm with one channel per group) are pure
+    # rounding noise on both sides: floor the comparison at 1e-6 of the largest gradient norm / value
+    floor_n = 1e-6 * float(np.max(g["grad_summary"][:, 1]))
+    floor_e = 1e-6 * float(np.max(g["grad_summary"][:, 2]))
+    bad = []
+    for k, (gs, gn, gm) in zip(keys, g["grad_summary"]):
+        if not k.startswith(prefix):
+            continue
+        got = G[k[len(prefix):]]
+        n = float(got.double().norm())
+        if abs(n - gn) > tol_norm * gn + floor_n:
+            bad.append((k, n, gn))
+    assert not bad, bad[:8]
+    for k in g:
+        if k.startswith("g__" + prefix):
+            ref = T(g[k]).double()
+            err = float((G[k[3 + len(prefix):]].detach().double().cpu() - ref).abs().max())
+            assert err < tol_elem * float(ref.abs().max()) + floor_e, (k, err)
+
+
+@pytest.mark.parametrize("tag,cfg", [("unet_a", C.CFG_UNET_A), ("unet_b", C.CFG_UNET_B)])
+def test_unet_forward_backward_vs_golden(tag, cfg):
+    from pdae_amd.model.unet import UNet
+    g = load_golden(tag)
+    net = load_into(UNet(device=DEV, **cfg), O.synth_state_dict(O.unet_param_shapes(cfg), int(g["seed"])))
+    x_t, t = T(g["x_t"]).to(DEV), T(g["t"]).to(DEV)
+    cond = T(g["cond"]).to(DEV) if g["cond"].size else None
+    with torch.no_grad():
+        out = net(x_t, t, cond)
+    assert out.shape == x_t.shape
+    assert rel_err(out, g["out"]) < 1e-4
+    # training path through the autograd bridge (regular_train_one_batch, gaussian_diffusion.py:199-211)
+    noise = T(g["noise"]).to(DEV)
+    net.train()
+    out = net(x_t, t, cond)
+    loss = torch.mean((noise - out) ** 2)
+    assert abs(loss.item() - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    check_grads(net.grads(), g)
+    assert net.P["out.2.weight"].grad is net.grads()["out.2.weight"]
+
+
+def test_shift_unet_forward_vs_golden_and_oracle():
+    from pdae_amd.model.shift_unet import ShiftUNet
+    g = load_golden("shift_tiny")
+    cfg, latent = C.CFG_SHIFT_T, int(g["latent"])
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=latent), int(g["seed"]))
+    net = load_into(ShiftUNet(device=DEV, latent_dim=latent, **cfg), sd)
+    with torch.no_grad():
+        eps, shift = net(T(g["x"]).to(DEV), T(g["t"]).to(DEV), T(g["z"]).to(DEV))
+    assert rel_err(eps, g["eps"]) < 1e-4 and rel_err(shift, g["shift"]) < 1e-4
+    # a different batch size / odd spatial size against the oracle (plan cache keyed by shape)
+    x = torch.randn(3, 3, 24, 24, generator=torch.Generator().manual_seed(5))
+    t = torch.tensor([0, 999, 312])
+    z = torch.randn(3, latent, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        eps, shift = net(x.to(DEV), t.to(DEV), z.to(DEV))
+        e_ref, s_ref = O.shift_unet_forward(sd, cfg, x, t, z)
+    assert rel_err(eps, e_ref) < 1e-4 and rel_err(shift, s_ref) < 1e-4
+
+
+def test_encoder_ffhq_vs_golden():
+    from pdae_amd.model.representation_learning.encoder import FFHQEncoder
+    g = load_golden("misc")
+    enc = load_into(FFHQEncoder(device=DEV, latent_dim=512), O.synth_state_dict(O.encoder_param_shapes("FFHQEncoder", 512), 41))
+    with torch.no_grad():
+        z = enc(T(g["enc_x0"]).to(DEV))
+    assert rel_err(z, g["enc_z"]) < 1e-4
+
+
+def test_rl_train_step_through_autograd_bridge_vs_golden():
+    """representation_learning_train_one_batch (gaussian_diffusion.py:234-255) + backward, (t, noise) injected."""
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
+    g = load_golden("rl_step")
+    cfg = C.CFG_SHIFT_64
+    enc = load_into(CELEBA64Encoder(device=DEV, latent_dim=512), O.synth_state_dict(O.encoder_param_shapes("CELEBA64Encoder", 512), int(g["seed_enc"])))
+    dec = load_into(ShiftUNet(device=DEV, latent_dim=512, **cfg), O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=512), int(g["seed_dec"])))
+    enc.train(); dec.set_train_mode()
+    s = O.Schedules()
+    x0, t, noise = T(g["x0"]).to(DEV), T(g["t0"]).to(DEV), T(g["noise0"]).to(DEV)
+    z = enc(x0)
+    assert rel_err(z, g["z"]) < 1e-4
+    x_t = O.q_sample(s, T(g["x0"]), T(g["t0"]), T(g["noise0"])).to(DEV)
+    eps, shift = dec(x_t, t, z)
+    assert rel_err(eps, g["eps"]) < 1e-4 and rel_err(shift, g["shift"]) < 1e-4
+    sc = s.shift_coef.to(DEV)[t].view(-1, 1, 1, 1)
+    w = s.weight.to(DEV)[t].view(-1, 1, 1, 1)
+    loss = torch.mean(w * (noise - (eps + sc * shift)) ** 2)
+    assert abs(loss.item() - float(g["loss0"])) < 1e-4 * abs(float(g["loss0"]))
+    loss.backward()
+    check_grads(dec.grads(), g, prefix="dec::")
+    check_grads(enc.grads(), g, prefix="enc::")
+    # frozen half: no gradient buffers exist for it
+    assert "out.2.weight" not in dec.grads() and "input_blocks.0.0.weight" not in dec.grads()
