@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Benchmark of the PDAE hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one complete representation-learning optimisation step (BASELINE.json metric, config
+ffhq_representation_learning): FFHQEncoder forward, q_sample, ShiftUNet forward (frozen trunk + eps branch +
+trainable shift branch), weighted L2 loss, backward through the shift branch and the encoder, (all-reduce of the
+82.4 M trainable gradients when N>1), Adam and EMA -- fp32, per-GPU batch 32, 3x128x128 synthetic images already
+resident in HBM, randomly initialised weights of the FFHQ-128 architecture ([ASSUMED] Diff-AE-compatible
+hyper-parameters).  Nothing is skipped inside the timed region.
+
+Rank 0 prints ONE JSON line; `value` is whole-job images/s.  Extra objects:
+  roofline     -- the dominant kernel family (igemm_kernel: f32-MFMA implicit-GEMM conv fwd/dgrad/wgrad + dense GEMM):
+                  algorithmic FLOPs of its launches in one step / their summed durations, measured here with HIP events
+                  on the launch stream (per-op event pairs, one extra un-timed step);
+  cpu_baseline -- the CPU oracle (torch fp32, all host threads) running the same step on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# FFHQ-128 UNet hyper-parameters: NOT in the reference tree (pre-trained-dpms/ffhq128/config.yml is a download);
+# Diff-AE-compatible values implied by the checkpoint key names -- [ASSUMED], SURVEY.md section 0.2.
+FFHQ128 = dict(input_channel=3, base_channel=128, channel_multiplier=[1, 1, 2, 3, 4], num_residual_blocks_of_a_block=2,
+               attention_resolutions=[8], num_heads=1, head_channel=-1, use_new_attention_order=False, dropout=0.1)
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+TRAIN_GFLOP_PER_IMG = 481.4         # fwd 258.4 + 2 x 110.7 (shift-branch bwd) + 3 x 0.549 (encoder)
+FWD_GFLOP_PER_IMG = 258.4
+
+
+def randomize(net, seed):
+    """random-init weights of the architecture; the reference's zero-initialised layers are randomised too so no
+    kernel sees all-zero operands (zero data raises clocks: guide 5.4 rule 25)."""
+    g = torch.Generator(device=net.device).manual_seed(seed)
+    with torch.no_grad():
+        for k, p in net.P.items():
+            if p.dim() > 1 and float(p.abs().max()) == 0.0:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g, device=net.device) / fan_in ** 0.5)
+
+
+def op_flops(op):
+    """Algorithmic FLOPs of one igemm-family op record (0 for everything else)."""
+    from pdae_amd import hip as H
+    i = op.i
+    if op.kind in (H.OP_CONV_FWD, H.OP_CONV_WGRAD):
+        N, Ho, Wo, Cout, KH, KW, cin = i[0], i[5], i[6], i[7], i[8], i[9], i[3] + i[4]
+        return 2.0 * N * Ho * Wo * Cout * KH * KW * cin
+    if op.kind == H.OP_CONV_DGRAD:
+        N, Hi, Wi, Cout, KH, KW, up = i[0], i[1], i[2], i[7], i[8], i[9], i[12]
+        s = 2 if up else 1
+        return 2.0 * N * (Hi * s) * (Wi * s) * i[14] * KH * KW * Cout
+    if op.kind == H.OP_GEMM:
+        return 2.0 * i[2] * i[3] * i[4] * i[14] * i[15]
+    return 0.0
+
+
+def profile_plan(plan, first, last):
+    """Per-op durations (ms) of plan ops [first, last) with HIP events on the launch stream."""
+    from pdae_amd import hip as H
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(last - first + 1)]
+    torch.cuda.synchronize()
+    for k in range(first, last):
+        evs[k - first].record()
+        H.run_ops(plan.arr[k], 1)
+    evs[-1].record()
+    torch.cuda.synchronize()
+    return [evs[j].elapsed_time(evs[j + 1]) for j in range(last - first)]
+
+
+def cpu_baseline(batch, steps):
+    """The CPU oracle (oracle/pdae_oracle.py, validated against the reference by tests/test_oracle_golden.py)
+    running the same train step: forward + autograd backward + Adam + EMA on all host threads."""
+    from oracle import pdae_oracle as O
+    torch.manual_seed(0)
+    cfg = dict(FFHQ128, dropout=0.0)
+    enc_sd = O.synth_state_dict(O.encoder_param_shapes("FFHQEncoder", 512), 1)
+    dec_sd = O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=512), 2)
+    s = O.Schedules()
+    train = {"e:" + k: v for k, v in enc_sd.items()}
+    train.update({"d:" + k: v for k, v in dec_sd.items() if O.shift_unet_trainable(k)})
+    m = {k: torch.zeros_like(v) for k, v in train.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in train.items()}
+    ema = {k: v.clone() for k, v in train.items()}
+    x0 = torch.rand(batch, 3, 128, 128) * 2 - 1
+    times = []
+    for step in range(steps + 1):
+        t0 = time.perf_counter()
+        for p in train.values():
+            p.requires_grad_(True)
+            p.grad = None
+        t = torch.randint(0, 1000, (batch,))
+        noise = torch.randn_like(x0)
+        loss = O.rl_loss(s, enc_sd, "FFHQEncoder", dec_sd, cfg, x0, t, noise)
+        loss.backward()
+        with torch.no_grad():
+            for k, p in train.items():
+                pn, m[k], v2[k] = O.adam_step(p.detach(), p.grad, m[k], v2[k], step + 1, 1e-4)
+                p.requires_grad_(False)
+                p.copy_(pn)
+                ema[k] = O.ema_update(ema[k], p, 0.9999)
+        times.append(time.perf_counter() - t0)
+    best = sorted(times[1:])[len(times[1:]) // 2]
+    return batch / best, best
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (config/ffhq_representation_learning.yml:29)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    import copy
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from pdae_amd.model.representation_learning.encoder import FFHQEncoder
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from pdae_amd.trainer.fused_step import FusedRLStep
+    from pdae_amd.utils import set_seed
+
+    log("building networks")
+    set_seed(0)                                    # identical weights on every rank (trainer/base_trainer.py:27-28)
+    enc = FFHQEncoder(device=dev, latent_dim=512)
+    dec = ShiftUNet(device=dev, latent_dim=512, **FFHQ128)
+    randomize(enc, 11)
+    randomize(dec, 12)
+    enc.train()
+    dec.set_train_mode()
+    ema_enc, ema_dec = copy.deepcopy(enc), copy.deepcopy(dec)
+    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, dev)
+    B = args.batch
+    log("building the fused step plan")
+    st = FusedRLStep(gd, enc, dec, ema_enc, ema_dec, B, 128, 128, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                     ema_decay=0.9999, ema_every=1, num_iterations=1)
+    log(f"plan: {st.plan.n} ops, {st.plan.bytes_alloc / 2**30:.1f} GiB of activations/workspaces")
+    set_seed(rank)                                 # per-rank data / noise streams (base_trainer.py:50-52)
+    x0 = torch.rand(B, 3, 128, 128, device=dev) * 2 - 1
+
+    for _ in range(args.warmup):
+        st.step(x0)
+        torch.cuda.synchronize()
+        log("warm-up step done")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st.step(x0)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = st.last_loss
+    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
+    ms_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    out = {"metric": "train_images_per_sec_ffhq128_representation_learning", "value": round(value, 3), "unit": "images/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "config/ffhq_representation_learning.yml: PDAE representation learning, FFHQ-128 [ASSUMED denoise_fn_config], "
+                                  "encoder FFHQEncoder + ShiftUNet, Adam lr 1e-4, EMA 0.9999, dropout 0.1",
+                      "per_gpu_batch": B, "global_batch": B * world, "image": "3x128x128", "parallelism": f"dp{world}",
+                      "params_total": int(sum(p.numel() for p in dec.P.values()) + sum(p.numel() for p in enc.P.values())),
+                      "params_trainable": int(sum(p.numel() for p in dec.P.values() if p.requires_grad) + sum(p.numel() for p in enc.P.values()))},
+           "images_per_sec_per_gpu": round(value / world, 3), "final_loss": round(loss_val, 6),
+           "step_tflops_algorithmic": round(TRAIN_GFLOP_PER_IMG * B / ms_step, 3),
+           "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMG * B / ms_step / PEAK_F32_MFMA_TFLOPS, 4)}
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family, live, with HIP events (one extra, un-timed step)
+        st.load_batch(x0)
+        durs = profile_plan(st.plan, 0, st.n_bwd)
+        fl = [op_flops(st.plan.arr[k]) for k in range(st.n_bwd)]
+        ig_ms = sum(d for d, f in zip(durs, fl) if f > 0)
+        ig_fl = sum(fl)
+        n_ig = sum(1 for f in fl if f > 0)
+        # the single heaviest launch (conv3x3 on the 128x128 grid)
+        kbig = max(range(st.n_bwd), key=lambda k: fl[k])
+        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (f32 MFMA implicit GEMM: conv fwd/dgrad/wgrad, dense GEMM)",
+                           "achieved": round(ig_fl / ig_ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ig_fl / ig_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": n_ig, "algorithmic_gflop_per_step": round(ig_fl / 1e9, 1),
+                           "family_ms_per_step": round(ig_ms, 3), "all_ops_ms_per_step": round(sum(durs), 3),
+                           "heaviest_launch": {"gflop": round(fl[kbig] / 1e9, 2), "ms": round(durs[kbig], 4),
+                                               "tflops": round(fl[kbig] / durs[kbig] / 1e9, 2)}}
+        st.micro = 0
+        log("per-op profile done")
+        # ---- DDIM-100 sampling throughput (second half of the BASELINE metric): 100 ShiftUNet forwards + fused updates
+        if not args.no_ddim:
+            dec.set_eval_mode()
+            with torch.no_grad():
+                z = torch.randn(B, 512, device=dev)
+                xT = torch.randn(B, 3, 128, 128, device=dev)
+                gd.representation_learning_ddim_sample("ddim10", None, dec, None, xT, z)       # builds the inference plan
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                gd.representation_learning_ddim_sample("ddim100", None, dec, None, xT, z)
+                torch.cuda.synchronize()
+                dd = time.perf_counter() - t1
+            log("ddim100 done")
+            out["ddim100"] = {"samples_per_sec": round(B / dd, 3), "batch": B, "seconds": round(dd, 3),
+                              "tflops_algorithmic": round(FWD_GFLOP_PER_IMG * B * 100 / dd / 1e3, 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            torch.set_num_threads(os.cpu_count() or 1)
+            ips, sec = cpu_baseline(args.cpu_batch, 2)
+            out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"same FFHQ-128 train step (fwd+bwd+Adam+EMA, dropout off), batch {args.cpu_batch}, "
+                                             f"median of 2 timed steps after 1 warm-up ({sec:.1f} s/step)"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

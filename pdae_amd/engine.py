@@ -107,8 +107,9 @@ class Builder:
     """Emits fused stages into a Plan.  `grads` maps parameter name -> gradient tensor (same memory
     layout as the parameter); presence of a name means that parameter is trained by this plan."""
 
-    def __init__(self, plan, params, grads=None, save=False, drop_p=0.0):
+    def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False):
         self.p = plan
+        self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
         self.P = params
         self.Gr = grads or {}
         self.save = save          # keep activations for backward (else buffers are recycled)
@@ -134,12 +135,12 @@ class Builder:
         if gw is not None:
             wsb = c.wgrad_ws_bytes()
             self.p.need_ws(wsb)
-            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0), ws_slot=4, wsb_slot=14)
+            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc), ws_slot=4, wsb_slot=14)
         gb = self.Gr.get(cx.wname + ".bias")
         if gb is not None:
             M = c.N * c.Ho * c.Wo
             self.p.need_ws(H.colsum_ws_bytes(M, c.Cout))
-            self.p.emit(H.op_colsum(dy, M, c.Cout, gb, None), ws_slot=2)
+            self.p.emit(H.op_colsum(dy, M, c.Cout, gb, None, acc=self.acc), ws_slot=2)
 
     def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0):
         c = cx.c
@@ -164,10 +165,10 @@ class Builder:
         w = self.P[lx.wname + ".weight"]
         gw, gb = self.Gr.get(lx.wname + ".weight"), self.Gr.get(lx.wname + ".bias")
         if gw is not None:
-            self.p.emit(H.op_gemm(1, 0, out, K, Nb, dy, out, lx.x, K, gw, K))
+            self.p.emit(H.op_gemm(1, 0, out, K, Nb, dy, out, lx.x, K, gw, K, accumulate=self.acc))
         if gb is not None:
             self.p.need_ws(H.colsum_ws_bytes(Nb, out))
-            self.p.emit(H.op_colsum(dy, Nb, out, gb, None), ws_slot=2)
+            self.p.emit(H.op_colsum(dy, Nb, out, gb, None, acc=self.acc), ws_slot=2)
         if dx is not None:
             self.p.emit(H.op_gemm(0, 0, Nb, K, out, dy, out, w, K, dx, K, accumulate=dx_acc))
 
@@ -214,7 +215,7 @@ class Builder:
         dzss = pl.buf(g.N, 2 * C) if (want_dzss and g.zss is not None) else None
         pl.need_ws(H.gn_ws_bytes(g.N, C))
         idx = pl.emit(H.op_gn_bwd(g.x0, g.C0, g.x1, g.C1, g.N, g.H, g.W, GROUPS, g.coef, g.rstd, gamma, beta, g.ss, g.zss, dA, g.act,
-                                  bmode, None, add=add, dx0=dx0, acc0=acc0, dx1=dx1, acc1=acc1, dgamma=dgamma, dbeta=dbeta, dss=dss,
+                                  bmode, None, add=add, dx0=dx0, acc0=acc0, dx1=dx1, acc1=acc1, dgamma=dgamma, dbeta=dbeta, acc_param=self.acc, dss=dss,
                                   dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0), ws_slot=16)
         if g.drop_p > 0:
             pl.drop_ops.append((idx, 11, 12))

@@ -309,20 +309,26 @@ def _head_backward(B, hd, dy):
     return dh
 
 
-def shift_backward(B, fx, d_shift):
+def shift_backward(B, fx, d_shift, mark=None):
     """Backward of the trainable half of ShiftUNet (label_emb, shift_middle_block, shift_output_blocks, shift_out;
-    shift_unet.py:299-310).  d_shift: NHWC gradient of the `shift` output.  Returns dz [N, latent]."""
+    shift_unet.py:299-310).  d_shift: NHWC gradient of the `shift` output.  Returns dz [N, latent].
+    mark(prefix): called when every parameter gradient under `prefix` has been emitted (DDP bucket boundaries)."""
     pl = B.p
+    mark = mark or (lambda prefix: None)
     N, E = fx.semb.shape
     d_eza = pl.buf(N, E, zero=True)
     dh = _head_backward(B, fx.shead, d_shift)
+    mark("shift_out.")
     for i in range(len(fx.sout_ctx) - 1, -1, -1):
         dh, _ = _block_backward(B, fx.sout_ctx[i], dh, None, d_eza)
+        mark(f"shift_output_blocks.{i}.")
     _block_backward(B, fx.smid_ctx, dh, None, d_eza, need_dx0_first=False)
+    mark("shift_middle_block.")
     d_semb = pl.buf(N, E)
     pl.emit(H.op_silu_bwd(fx.semb, d_eza, d_semb, N * E))
     dz = pl.buf(N, fx.z.shape[1])
     B.linear_bwd(fx.l_lab, d_semb, dx=dz, dx_acc=0)
+    mark("label_emb.")
     pl.free(d_eza, d_semb)
     return dz
 

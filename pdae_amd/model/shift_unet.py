@@ -1,4 +1,6 @@
 """ShiftUNet front-end (model/shift_unet.py:29-44, 253-310): frozen pre-trained UNet + trainable shift branch."""
+import random
+
 import torch
 
 from .. import hip as H
@@ -80,7 +82,7 @@ class ShiftUNet(PlannedNet):
             p.t.copy_(time)
             p.z.copy_(zz)
             if p.drop_ops:
-                p.set_dropout(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), 0)
+                p.set_dropout(random.getrandbits(31), 0)
             p.run(0, p.n_fwd)
             return as_nchw(p.eps), as_nchw(p.shift)
 

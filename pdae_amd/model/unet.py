@@ -1,4 +1,6 @@
 """UNet front-end with the reference constructor / forward signature (model/unet.py:30-45, 177-202)."""
+import random
+
 import torch
 
 from .. import hip as H
@@ -67,7 +69,7 @@ class UNet(PlannedNet):
             if p.cond is not None:
                 p.cond.copy_(condition)
             if p.drop_ops:
-                p.set_dropout(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), 0)
+                p.set_dropout(random.getrandbits(31), 0)
             p.run(0, p.n_fwd)
             return (as_nchw(p.eps),)
 

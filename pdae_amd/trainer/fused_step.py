@@ -1,0 +1,159 @@
+"""One representation-learning optimisation step as a single planned graph.
+
+Replaces the body of RepresentationLearningTrainer.train (trainer/train_representation_learning.py:81-124):
+    zero_grad -> encoder fwd -> randint/randn -> q_sample -> ShiftUNet fwd -> weighted L2 -> backward
+    (DDP all-reduce of the trainable gradients) -> Adam -> EMA
+with one static op list over pre-allocated buffers:
+  * the frozen trunk / eps-branch keep no activations and emit no backward;
+  * loss and d(loss)/d(shift) come out of one kernel; the loss stays on the device (the reference's two
+    `.item()` syncs per micro-batch, :107-108, are gone -- read `last_loss` when you want the value);
+  * gradients live in two flat buffers (decoder-trainable, encoder); the data-parallel exchange is an
+    all-reduce(sum) over contiguous ranges of them, launched as soon as the backward has finished each range
+    (reverse execution order) so RCCL overlaps with the rest of the backward; 1/world is folded into Adam;
+  * Adam (torch.optim.Adam semantics) and the EMA update are one kernel per flat buffer.
+"""
+import math
+import random
+
+import torch
+import torch.distributed as dist
+
+from .. import hip as H
+from ..engine import Plan, Builder
+from ..model import graph as G
+
+
+class FusedRLStep:
+    def __init__(self, gaussian_diffusion, encoder, decoder, ema_encoder, ema_decoder, batch, height, width, lr=1e-4, betas=(0.9, 0.999),
+                 eps=1e-8, weight_decay=0.0, decoupled=False, ema_decay=0.9999, ema_every=1, num_iterations=1, process_group=None,
+                 bucket_mb=48):
+        gd = gaussian_diffusion
+        self.gd, self.enc, self.dec, self.ema_enc, self.ema_dec = gd, encoder, decoder, ema_encoder, ema_decoder
+        self.N, self.Hh, self.W = batch, height, width
+        self.lr, self.b1, self.b2, self.eps, self.wd, self.decoupled = lr, betas[0], betas[1], eps, weight_decay, int(decoupled)
+        self.ema_decay, self.ema_every, self.num_iterations = ema_decay, ema_every, num_iterations
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.step_count = 0
+        self.micro = 0
+        dev = decoder.device
+        cfg = decoder.cfg
+        N, Hh, W, Cimg = batch, height, width, cfg["input_channel"]
+        per = Hh * W * Cimg
+        acc = num_iterations > 1
+        drop = float(cfg["dropout"]) if decoder._shift_train else 0.0
+
+        p = Plan(dev)
+        self.plan = p
+        self.x0 = p.buf(N, Hh, W, Cimg)
+        self.noise = p.buf(N, Hh, W, Cimg)
+        self.t = p.buf(N, dtype=torch.int64)
+        self.loss = p.buf(1)
+        Be = Builder(p, encoder.P, encoder.grads(), save=True, acc_grads=acc)
+        Bd = Builder(p, decoder.P, decoder.grads(), save=False, drop_p=drop, acc_grads=acc)
+        # ---- forward
+        z, ex = G.encoder_forward(Be, encoder.NAME, self.x0)
+        x_t = p.buf(N, Hh, W, Cimg)
+        p.emit(H.op_q_sample(self.x0, self.noise, self.t, gd.sqrt_alphas_cumprod, gd.sqrt_one_minus_alphas_cumprod, N, per, x_t))
+        fx = G.unet_forward(Bd, cfg, x_t, self.t, decoder.freqs, z=z, shift=True, train_shift=True, dropout=drop > 0)
+        d_shift = p.buf(N, Hh, W, Cimg)
+        p.emit(H.op_loss(self.noise, fx.eps, fx.shift, self.t, gd.shift_coef, gd.weight, N, per, self.loss, None, dg=d_shift,
+                         scale=1.0 / num_iterations), ws_slot=9)
+        self.n_fwd = len(p.recs)
+        self.z, self.eps, self.shift = z, fx.eps, fx.shift
+        # ---- backward, with the op index at which each parameter block's gradients are final
+        marks = []
+        dz = G.shift_backward(Bd, fx, d_shift, mark=lambda prefix: marks.append((len(p.recs), prefix)))
+        G.encoder_backward(Be, ex, dz)
+        self.n_bwd = len(p.recs)
+        # ---- optimizer (+EMA): one op per flat buffer; scalars are patched every step
+        self.m = [torch.zeros_like(decoder.flat_train), torch.zeros_like(encoder.flat_train)]
+        self.v = [torch.zeros_like(decoder.flat_train), torch.zeros_like(encoder.flat_train)]
+        self.adam_idx = []
+        for k, (net, ema) in enumerate([(decoder, ema_decoder), (encoder, ema_encoder)]):
+            idx = p.emit(H.op_adam_ema(net.flat_train, net.flat_grad, self.m[k], self.v[k], ema.flat_train if ema is not None else None,
+                                       net.flat_train.numel(), lr, self.b1, self.b2, eps, weight_decay, self.decoupled, lr, 1.0, 1.0, ema_decay))
+            self.adam_idx.append((idx, ema.flat_train.data_ptr() if ema is not None else 0))
+        p.compile()
+        self.buckets = self._make_buckets(marks, bucket_mb)
+
+    # ------------------------------------------------------------------ DDP buckets
+    def _make_buckets(self, marks, bucket_mb):
+        """[(op_index_after_which_ready, flat_grad_tensor_slice)] in backward order."""
+        dec = self.dec
+        limit = bucket_mb * (1 << 20) // 4
+        ranges = []
+        for op_idx, prefix in marks:
+            offs = [(o, n) for k, (tr, o, n) in dec._offs.items() if tr and k.startswith(prefix)]
+            if offs:
+                ranges.append((op_idx, min(o for o, _ in offs), max(o + n for o, n in offs)))
+        buckets, cur_hi = [], dec.flat_grad.numel()
+        pend_lo = cur_hi
+        for op_idx, lo, hi in ranges:                    # backward order: descending offsets
+            pend_lo = min(pend_lo, lo)
+            if cur_hi - pend_lo >= limit:
+                buckets.append((op_idx, dec.flat_grad[pend_lo:cur_hi]))
+                cur_hi = pend_lo
+        if cur_hi > 0:
+            buckets.append((ranges[-1][0] if ranges else self.n_bwd, dec.flat_grad[0:cur_hi]))
+        buckets.append((self.n_bwd, self.enc.flat_grad))
+        return buckets
+
+    # ------------------------------------------------------------------ one micro-batch / one step
+    def load_batch(self, x_0, t=None, noise=None):
+        """x_0 / noise: (N,C,H,W) tensors of any strides.  t, noise are drawn like the reference
+        (torch.randint then torch.randn_like, gaussian_diffusion.py:240-241) unless injected."""
+        self.x0.copy_(x_0.permute(0, 2, 3, 1))
+        if t is None:
+            t = torch.randint(0, self.gd.timesteps, (self.N,), device=self.x0.device, dtype=torch.long)
+        self.t.copy_(t)
+        if noise is None:
+            self.noise.normal_()
+        else:
+            self.noise.copy_(noise.permute(0, 2, 3, 1))
+
+    def _patch_adam(self):
+        step = self.step_count + 1
+        bc1, bc2 = 1.0 - self.b1 ** step, 1.0 - self.b2 ** step
+        use_ema = (step % self.ema_every) == 0
+        for idx, ema_ptr in self.adam_idx:
+            op = self.plan.arr[idx]
+            op.f[5] = self.lr / bc1
+            op.f[6] = 1.0 / math.sqrt(bc2)
+            op.f[7] = 1.0 / self.world
+            op.p[4] = ema_ptr if (use_ema and ema_ptr) else None
+
+    def step(self, x_0, t=None, noise=None):
+        """Runs one micro-batch; every `num_iterations`-th call also reduces gradients and applies Adam + EMA.
+        Returns the (device-resident) loss of this micro-batch."""
+        p = self.plan
+        if self.micro == 0 and self.num_iterations > 1:
+            self.dec.flat_grad.zero_()
+            self.enc.flat_grad.zero_()
+        self.load_batch(x_0, t, noise)
+        if p.drop_ops:
+            p.set_dropout(random.getrandbits(31), self.step_count * self.num_iterations + self.micro)   # host RNG: no device sync
+        last = self.micro == self.num_iterations - 1
+        works = []
+        if last and self.world > 1:
+            cur = 0
+            for op_idx, view in self.buckets:
+                p.run(cur, op_idx)
+                cur = op_idx
+                works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            p.run(cur, self.n_bwd)
+            for w in works:
+                w.wait()
+        else:
+            p.run(0, self.n_bwd)
+        self.micro += 1
+        if last:
+            self._patch_adam()
+            p.run(self.n_bwd, p.n)
+            self.step_count += 1
+            self.micro = 0
+        return self.loss
+
+    @property
+    def last_loss(self):
+        return float(self.loss.item())

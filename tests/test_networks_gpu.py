@@ -117,3 +117,45 @@ def test_rl_train_step_through_autograd_bridge_vs_golden():
     check_grads(enc.grads(), g, prefix="enc::")
     # frozen half: no gradient buffers exist for it
     assert "out.2.weight" not in dec.grads() and "input_blocks.0.0.weight" not in dec.grads()
+
+
+def test_fused_rl_step_three_steps_vs_golden():
+    """FusedRLStep (encoder fwd .. Adam+EMA in one plan): losses of 3 consecutive steps and the parameters / EMA after
+    steps 1 and 3 against torch.optim.Adam driving the reference (tests/golden/make_fixtures.py section 4)."""
+    import copy
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from pdae_amd.trainer.fused_step import FusedRLStep
+    g = load_golden("rl_step")
+    cfg = C.CFG_SHIFT_64
+    enc = load_into(CELEBA64Encoder(device=DEV, latent_dim=512), O.synth_state_dict(O.encoder_param_shapes("CELEBA64Encoder", 512), int(g["seed_enc"])))
+    dec = load_into(ShiftUNet(device=DEV, latent_dim=512, **cfg), O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=512), int(g["seed_dec"])))
+    frozen_before = dec.flat_frozen.clone()
+    enc.train(); dec.set_train_mode()
+    ema_enc, ema_dec = copy.deepcopy(enc), copy.deepcopy(dec)
+    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device(DEV))
+    st = FusedRLStep(gd, enc, dec, ema_enc, ema_dec, 2, 64, 64, lr=1e-4, ema_decay=0.9999)
+    x0 = T(g["x0"]).to(DEV)
+    for step in range(3):
+        loss = st.step(x0, t=T(g[f"t{step}"]).to(DEV), noise=T(g[f"noise{step}"]).to(DEV))
+        ref = float(g[f"loss{step}"])
+        assert abs(loss.item() - ref) < 2e-4 * abs(ref), (step, loss.item(), ref)
+        if step == 0:
+            assert rel_err(st.z, g["z"]) < 1e-4
+            check_grads(dec.grads(), g, prefix="dec::")
+            check_grads(enc.grads(), g, prefix="enc::")
+        if step in (0, 2):
+            for k in g:
+                if k.startswith(f"p{step + 1}__"):
+                    kind, name = k.split("__", 1)[1].split("::")
+                    net, ema = (enc, ema_enc) if kind == "enc" else (dec, ema_dec)
+                    # Adam's first steps move every weight by ~lr regardless of gradient scale: compare the UPDATE, not the value
+                    sd0 = O.synth_state_dict(O.encoder_param_shapes("CELEBA64Encoder", 512) if kind == "enc" else
+                                             O.unet_param_shapes(cfg, shift=True, latent_dim=512), int(g["seed_enc" if kind == "enc" else "seed_dec"]))
+                    upd_ref = T(g[k]).double() - sd0[name].double()
+                    upd = net.P[name].detach().double().cpu() - sd0[name].double()
+                    assert float((upd - upd_ref).abs().max()) < 0.02 * float(upd_ref.abs().max()) + 1e-9, k
+                    assert rel_err(ema.P[name], g[f"ema{step + 1}__{kind}::{name}"]) < 1e-6, k
+    assert torch.equal(dec.flat_frozen, frozen_before)
+    assert torch.equal(ema_dec.flat_frozen, frozen_before)
