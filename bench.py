@@ -113,6 +113,18 @@ def cpu_baseline(batch, steps):
     return batch / best, best
 
 
+def host_cores():
+    """Usable host cores: min(affinity mask, cgroup CPU quota) -- the GPU box advertises 256 logical CPUs under a 16-CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 _T0 = time.perf_counter()
 
 
@@ -128,7 +140,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (config/ffhq_representation_learning.yml:29)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=4)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -236,7 +248,8 @@ def main():
             out["ddim100"] = {"samples_per_sec": round(B / dd, 3), "batch": B, "seconds": round(dd, 3),
                               "tflops_algorithmic": round(FWD_GFLOP_PER_IMG * B * 100 / dd / 1e3, 2)}
         if world == 1 and not args.no_cpu_baseline:
-            torch.set_num_threads(os.cpu_count() or 1)
+            torch.set_num_threads(host_cores())
+            log(f"cpu baseline on {host_cores()} host cores")
             ips, sec = cpu_baseline(args.cpu_batch, 2)
             out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"same FFHQ-128 train step (fwd+bwd+Adam+EMA, dropout off), batch {args.cpu_batch}, "

@@ -273,15 +273,31 @@ int k_softmax_bwd(const float* p, float* dp, long long rows, int T, hipStream_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// column sums of a row-major [M][C] matrix (bias gradients), two deterministic stages
+// column sums of a row-major [M][C] matrix (bias gradients), two deterministic stages.
+// stage 1: block b owns a contiguous row range; its 256 threads are (row lanes) x (column threads), reduced
+// through LDS in fixed order.  stage 2: one thread per column adds the <=256 block partials.
 // ---------------------------------------------------------------------------------------------
+#define COLSUM_MAXB 256
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, long long M, int C, int rows_per, float* __restrict__ part) {
-  // block handles rows [b*rows_per, ...), thread handles columns c = threadIdx.x + 256*k
-  long long r0 = (long long)blockIdx.x * rows_per, r1 = r0 + rows_per; if (r1 > M) r1 = M;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  __shared__ float red[256];
+  const long long r0 = (long long)blockIdx.x * rows_per;
+  long long r1 = r0 + rows_per; if (r1 > M) r1 = M;
+  const int CT = C < 256 ? C : 256;            // column threads
+  const int RL = 256 / CT;                     // row lanes
+  const int t = threadIdx.x, ct = t % CT, rl = t / CT;
+  for (int c0 = 0; c0 < C; c0 += CT) {
+    const int c = c0 + ct;
     float a = 0.f;
-    for (long long r = r0; r < r1; ++r) a += x[r * C + c];
-    part[(size_t)blockIdx.x * C + c] = a;
+    if (rl < RL && c < C)
+      for (long long r = r0 + rl; r < r1; r += RL) a += x[r * C + c];
+    red[t] = a;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      float s = 0.f;
+      for (int l = 0; l < RL; ++l) s += red[l * CT + ct];
+      part[(size_t)blockIdx.x * C + c] = s;
+    }
+    __syncthreads();
   }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out, int acc) {
@@ -291,11 +307,12 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int 
   for (int b = 0; b < nb; ++b) a += part[(size_t)b * C + c];
   out[c] = acc ? out[c] + a : a;
 }
-size_t k_colsum_workspace_floats(long long M, int C) { return (size_t)1024 * C; }
+size_t k_colsum_workspace_floats(long long M, int C) { return (size_t)COLSUM_MAXB * C; }
 int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws, hipStream_t st) {
-  int nb = (int)(M < 1024 ? M : 1024);
+  long long want = (M * C + 65535) / 65536;          // >= 64K elements per block
+  int nb = (int)(want < 1 ? 1 : (want > COLSUM_MAXB ? COLSUM_MAXB : want));
   int rows_per = cdiv(M, nb); nb = cdiv(M, rows_per);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, M, C, rows_per, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, nb, C, out, acc);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, nb, C, out, acc);
   return pdae_launch_status("colsum");
 }
