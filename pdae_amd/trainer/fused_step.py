@@ -70,6 +70,7 @@ class FusedRLStep:
         self.m = [torch.zeros_like(decoder.flat_train), torch.zeros_like(encoder.flat_train)]
         self.v = [torch.zeros_like(decoder.flat_train), torch.zeros_like(encoder.flat_train)]
         self.adam_idx = []
+        self.flat_nets = [decoder, encoder]
         for k, (net, ema) in enumerate([(decoder, ema_decoder), (encoder, ema_encoder)]):
             idx = p.emit(H.op_adam_ema(net.flat_train, net.flat_grad, self.m[k], self.v[k], ema.flat_train if ema is not None else None,
                                        net.flat_train.numel(), lr, self.b1, self.b2, eps, weight_decay, self.decoupled, lr, 1.0, 1.0, ema_decay))
@@ -134,16 +135,8 @@ class FusedRLStep:
         if p.drop_ops:
             p.set_dropout(random.getrandbits(31), self.step_count * self.num_iterations + self.micro)   # host RNG: no device sync
         last = self.micro == self.num_iterations - 1
-        works = []
         if last and self.world > 1:
-            cur = 0
-            for op_idx, view in self.buckets:
-                p.run(cur, op_idx)
-                cur = op_idx
-                works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-            p.run(cur, self.n_bwd)
-            for w in works:
-                w.wait()
+            self.backward_with_allreduce(p.run)
         else:
             p.run(0, self.n_bwd)
         self.micro += 1
@@ -154,6 +147,125 @@ class FusedRLStep:
             self.micro = 0
         return self.loss
 
+    def backward_with_allreduce(self, run):
+        """Issues the forward+backward op list in segments; as soon as a bucket's gradients are final its all-reduce(sum) is
+        launched asynchronously (RCCL stream), overlapping with the rest of the backward.  `run(first, last)` issues plan ops."""
+        works, cur = [], 0
+        for op_idx, view in self.buckets:
+            run(cur, op_idx)
+            cur = op_idx
+            works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        run(cur, self.n_bwd)
+        for w in works:
+            w.wait()
+
     @property
     def last_loss(self):
         return float(self.loss.item())
+
+
+# ----------------------------------------------------------------------------------------------------------
+# torch.optim.Adam-compatible optimizer state (checkpoint key 'optimizer', train_representation_learning.py:214-226)
+# ----------------------------------------------------------------------------------------------------------
+def _param_order(groups):
+    """[(net, name)] in the reference's param-group order."""
+    order = []
+    for net, prefixes in groups:
+        for k, p in net.P.items():
+            if p.requires_grad and (prefixes is None or k.startswith(prefixes)):
+                order.append((net, k))
+    return order
+
+
+def export_adam_state(step_obj, groups, lr, betas, eps, weight_decay):
+    nets = {id(n): i for i, n in enumerate(step_obj.flat_nets)}
+    state, idx, param_groups = {}, 0, []
+    for net, prefixes in groups:
+        ids = []
+        for n_, k in _param_order([(net, prefixes)]):
+            tr, o, n = net._offs[k]
+            fi = nets[id(net)]
+            state[idx] = {"step": torch.tensor(float(step_obj.step_count)),
+                          "exp_avg": net._view(step_obj.m[fi], o, net._shapes[k]).clone(),
+                          "exp_avg_sq": net._view(step_obj.v[fi], o, net._shapes[k]).clone()}
+            ids.append(idx)
+            idx += 1
+        param_groups.append({"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "params": ids})
+    return {"state": state, "param_groups": param_groups}
+
+
+def load_adam_state(step_obj, groups, sd):
+    nets = {id(n): i for i, n in enumerate(step_obj.flat_nets)}
+    idx = 0
+    for net, prefixes in groups:
+        for n_, k in _param_order([(net, prefixes)]):
+            st = sd["state"].get(idx)
+            if st is not None:
+                tr, o, n = net._offs[k]
+                fi = nets[id(net)]
+                net._view(step_obj.m[fi], o, net._shapes[k]).copy_(st["exp_avg"])
+                net._view(step_obj.v[fi], o, net._shapes[k]).copy_(st["exp_avg_sq"])
+                step_obj.step_count = int(float(st["step"]))
+            idx += 1
+
+
+class FusedRegularStep:
+    """One optimisation step of a plain DDPM UNet (config #1, trainer/train_regular_diffusion.py:59-141 +
+    gaussian_diffusion.py:199-211): q_sample -> UNet fwd -> L2 -> full backward -> all-reduce -> Adam -> EMA, one plan."""
+
+    def __init__(self, gaussian_diffusion, net, ema_net, batch, height, width, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 decoupled=False, ema_decay=0.9999, process_group=None):
+        gd = gaussian_diffusion
+        self.gd, self.net, self.ema = gd, net, ema_net
+        self.N = batch
+        self.lr, self.b1, self.b2 = lr, betas[0], betas[1]
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.step_count = 0
+        cfg = net.cfg
+        N, Hh, W, Cimg = batch, height, width, cfg["input_channel"]
+        per = Hh * W * Cimg
+        p = Plan(net.device)
+        self.plan = p
+        self.x0, self.noise = p.buf(N, Hh, W, Cimg), p.buf(N, Hh, W, Cimg)
+        self.t = p.buf(N, dtype=torch.int64)
+        self.cond = p.buf(N, dtype=torch.int64) if cfg.get("num_class") is not None else None
+        self.loss = p.buf(1)
+        drop = float(cfg["dropout"])
+        B = Builder(p, net.P, net.grads(), save=True, drop_p=drop)
+        x_t = p.buf(N, Hh, W, Cimg)
+        p.emit(H.op_q_sample(self.x0, self.noise, self.t, gd.sqrt_alphas_cumprod, gd.sqrt_one_minus_alphas_cumprod, N, per, x_t))
+        fx = G.unet_forward(B, cfg, x_t, self.t, net.freqs, cond=self.cond, dropout=drop > 0)
+        d_eps = p.buf(*fx.eps.shape)
+        p.emit(H.op_loss(self.noise, fx.eps, None, None, None, None, N, fx.eps.numel() // N, self.loss, None, deps=d_eps), ws_slot=9)
+        G.unet_backward(B, fx, d_eps)
+        self.n_bwd = len(p.recs)
+        self.m, self.v = [torch.zeros_like(net.flat_train)], [torch.zeros_like(net.flat_train)]
+        self.flat_nets = [net]
+        self.adam_idx = p.emit(H.op_adam_ema(net.flat_train, net.flat_grad, self.m[0], self.v[0], ema_net.flat_train if ema_net is not None else None,
+                                             net.flat_train.numel(), lr, self.b1, self.b2, eps, weight_decay, int(decoupled), lr, 1.0, 1.0, ema_decay))
+        p.compile()
+
+    def step(self, x_0, condition=None, t=None, noise=None):
+        p = self.plan
+        self.x0.copy_(x_0.permute(0, 2, 3, 1))
+        self.t.copy_(torch.randint(0, self.gd.timesteps, (self.N,), device=self.x0.device, dtype=torch.long) if t is None else t)
+        if noise is None:
+            self.noise.normal_()
+        else:
+            self.noise.copy_(noise.permute(0, 2, 3, 1))
+        if self.cond is not None:
+            self.cond.copy_(condition)
+        if p.drop_ops:
+            p.set_dropout(random.getrandbits(31), self.step_count)
+        p.run(0, self.n_bwd)
+        if self.world > 1:
+            dist.all_reduce(self.net.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+        step = self.step_count + 1
+        op = p.arr[self.adam_idx]
+        op.f[5] = self.lr / (1.0 - self.b1 ** step)
+        op.f[6] = 1.0 / math.sqrt(1.0 - self.b2 ** step)
+        op.f[7] = 1.0 / self.world
+        p.run(self.n_bwd, p.n)
+        self.step_count = step
+        return self.loss

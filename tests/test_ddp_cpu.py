@@ -1,0 +1,97 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange of FusedRLStep (flat-gradient buckets in backward order,
+all-reduce(sum), 1/world folded into Adam) and the reference's seeding / dispatch semantics.
+The kernels themselves cannot run here (HIP only): the plan is built on CPU tensors and `run` is replaced by a
+recorder, so what is exercised is exactly the code path that issues collectives on the GPU box."""
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.golden import make_fixtures_cfg as C
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pdae_amd.utils import set_seed
+        from pdae_amd.model.shift_unet import ShiftUNet
+        from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
+        from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+        from pdae_amd.trainer.fused_step import FusedRLStep
+        set_seed(0)                                   # same init on all ranks (base_trainer.py:27-28)
+        enc = CELEBA64Encoder(device="cpu", latent_dim=512)
+        dec = ShiftUNet(device="cpu", latent_dim=512, **C.CFG_SHIFT_64)
+        dec.set_train_mode()
+        w0 = [dec.flat_train.clone(), enc.flat_train.clone()]
+        gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
+        dist.all_gather(gathered, w0[0])
+        assert all(torch.equal(g, w0[0]) for g in gathered), "ranks must start from identical weights"
+        set_seed(rank)                                # different data/noise streams afterwards (base_trainer.py:50-52)
+        r = torch.rand(4)
+        allr = [torch.zeros(4) for _ in range(world)]
+        dist.all_gather(allr, r)
+        assert not torch.equal(allr[0], allr[1])
+        gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device("cpu"))
+        st = FusedRLStep(gd, enc, dec, copy.deepcopy(enc), copy.deepcopy(dec), 2, 64, 64, bucket_mb=1)
+        assert st.world == world
+        # buckets: cover both flat gradient buffers exactly once, in backward (descending offset) order
+        dec_b = [v for _, v in st.buckets[:-1]]
+        assert sum(v.numel() for v in dec_b) == dec.flat_grad.numel() and len(dec_b) >= 3
+        ptrs = [v.data_ptr() for v in dec_b]
+        assert ptrs == sorted(ptrs, reverse=True)
+        assert st.buckets[-1][1].data_ptr() == enc.flat_grad.data_ptr()
+        ops_idx = [i for i, _ in st.buckets]
+        assert ops_idx == sorted(ops_idx) and st.n_fwd < ops_idx[0] and ops_idx[-1] == st.n_bwd
+        # fake "backward": every rank writes rank-dependent gradients, segments are recorded instead of launched
+        dec.flat_grad.copy_(torch.arange(dec.flat_grad.numel(), dtype=torch.float32) % 7 + rank)
+        enc.flat_grad.fill_(float(rank + 1))
+        segs = []
+        st.backward_with_allreduce(lambda a, b: segs.append((a, b)))
+        assert segs[0][0] == 0 and segs[-1][1] == st.n_bwd and all(segs[i][1] == segs[i + 1][0] for i in range(len(segs) - 1))
+        exp = sum((torch.arange(dec.flat_grad.numel(), dtype=torch.float32) % 7 + rk) for rk in range(world))
+        assert torch.equal(dec.flat_grad, exp)
+        assert torch.equal(enc.flat_grad, torch.full_like(enc.flat_grad, float(sum(range(1, world + 1)))))
+        st._patch_adam()
+        assert abs(st.plan.arr[st.adam_idx[0][0]].f[7] - 1.0 / world) < 1e-12      # mean = sum * (1/world) inside Adam
+        q.put((rank, "ok"))
+    except Exception as e:                        # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_exchange_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_dispatch_num_samples_matches_reference_table():
+    """trainer/base_trainer.py:143-153 (remainder to the last rank)."""
+    from pdae_amd.utils import dispatch_num_samples_for_process as d
+    assert [d(36, 8, r) for r in range(8)] == [4] * 7 + [8]
+    assert [d(10, 3, r) for r in range(3)] == [3, 3, 4]
+    assert d(5, 5, 4) == 1 and d(7, 1, 0) == 7
+    with pytest.raises(AssertionError):
+        d(3, 4, 0)
