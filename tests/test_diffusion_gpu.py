@@ -104,3 +104,49 @@ def test_regular_unet_ddim_and_train_one_batch(setup):
         ref = O.ddim_encode_loop(s, "ddim10", lambda x, t: O.unet_forward(sd, cfg, x, t), xT.clamp(-1, 1))
         got = gd.ddim_encode("ddim10", net, xT.clamp(-1, 1).to(DEV))
         assert psnr(got, ref.numpy()) > 80
+
+
+def test_fused_regular_step_vs_golden(setup):
+    """FusedRegularStep (config #1 path): loss + every gradient of a plain UNet against the reference's vectors, then Adam."""
+    import copy
+    from pdae_amd.model.unet import UNet
+    from pdae_amd.trainer.fused_step import FusedRegularStep
+    from tests.test_networks_gpu import check_grads
+    _, _, gd = setup
+    for tag, cfg, hw in [("unet_a", C.CFG_UNET_A, 16), ("unet_b", C.CFG_UNET_B, 32)]:
+        g = load_golden(tag)
+        net = UNet(device=DEV, **cfg)
+        net.load_state_dict(O.synth_state_dict(O.unet_param_shapes(cfg), int(g["seed"])))
+        net.train()
+        ema = copy.deepcopy(net)
+        st = FusedRegularStep(gd, net, ema, 2, hw, hw, lr=1e-4)
+        w0 = net.flat_train.clone()
+        cond = T(g["cond"]).to(DEV) if g["cond"].size else None
+        loss = st.step(T(g["x0"]).to(DEV), condition=cond, t=T(g["t"]).to(DEV), noise=T(g["noise"]).to(DEV))
+        assert abs(loss.item() - float(g["loss"])) < 1e-4 * float(g["loss"])
+        check_grads(net.grads(), g)
+        d = (net.flat_train - w0).abs()
+        assert 0.5e-4 < float(d.max()) < 1.01e-4            # |first Adam update| <= lr
+        assert rel_err(ema.flat_train, 0.9999 * w0 + 0.0001 * net.flat_train) < 1e-6
+
+
+def test_ddpm_ancestral_sampler_mean_vs_oracle(setup):
+    """noise_p_sample (gaussian_diffusion.py:112-126) with the RL shift term (:268-269), noise injected."""
+    g, net, gd = setup
+    s = O.Schedules()
+    N = 2
+    gen = torch.Generator().manual_seed(9)
+    x, eps, grad, nz = [torch.randn(N, 3, 16, 16, generator=gen) for _ in range(4)]
+    for i in (0, 1, 500, 999):
+        t = torch.full((N,), i, dtype=torch.long)
+        mean = O.noise_p_sample_mean(s, x, t, eps + O._at(s.shift_coef, t, x) * grad)
+        ref = mean + (0.0 if i == 0 else 1.0) * (0.5 * O._at(s.posterior_log_variance_clipped, t, x)).exp() * nz
+        got = gd.noise_p_sample(x.to(DEV), t.to(DEV), eps.to(DEV), gradient=grad.to(DEV), noise=nz.to(DEV))
+        assert rel_err(got, ref) < 1e-5, i
+    # a short full loop runs and stays finite
+    z = T(g["z"]).to(DEV)
+    gd_small = type(gd)({"timesteps": 1000, "betas_type": "cosine"}, torch.device(DEV))
+    gd_small.timesteps = 5
+    with torch.no_grad():
+        out = gd_small.representation_learning_ddpm_sample(None, net, None, torch.randn(2, 3, 16, 16, device=DEV), z)
+    assert torch.isfinite(out).all()
