@@ -58,7 +58,7 @@ def op_flops(op):
     if op.kind == H.OP_CONV_DGRAD:
         N, Hi, Wi, Cout, KH, KW, up = i[0], i[1], i[2], i[7], i[8], i[9], i[12]
         s = 2 if up else 1
-        return 2.0 * N * (Hi * s) * (Wi * s) * i[14] * KH * KW * Cout
+        return 2.0 * N * (Hi * s) * (Wi * s) * i[15] * KH * KW * Cout
     if op.kind == H.OP_GEMM:
         return 2.0 * i[2] * i[3] * i[4] * i[14] * i[15]
     return 0.0

@@ -38,6 +38,9 @@ typedef struct pdae_conv_desc {
   int32_t Ho, Wo, Cout;   /* output size */
   int32_t KH, KW, stride, pad;
   int32_t up;             /* 1: the conv reads the nearest-x2 upsample of the stored input (F.interpolate, module.py:169) */
+  int32_t math;           /* MFMA arithmetic for fp32 tensors: 0 = f32 MFMA (exact fp32 fmaf chain);
+                           * 1 = bf16 operands (rn); 2 = 2 bf16 planes, 3 products (~2^-17 per product);
+                           * 3 = 3 exact bf16 planes, 6 products (~2^-23 per product, fp32 grade).  fp32 accumulate in all modes. */
 } pdae_conv_desc;
 
 /* y[N,Ho,Wo,Cout] = conv(x) + bias (+ res).  res_mode: 0 none, 1 res[N,Ho,Wo,Cout], 2 res stored at half resolution
@@ -117,7 +120,7 @@ typedef struct pdae_op {
   int32_t kind;
   int32_t reserved;
   void* p[20];     /* pointer arguments, in the order of the corresponding function's pointer parameters */
-  int64_t i[24];   /* integer arguments, in order (a pdae_conv_desc is flattened to its 13 fields) */
+  int64_t i[24];   /* integer arguments, in order (a pdae_conv_desc is flattened to its 14 fields) */
   double f[12];    /* floating-point arguments, in order */
 } pdae_op;
 /* returns 0, or the first failing op's status (its index is in pdae_last_error()). */

@@ -27,6 +27,7 @@ static int check_desc(const pdae_conv_desc* d) {
   PDAE_CHECK_ARG(d && d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad dims");
   PDAE_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2");
   PDAE_CHECK_ARG(!(d->up && d->stride != 1), "conv: up with stride!=1");
+  PDAE_CHECK_ARG(d->math >= 0 && d->math <= 3, "conv: math mode must be 0..3");
   int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
   PDAE_CHECK_ARG(d->Ho == (Hl + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (Wl + 2 * d->pad - d->KW) / d->stride + 1,
                  "conv: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d->Ho, d->Wo, Hl, Wl, d->KH, d->stride, d->pad);
@@ -46,6 +47,9 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd: res_mode 2 needs even output");
+  if (tile == 0 && conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout))
+    return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, w, 0, d->C0, d->Cout, y, bias, res_mode ? res : nullptr,
+                           res_mode, 0, S(stream));
   GemmParams P;
   memset(&P, 0, sizeof(P));
   fwd_geom(P.a.g, d, x0, x1);
@@ -54,7 +58,7 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   P.b.p = w; P.b.ld = P.K;
   P.C = y; P.ldc = d->Cout; P.bias = bias; P.res = res_mode ? res : nullptr; P.ldr = d->Cout; P.res_mode = res_mode;
   P.rHo = d->Ho; P.rWo = d->Wo; P.alpha = 1.0f; P.accumulate = 0;
-  return igemm_conv_fwd(P, tile, S(stream));
+  return igemm_conv_fwd(P, tile, d->math, S(stream));
 }
 
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, float* dx, int ci_off, int ci_cnt, int accumulate,
@@ -64,6 +68,8 @@ extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const
   PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
   PDAE_CHECK_ARG(d->stride == 1 || (Hl == 2 * d->Ho && Wl == 2 * d->Wo), "conv2d_dgrad: stride 2 needs even input");
+  if (tile == 0 && ci_off == 0 && ci_cnt == Cin && conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, 0, d->Cout, Hl, Wl, d->N, Cin))
+    return conv3x3p_launch(d->math, dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, w, 1, Cin, Cin, dx, nullptr, nullptr, 0, accumulate, S(stream));
   GemmParams P;
   memset(&P, 0, sizeof(P));
   ConvGeom& g = P.a.g;
@@ -76,7 +82,7 @@ extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const
   P.splitk = 1; P.kchunk = P.K; P.Bi = 1;
   P.b.p = w; P.b.dgT = d->KH * d->KW; P.b.dgCout = d->Cout; P.b.dgWCin = Cin; P.b.dgCiOff = ci_off;
   P.C = dx; P.ldc = ci_cnt; P.alpha = 1.0f; P.accumulate = accumulate;
-  return igemm_conv_dgrad(P, tile, S(stream));
+  return igemm_conv_dgrad(P, tile, d->math, S(stream));
 }
 
 static void wgrad_plan(const pdae_conv_desc* d, int& tile, int& splits, int& kchunk) {
@@ -113,12 +119,12 @@ extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const
   const long long MN = (long long)P.M * P.N;
   if (splits <= 1) {
     P.splitk = 1; P.kchunk = P.K; P.C = dw; P.ldc = P.N; P.accumulate = accumulate;
-    return igemm_conv_wgrad(P, tile, 1, S(stream));
+    return igemm_conv_wgrad(P, tile, 1, d->math, S(stream));
   }
   PDAE_CHECK_ARG(ws && ws_bytes >= (size_t)splits * MN * sizeof(float), "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes,
                  (size_t)splits * MN * sizeof(float));
   P.splitk = splits; P.kchunk = kchunk; P.split_stride = MN; P.C = (float*)ws; P.ldc = P.N; P.accumulate = 0;
-  if (int e = igemm_conv_wgrad(P, tile, splits, S(stream))) return e;
+  if (int e = igemm_conv_wgrad(P, tile, splits, d->math, S(stream))) return e;
   return igemm_splitk_reduce((const float*)ws, dw, MN, splits, accumulate, S(stream));
 }
 
@@ -227,7 +233,7 @@ extern "C" int pdae_adam_ema(float* p, const float* g, float* m, float* v, float
 // ---- planned-graph executor
 static void desc_from(const int64_t* i, pdae_conv_desc& d) {
   d.N = (int)i[0]; d.Hi = (int)i[1]; d.Wi = (int)i[2]; d.C0 = (int)i[3]; d.C1 = (int)i[4]; d.Ho = (int)i[5]; d.Wo = (int)i[6]; d.Cout = (int)i[7];
-  d.KH = (int)i[8]; d.KW = (int)i[9]; d.stride = (int)i[10]; d.pad = (int)i[11]; d.up = (int)i[12];
+  d.KH = (int)i[8]; d.KW = (int)i[9]; d.stride = (int)i[10]; d.pad = (int)i[11]; d.up = (int)i[12]; d.math = (int)i[13];
 }
 
 static int run_one(const pdae_op& o, pdae_stream_t st) {
@@ -236,9 +242,9 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
 #define FM(k) ((float*)p[k])
   pdae_conv_desc d;
   switch (o.kind) {
-    case PDAE_OP_CONV_FWD: desc_from(i, d); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), F(3), F(4), (int)i[13], FM(5), (int)i[14], st);
-    case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), FM(2), (int)i[13], (int)i[14], (int)i[15], (int)i[16], st);
-    case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), (int)i[13], p[4], (size_t)i[14], st);
+    case PDAE_OP_CONV_FWD: desc_from(i, d); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), F(3), F(4), (int)i[14], FM(5), (int)i[15], st);
+    case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], st);
+    case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), (int)i[14], p[4], (size_t)i[15], st);
     case PDAE_OP_GEMM:
       return pdae_gemm((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), i[5], i[6], i[7], F(1), i[8], i[9], i[10], FM(2),
                        i[11], i[12], i[13], (int)i[14], (int)i[15], F(3), (int)i[16], st);

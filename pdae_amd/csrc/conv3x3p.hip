@@ -1,0 +1,281 @@
+// 3x3 / stride-1 / pad-1 convolution (forward and data-gradient) for gfx950 on the bf16 MFMA pipe with split fp32
+// operands -- the "patch" kernel.
+//
+// Block = 512 threads (8 waves as 4(M) x 2(N)), output tile = 16x16 pixels x 128 output channels.
+// For every 32-channel chunk of the input the 18x18-pixel halo patch is staged in LDS ONCE (as NS bf16 planes, see
+// igemm.hip) and all 9 taps read their shifted A fragments straight out of it, so the input crosses L2->CU ~1.3x
+// instead of 9x; the weight panel of one tap (32 x 128) is double-buffered in LDS with its global load in flight under
+// the previous tap's MFMAs: one barrier per tap (~48 MFMAs per wave in the 6-product mode).
+//
+// Replaces F.conv2d(k=3, padding=1) of model/module.py:242,265 (+ nearest upsample :169) and its input gradient.
+#include "common.h"
+#include "igemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define PLDH 40                 // bf16 per LDS row (32 + 8 pad): 80-byte rows
+#define PTH 16
+#define PTW 16
+#define PPW (PTW + 2)
+#define PNPIX ((PTH + 2) * (PTW + 2))     // 324
+#define PBN 128
+#define PTHREADS 512
+#define PA_LD ((PNPIX * 8 + PTHREADS - 1) / PTHREADS)   // float4 loads per thread for the patch: 6
+
+__device__ __forceinline__ float p_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+__device__ __forceinline__ unsigned p_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
+__device__ __forceinline__ unsigned p_rn(float a, float b) {
+  unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
+  return (unsigned)x | ((unsigned)y << 16);
+}
+template <int NS> __device__ __forceinline__ void p_split2(float e0, float e1, unsigned (&w)[NS]) {
+  if constexpr (NS == 1) { w[0] = p_rn(e0, e1); }
+  else {
+    float h0 = p_trunc(e0), h1 = p_trunc(e1);
+    float r0 = e0 - h0, r1 = e1 - h1;
+    w[0] = p_hi16(h0, h1);
+    if constexpr (NS == 2) { w[1] = p_rn(r0, r1); }
+    else {
+      float m0 = p_trunc(r0), m1 = p_trunc(r1);
+      w[1] = p_hi16(m0, m1);
+      w[2] = p_hi16(r0 - m0, r1 - m1);
+    }
+  }
+}
+
+struct PatchParams {
+  const float* x; int N, Hs, Ws, C;     // stored input [N,Hs,Ws,C]
+  int H, W, up;                         // output (= logical input) size; up: stored = logical >> 1
+  const float* w; int wmode;            // 0: forward weights [Nout][9][C]; 1: dgrad, weights [C][9][wN] read as B[k=(tap',co)][n]
+  int wN;                               // dgrad: innermost weight dimension (forward Cin)
+  int Nout;                             // GEMM N
+  float* y; const float* bias; const float* res; int res_mode; int accumulate;
+  int tiles_x, tiles_y, tiles_n;
+};
+
+template <int NS>
+__global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  constexpr int SA = NS * PNPIX * PLDH;          // A patch planes
+  constexpr int SB = NS * PBN * PLDH;            // one B buffer
+  unsigned short* sA = smem;
+  unsigned short* sB = smem + SA;                // two buffers: sB, sB + SB
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
+  const int wm = wv >> 1, wn = wv & 1;           // 4 x 2 waves; wave tile = 64 pixels x 64 channels
+
+  // block -> (image, tile_y, tile_x, n-tile); n-tile fastest so the blocks sharing a patch are co-scheduled
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tn_i = tid % P.tiles_n; tid /= P.tiles_n;
+  const int tx_i = tid % P.tiles_x; tid /= P.tiles_x;
+  const int ty_i = tid % P.tiles_y; const int img = tid / P.tiles_y;
+  const int y0 = ty_i * PTH, x0 = tx_i * PTW, n0 = tn_i * PBN;
+  const int C = P.C;
+
+  // ---- A patch: per-thread source offsets (fixed across chunks)
+  long long aoff[PA_LD];
+#pragma unroll
+  for (int l = 0; l < PA_LD; ++l) {
+    int idx = t + PTHREADS * l;
+    int pix = idx >> 3, qd = idx & 7;
+    aoff[l] = -1;
+    if (pix < PNPIX) {
+      int py = pix / PPW, px = pix - py * PPW;
+      int ly = y0 - 1 + py, lx = x0 - 1 + px;
+      if ((unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
+        int sy = P.up ? ly >> 1 : ly, sx = P.up ? lx >> 1 : lx;
+        aoff[l] = ((long long)(img * P.Hs + sy) * P.Ws + sx) * C + qd * 4;
+      }
+    }
+  }
+  float4 apre[PA_LD];
+  auto a_gload = [&](int c0) {
+#pragma unroll
+    for (int l = 0; l < PA_LD; ++l)
+      apre[l] = aoff[l] >= 0 ? *reinterpret_cast<const float4*>(P.x + aoff[l] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto a_lstore = [&]() {
+#pragma unroll
+    for (int l = 0; l < PA_LD; ++l) {
+      int idx = t + PTHREADS * l;
+      int pix = idx >> 3, qd = idx & 7;
+      if (pix < PNPIX) {
+        unsigned a[NS], b[NS];
+        p_split2<NS>(apre[l].x, apre[l].y, a);
+        p_split2<NS>(apre[l].z, apre[l].w, b);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sA[(p * PNPIX + pix) * PLDH + qd * 4]) = make_uint2(a[p], b[p]);
+      }
+    }
+  };
+
+  // ---- B panel of one (chunk, tap): 32 k x 128 n
+  float4 bpre[2];
+  const int T9 = 9;
+  auto b_gload = [&](int chunk, int tap) {
+    if (P.wmode == 0) {                 // forward: row n, 8 consecutive k
+      int n = n0 + (t >> 2), k8 = (t & 3) * 8;
+      if (n < P.Nout) {
+        const float* src = P.w + ((size_t)n * T9 + tap) * C + (chunk << 5) + k8;
+        bpre[0] = *reinterpret_cast<const float4*>(src);
+        bpre[1] = *reinterpret_cast<const float4*>(src + 4);
+      } else { bpre[0] = bpre[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    } else {                            // dgrad: k = output channel of the forward conv, taps flipped; two adjacent k rows, 4 n
+      int n4 = n0 + (t & 31) * 4, kr = (t >> 5) * 2;
+      if (n4 < P.Nout) {                // Nout % 4 == 0
+        const float* src = P.w + ((size_t)((chunk << 5) + kr) * T9 + (T9 - 1 - tap)) * P.wN + n4;
+        bpre[0] = *reinterpret_cast<const float4*>(src);
+        bpre[1] = *reinterpret_cast<const float4*>(src + (size_t)T9 * P.wN);
+      } else { bpre[0] = bpre[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+  };
+  auto b_lstore = [&](unsigned short* sb) {
+    if (P.wmode == 0) {
+      int nl = t >> 2, k8 = (t & 3) * 8;
+      unsigned a[NS], b[NS], c[NS], d[NS];
+      p_split2<NS>(bpre[0].x, bpre[0].y, a); p_split2<NS>(bpre[0].z, bpre[0].w, b);
+      p_split2<NS>(bpre[1].x, bpre[1].y, c); p_split2<NS>(bpre[1].z, bpre[1].w, d);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(&sb[(p * PBN + nl) * PLDH + k8]) = make_uint4(a[p], b[p], c[p], d[p]);
+    } else {
+      int nl = (t & 31) * 4, kr = (t >> 5) * 2;
+      const float e0[4] = {bpre[0].x, bpre[0].y, bpre[0].z, bpre[0].w};
+      const float e1[4] = {bpre[1].x, bpre[1].y, bpre[1].z, bpre[1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned a[NS];
+        p_split2<NS>(e0[j], e1[j], a);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&sb[(p * PBN + nl + j) * PLDH + kr]) = a[p];
+      }
+    }
+  };
+
+  // ---- A fragment rows of this wave
+  int apix[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) { int m = (wm * 2 + a) * 32 + li; apix[a] = (m >> 4) * PPW + (m & 15); }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunk = C >> 5;
+  a_gload(0);
+  b_gload(0, 0);
+  a_lstore();
+  b_lstore(sB);
+  __syncthreads();
+  int buf = 0;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    if (chunk + 1 < nchunk) a_gload((chunk + 1) << 5);          // next patch in flight during the 9 taps
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const bool more = (tap < 8) || (chunk + 1 < nchunk);
+      if (more) { if (tap < 8) b_gload(chunk, tap + 1); else b_gload(chunk + 1, 0); }
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const unsigned short* sb = sB + buf * SB;
+      const int ashift = dy * PPW + dx;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        bf16x8 af[2][NS], bfr[2][NS];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int p = 0; p < NS; ++p)
+            af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[(p * PNPIX + apix[a] + ashift) * PLDH + kc * 16 + h * 8]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int p = 0; p < NS; ++p)
+            bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sb[(p * PBN + (wn * 2 + b) * 32 + li) * PLDH + kc * 16 + h * 8]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            if constexpr (NS == 3) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bfr[b][1], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][2], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bfr[b][0], acc[a][b], 0, 0, 0);
+            }
+            if constexpr (NS >= 2) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][1], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bfr[b][0], acc[a][b], 0, 0, 0);
+            }
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][0], acc[a][b], 0, 0, 0);
+          }
+      }
+      if (more) b_lstore(sB + (buf ^ 1) * SB);                   // other buffer: nobody reads it during this tap
+      if (tap == 8 && chunk + 1 < nchunk) {
+        __syncthreads();                                         // every wave is done with the current patch
+        a_lstore();
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int oy = y0 + (m >> 4), ox = x0 + (m & 15);
+      if (oy >= P.H || ox >= P.W) continue;
+      const long long row = ((long long)img * P.H + oy) * P.W + ox;
+      long long rrow = row;
+      if (P.res_mode == 2) rrow = ((long long)img * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int col = n0 + (wn * 2 + b) * 32 + li;
+        if (col >= P.Nout) continue;
+        float val = acc[a][b][r];
+        if (P.bias) val += P.bias[col];
+        if (P.res_mode) val += P.res[rrow * P.Nout + col];
+        float* dst = P.y + row * P.Nout + col;
+        if (P.accumulate) val += *dst;
+        *dst = val;
+      }
+    }
+  }
+}
+
+template <int NS> static int launch_ns(const PatchParams& P, hipStream_t s) {
+  const size_t smem = (size_t)(NS * PNPIX * PLDH + 2 * NS * PBN * PLDH) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { pdae_set_error("conv3x3p: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  dim3 grid(P.N * P.tiles_y * P.tiles_x * P.tiles_n);
+  hipLaunchKernelGGL(conv3x3p_kernel<NS>, grid, dim3(PTHREADS), smem, s, P);
+  return pdae_launch_status("conv3x3p");
+}
+
+// eligibility: 3x3, stride 1, pad 1, one source, channels % 32, spatial tile-aligned and enough tiles to fill the chip
+bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout) {
+  if (math < 1 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || C1 != 0) return false;
+  if ((C & 31) || (H % PTH) || (W % PTW) || (Nout & 3) || Nout < 32) return false;
+  long long blocks = (long long)N * (H / PTH) * (W / PTW) * ((Nout + PBN - 1) / PBN);
+  return blocks >= 192;
+}
+
+int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* w, int wmode, int wN, int Nout,
+                    float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s) {
+  PatchParams P;
+  P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.w = w; P.wmode = wmode; P.wN = wN; P.Nout = Nout;
+  P.y = y; P.bias = bias; P.res = res; P.res_mode = res_mode; P.accumulate = accumulate;
+  P.tiles_x = W / PTW; P.tiles_y = H / PTH; P.tiles_n = (Nout + PBN - 1) / PBN;
+  if (math == 1) return launch_ns<1>(P, s);
+  if (math == 2) return launch_ns<2>(P, s);
+  return launch_ns<3>(P, s);
+}

@@ -23,6 +23,7 @@ struct OpParams {
   long long so, si;  // outer / inner batch strides (dense)
   ConvGeom g;        // CONV_KC / GATHER_OC
   int dgT, dgCout, dgWCin, dgCiOff;   // DGRAD_OC: taps, Cout, weight Cin, first input channel
+  int kpT, kpC;      // chunk-major K order of the vector conv paths: taps, channels (0 = natural order)
 };
 
 struct GemmParams {
@@ -42,8 +43,13 @@ struct GemmParams {
   int accumulate;              // C += ...
 };
 
-int igemm_conv_fwd(const GemmParams& P, int tile, hipStream_t s);
-int igemm_conv_dgrad(const GemmParams& P, int tile, hipStream_t s);
-int igemm_conv_wgrad(const GemmParams& P, int tile, int splits, hipStream_t s);
+int igemm_conv_fwd(const GemmParams& P, int tile, int math, hipStream_t s);
+int igemm_conv_dgrad(const GemmParams& P, int tile, int math, hipStream_t s);
+int igemm_conv_wgrad(const GemmParams& P, int tile, int splits, int math, hipStream_t s);
 int igemm_splitk_reduce(const float* ws, float* out, long long n, int splits, int accumulate, hipStream_t s);
 int igemm_dense(int transA, int transB, const GemmParams& P, int zdim, hipStream_t s);
+
+// conv3x3p.hip: 3x3 stride-1 "patch" kernel on the bf16 MFMA pipe (math modes 1..3)
+bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout);
+int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* w, int wmode, int wN, int Nout,
+                    float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s);

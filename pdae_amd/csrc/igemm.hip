@@ -30,6 +30,75 @@ __device__ __forceinline__ bool map_pix(const ConvGeom& g, int ly, int lx, int& 
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16 "split operand" support.  An fp32 value is the exact sum of three bf16 planes (hi + mid + lo, 8 significand bits
+// each; truncation keeps every remainder exact), so with NS planes per operand the products are formed on the bf16 MFMA
+// pipe (16x the f32-MFMA rate) and accumulated in fp32:
+//   NS = 1 : plain bf16 operands (round-to-nearest)                      1 MFMA  per 32x32x16 block
+//   NS = 2 : hi + rn(lo)          products hi.hi + hi.lo + lo.hi         3 MFMAs, ~2^-17 relative per product
+//   NS = 3 : hi + mid + lo exact  6 leading products                     6 MFMAs, ~2^-23 relative per product (fp32 grade)
+// LDS holds NS planes per operand, each [rows][LDH] bf16, K-contiguous (80-byte rows: conflict-free ds_read_b128).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define LDH 40
+
+__device__ __forceinline__ float trunc_bf(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_rn(float a, float b) {
+  unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
+  return (unsigned)x | ((unsigned)y << 16);
+}
+// two consecutive-k values -> one packed word per plane
+template <int NS> __device__ __forceinline__ void split2(float e0, float e1, unsigned (&w)[NS]) {
+  if constexpr (NS == 1) { w[0] = pack_rn(e0, e1); }
+  else {
+    float h0 = trunc_bf(e0), h1 = trunc_bf(e1);
+    float r0 = e0 - h0, r1 = e1 - h1;
+    w[0] = pack_hi16(h0, h1);
+    if constexpr (NS == 2) { w[1] = pack_rn(r0, r1); }
+    else {
+      float m0 = trunc_bf(r0), m1 = trunc_bf(r1);
+      w[1] = pack_hi16(m0, m1);
+      w[2] = pack_hi16(r0 - m0, r1 - m1);         // exact: <= 8 significant bits remain
+    }
+  }
+}
+// K-contiguous loaders: v[r] = 4 consecutive k of one row
+template <int NS, int BO, int R> __device__ __forceinline__ void store_bf_kc(unsigned short* s, const float4 (&v)[R], int row0, int kq) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned a[NS], b[NS];
+    split2<NS>(v[r].x, v[r].y, a);
+    split2<NS>(v[r].z, v[r].w, b);
+#pragma unroll
+    for (int p = 0; p < NS; ++p)
+      *reinterpret_cast<uint2*>(&s[(p * BO + row0 + 32 * r) * LDH + kq * 4]) = make_uint2(a[p], b[p]);
+  }
+}
+// outer-contiguous loaders with k-adjacent rows: v[r] = 4 consecutive outer indices at k = krow0*R + r  -> transpose while storing
+template <int NS, int BO, int R> __device__ __forceinline__ void store_bf_oc(unsigned short* s, const float4 (&v)[R], int krow0, int oq) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float e[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) e[r] = j == 0 ? v[r].x : (j == 1 ? v[r].y : (j == 2 ? v[r].z : v[r].w));
+    const int row = oq * 4 + j;
+    if constexpr (R == 4) {
+      unsigned a[NS], b[NS];
+      split2<NS>(e[0], e[1], a);
+      split2<NS>(e[2], e[3], b);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&s[(p * BO + row) * LDH + krow0 * 4]) = make_uint2(a[p], b[p]);
+    } else {
+      unsigned a[NS];
+      split2<NS>(e[0], e[1], a);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&s[(p * BO + row) * LDH + krow0 * 2]) = a[p];
+    }
+  }
+}
+
 template <int MODE, bool VEC, int BO> struct Op;
 
 // ---------------------------------------------------------------------------------------------
@@ -57,7 +126,11 @@ template <bool VEC, int BO> struct Op<OP_CONV_KC, VEC, BO> {
   __device__ __forceinline__ void load(const OpParams& p, int k0, int kend) {
     const ConvGeom& g = p.g;
     if constexpr (VEC) {
-      int tap = k0 / g.Cin; int ci0 = k0 - tap * g.Cin; int dy = tap / g.KW; int dx = tap - dy * g.KW;
+      // K order of the vector path: (32-channel chunk, tap, channel-in-chunk) -- the 9 taps of one chunk run back to back,
+      // so a block re-reads a (3 rows x 32 ch) patch from L1/L2 instead of sweeping whole rows once per tap
+      const int T = g.KH * g.KW;
+      int step = k0 >> 5; int chunk = step / T; int tap = step - chunk * T; int ci0 = chunk << 5;
+      int dy = tap / g.KW; int dx = tap - dy * g.KW;
       const float* src; int Cs; int ci = ci0 + kq * 4;
       if (ci0 < g.C0) { src = g.src0; Cs = g.C0; } else { src = g.src1; Cs = g.C1; ci -= g.C0; }
 #pragma unroll
@@ -92,6 +165,7 @@ template <bool VEC, int BO> struct Op<OP_CONV_KC, VEC, BO> {
 #pragma unroll
     for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(&s[(row0 + 32 * r) * LDK + kq * 4]) = v[r];
   }
+  template <int NS> __device__ __forceinline__ void store_bf(unsigned short* s) const { store_bf_kc<NS, BO, R>(s, v, row0, kq); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -111,12 +185,14 @@ template <bool VEC, int BO> struct Op<OP_DENSE_KC, VEC, BO> {
       ptr[r] = (o < O) ? p.p + boff + (long long)o * p.ld : nullptr;
     }
   }
-  __device__ __forceinline__ void load(const OpParams&, int k0, int kend) {
+  __device__ __forceinline__ void load(const OpParams& p, int k0, int kend) {
     int k = k0 + kq * 4;
+    int km = k;                                  // memory offset of logical k
+    if (p.kpT) { int step = k0 >> 5; int chunk = step / p.kpT; int tap = step - chunk * p.kpT; km = tap * p.kpC + (chunk << 5) + kq * 4; }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if constexpr (VEC) {
-        v[r] = (ptr[r] && k < kend) ? *reinterpret_cast<const float4*>(ptr[r] + k) : f4zero();
+        v[r] = (ptr[r] && k < kend) ? *reinterpret_cast<const float4*>(ptr[r] + km) : f4zero();
       } else {
         float e[4];
 #pragma unroll
@@ -129,6 +205,7 @@ template <bool VEC, int BO> struct Op<OP_DENSE_KC, VEC, BO> {
 #pragma unroll
     for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(&s[(row0 + 32 * r) * LDK + kq * 4]) = v[r];
   }
+  template <int NS> __device__ __forceinline__ void store_bf(unsigned short* s) const { store_bf_kc<NS, BO, R>(s, v, row0, kq); }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -137,7 +214,7 @@ template <bool VEC, int BO> struct Op<OP_DENSE_KC, VEC, BO> {
 //   DGRAD_OC : k = tap'*Cout + co -> W[co][T-1-tap'][ciOff + o]           (conv dgrad weights)
 //   GATHER_OC: k = output pixel, o = tap*Cin + ci -> activation gather     (conv wgrad)
 // ---------------------------------------------------------------------------------------------
-template <int MODE, bool VEC, int BO> struct OpOC {
+template <int MODE, bool VEC, int BO, bool KADJ = false> struct OpOC {
   static constexpr int R = BO / 32;
   static constexpr int CPR = BO / 4;           // float4 chunks per k-row
   static constexpr int KSTEP = 256 / CPR;      // k rows covered per pass
@@ -163,7 +240,7 @@ template <int MODE, bool VEC, int BO> struct OpOC {
   __device__ __forceinline__ void load(const OpParams& p, int k0, int kend) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int k = k0 + krow0 + KSTEP * r;
+      int k = KADJ ? k0 + krow0 * R + r : k0 + krow0 + KSTEP * r;
       v[r] = f4zero();
       if (k >= kend || o >= O_) continue;
       if constexpr (MODE == OP_GATHER_OC) {
@@ -193,7 +270,9 @@ template <int MODE, bool VEC, int BO> struct OpOC {
       } else {
         const float* row;
         if constexpr (MODE == OP_DGRAD_OC) {
-          int tap = k / p.dgCout; int co = k - tap * p.dgCout;
+          int tap, co;
+          if (p.kpT) { int step = k0 >> 5; int chunk = step / p.kpT; tap = step - chunk * p.kpT; co = (chunk << 5) + (k - k0); }
+          else { tap = k / p.dgCout; co = k - tap * p.dgCout; }
           row = base + ((size_t)co * p.dgT + (p.dgT - 1 - tap)) * p.dgWCin + p.dgCiOff;
         } else {
           row = base + (long long)k * p.ld;
@@ -213,10 +292,18 @@ template <int MODE, bool VEC, int BO> struct OpOC {
 #pragma unroll
     for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(&s[(krow0 + KSTEP * r) * (BO + 4) + oq * 4]) = v[r];
   }
+  template <int NS> __device__ __forceinline__ void store_bf(unsigned short* s) const {
+    static_assert(KADJ, "bf16 planes need the k-adjacent row mapping");
+    store_bf_oc<NS, BO, R>(s, v, krow0, oq);
+  }
 };
 template <bool VEC, int BO> struct Op<OP_DENSE_OC, VEC, BO> : OpOC<OP_DENSE_OC, VEC, BO> {};
 template <bool VEC, int BO> struct Op<OP_DGRAD_OC, VEC, BO> : OpOC<OP_DGRAD_OC, VEC, BO> {};
 template <bool VEC, int BO> struct Op<OP_GATHER_OC, VEC, BO> : OpOC<OP_GATHER_OC, VEC, BO> {};
+template <int MODE, bool VEC, int BO> struct OpBF : Op<MODE, VEC, BO> {};                        // K-contiguous: unchanged
+template <bool VEC, int BO> struct OpBF<OP_DENSE_OC, VEC, BO> : OpOC<OP_DENSE_OC, VEC, BO, true> {};
+template <bool VEC, int BO> struct OpBF<OP_DGRAD_OC, VEC, BO> : OpOC<OP_DGRAD_OC, VEC, BO, true> {};
+template <bool VEC, int BO> struct OpBF<OP_GATHER_OC, VEC, BO> : OpOC<OP_GATHER_OC, VEC, BO, true> {};
 
 // ---------------------------------------------------------------------------------------------
 // the kernel: 256 threads = 4 waves (WM x WN), each wave owns TM x TN tiles of 32x32
@@ -337,6 +424,114 @@ __global__ void __launch_bounds__(256) igemm_kernel(const GemmParams P) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// bf16-MFMA variant of the kernel above (v_mfma_f32_32x32x16_bf16), NS planes per operand
+// ---------------------------------------------------------------------------------------------
+template <int AM, bool AV, int BMODE, bool BV, int BM, int BN, int WM, int WN, int NS>
+__global__ void __launch_bounds__(256) igemm_bf_kernel(const GemmParams P) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  using LA = OpBF<AM, AV, BM>;
+  using LB = OpBF<BMODE, BV, BN>;
+  constexpr int SA = NS * BM * LDH, SB = NS * BN * LDH;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[SA + SB];
+  unsigned short* sA = smem;
+  unsigned short* sB = smem + SA;
+
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, h = lane >> 5;
+  const int wm = w / WN, wn = w - wm * WN;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  const int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  const int tmi = tid / tiles_n, tni = tid - tmi * tiles_n;
+  const int m0 = tmi * BM, n0 = tni * BN;
+
+  int kbeg = 0, kend = P.K;
+  long long aoff = 0, boff = 0, coff = 0;
+  const int z = blockIdx.z;
+  if (P.splitk > 1) {
+    kbeg = z * P.kchunk; kend = min(P.K, kbeg + P.kchunk); coff = (long long)z * P.split_stride;
+  } else {
+    int bo = z / P.Bi, bi = z - bo * P.Bi;
+    aoff = bo * P.a.so + bi * P.a.si; boff = bo * P.b.so + bi * P.b.si; coff = bo * P.sCo + bi * P.sCi;
+  }
+  LA la; LB lb;
+  la.init(P.a, aoff, m0, P.M, t);
+  lb.init(P.b, boff, n0, P.N, t);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) { la.load(P.a, kbeg, kend); lb.load(P.b, kbeg, kend); }
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    la.template store_bf<NS>(sA); lb.template store_bf<NS>(sB);
+    __syncthreads();
+    if (kt + 1 < nk) { la.load(P.a, kbeg + (kt + 1) * BK, kend); lb.load(P.b, kbeg + (kt + 1) * BK, kend); }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      bf16x8 af[TM][NS], bfr[TN][NS];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+          af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[(p * BM + (wm * TM + a) * 32 + li) * LDH + kc * 16 + h * 8]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+          bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sB[(p * BN + (wn * TN + b) * 32 + li) * LDH + kc * 16 + h * 8]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          if constexpr (NS == 3) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bfr[b][1], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][2], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bfr[b][0], acc[a][b], 0, 0, 0);
+          }
+          if constexpr (NS >= 2) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][1], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bfr[b][0], acc[a][b], 0, 0, 0);
+          }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][0], acc[a][b], 0, 0, 0);
+        }
+    }
+  }
+  float* Cb = P.C + coff;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row >= P.M) continue;
+      long long rrow = row;
+      if (P.res_mode == 2) {
+        int hw = P.rHo * P.rWo; int n = row / hw; int rem = row - n * hw; int oy = rem / P.rWo; int ox = rem - oy * P.rWo;
+        rrow = ((long long)n * (P.rHo >> 1) + (oy >> 1)) * (P.rWo >> 1) + (ox >> 1);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + (wn * TN + b) * 32 + li;
+        if (col >= P.N) continue;
+        float val = P.alpha * acc[a][b][r];
+        if (P.bias) val += P.bias[col];
+        if (P.res_mode) val += P.res[rrow * P.ldr + col];
+        float* dst = Cb + (long long)row * P.ldc + col;
+        if (P.accumulate) val += *dst;
+        *dst = val;
+      }
+    }
+  }
+}
+
 // sums split-K slabs: out[i] = (acc ? out[i] : 0) + sum_s ws[s*n + i]   (fixed order => deterministic)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n,
                                                              int splits, int accumulate) {
@@ -373,6 +568,21 @@ static int launch_tiles(int tile, const GemmParams& P, int zdim, hipStream_t s) 
   return pdae_launch_status("igemm");
 }
 
+template <int AM, int BMODE>
+static int launch_tiles_bf(int ns, int tile, const GemmParams& P, int zdim, hipStream_t s) {
+#define PDAE_BF_LAUNCH(NS_)                                                                                              \
+  if (tile == 128) {                                                                                                     \
+    dim3 grid(cdiv(P.M, 128) * cdiv(P.N, 128), 1, zdim);                                                                 \
+    hipLaunchKernelGGL((igemm_bf_kernel<AM, true, BMODE, true, 128, 128, 2, 2, NS_>), grid, dim3(256), 0, s, P);        \
+  } else {                                                                                                               \
+    dim3 grid(cdiv(P.M, 64) * cdiv(P.N, 64), 1, zdim);                                                                   \
+    hipLaunchKernelGGL((igemm_bf_kernel<AM, true, BMODE, true, 64, 64, 2, 2, NS_>), grid, dim3(256), 0, s, P);          \
+  }
+  if (ns == 1) { PDAE_BF_LAUNCH(1) } else if (ns == 2) { PDAE_BF_LAUNCH(2) } else { PDAE_BF_LAUNCH(3) }
+#undef PDAE_BF_LAUNCH
+  return pdae_launch_status("igemm_bf");
+}
+
 static int pick_tile(long long M, long long N) {
   // 128x128 tiles once they fill the 256 CUs at least twice; otherwise 64x64 for occupancy
   long long t128 = (long long)cdiv(M, 128) * cdiv(N, 128);
@@ -381,28 +591,35 @@ static int pick_tile(long long M, long long N) {
 
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-int igemm_conv_fwd(const GemmParams& P, int tile, hipStream_t s) {
+int igemm_conv_fwd(const GemmParams& P, int tile, int math, hipStream_t s) {
   const ConvGeom& g = P.a.g;
   bool vec = (g.Cin % 32 == 0) && (g.C0 % 32 == 0) && al16(g.src0) && (g.C1 == 0 || al16(g.src1)) && al16(P.b.p);
   if (tile == 0) tile = pick_tile(P.M, P.N);
+  if (vec) { GemmParams Q = P; Q.b.kpT = g.KH * g.KW; Q.b.kpC = g.Cin;
+    if (math > 0) return launch_tiles_bf<OP_CONV_KC, OP_DENSE_KC>(math, tile, Q, 1, s);
+    return launch_tiles<OP_CONV_KC, true, OP_DENSE_KC, true>(tile, Q, 1, s); }
+  if (vec && math > 0) return launch_tiles_bf<OP_CONV_KC, OP_DENSE_KC>(math, tile, P, 1, s);
   if (vec) return launch_tiles<OP_CONV_KC, true, OP_DENSE_KC, true>(tile, P, 1, s);
   return launch_tiles<OP_CONV_KC, false, OP_DENSE_KC, false>(tile, P, 1, s);
 }
 
-int igemm_conv_dgrad(const GemmParams& P, int tile, hipStream_t s) {
+int igemm_conv_dgrad(const GemmParams& P, int tile, int math, hipStream_t s) {
   const ConvGeom& g = P.a.g;
   bool avec = (g.Cin % 32 == 0) && al16(g.src0);
   bool bvec = (P.b.dgWCin % 4 == 0) && (P.b.dgCiOff % 4 == 0) && (P.N % 4 == 0) && al16(P.b.p);
   if (tile == 0) tile = pick_tile(P.M, P.N);
-  if (avec && bvec) return launch_tiles<OP_CONV_KC, true, OP_DGRAD_OC, true>(tile, P, 1, s);
+  if (avec && bvec) { GemmParams Q = P; Q.b.kpT = g.KH * g.KW; Q.b.kpC = g.Cin;
+    if (math > 0) return launch_tiles_bf<OP_CONV_KC, OP_DGRAD_OC>(math, tile, Q, 1, s);
+    return launch_tiles<OP_CONV_KC, true, OP_DGRAD_OC, true>(tile, Q, 1, s); }
   if (!avec && bvec) return launch_tiles<OP_CONV_KC, false, OP_DGRAD_OC, true>(tile, P, 1, s);
   return launch_tiles<OP_CONV_KC, false, OP_DGRAD_OC, false>(tile, P, 1, s);
 }
 
-int igemm_conv_wgrad(const GemmParams& P, int tile, int splits, hipStream_t s) {
+int igemm_conv_wgrad(const GemmParams& P, int tile, int splits, int math, hipStream_t s) {
   const ConvGeom& g = P.b.g;
   bool avec = (P.M % 4 == 0) && (P.a.ld % 4 == 0) && al16(P.a.p);
   bool bvec = (g.Cin % 4 == 0) && (g.C0 % 4 == 0) && al16(g.src0) && (g.C1 == 0 || al16(g.src1));
+  if (avec && bvec && math > 0) return launch_tiles_bf<OP_DENSE_OC, OP_GATHER_OC>(math, tile, P, splits, s);
   if (avec && bvec) return launch_tiles<OP_DENSE_OC, true, OP_GATHER_OC, true>(tile, P, splits, s);
   if (avec && !bvec) return launch_tiles<OP_DENSE_OC, true, OP_GATHER_OC, false>(tile, P, splits, s);
   if (!avec && bvec) return launch_tiles<OP_DENSE_OC, false, OP_GATHER_OC, true>(tile, P, splits, s);

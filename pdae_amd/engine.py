@@ -107,9 +107,10 @@ class Builder:
     """Emits fused stages into a Plan.  `grads` maps parameter name -> gradient tensor (same memory
     layout as the parameter); presence of a name means that parameter is trained by this plan."""
 
-    def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False):
+    def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False, math=None):
         self.p = plan
         self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
+        self.math = H.MATH_NAMES[os.environ.get("PDAE_CONV_MATH", "f32")] if math is None else int(math)
         self.P = params
         self.Gr = grads or {}
         self.save = save          # keep activations for backward (else buffers are recycled)
@@ -122,7 +123,7 @@ class Builder:
         C1 = 0 if x1 is None else x1.shape[3]
         w = self.P[wname + ".weight"]
         b = self.P[wname + ".bias"] if bias else None
-        c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=k, stride=stride, up=up)
+        c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=k, stride=stride, up=up, math=self.math)
         assert w.numel() == c.Cout * k * k * c.Cin, (wname, tuple(w.shape), c.Cin)
         y = self.p.buf(N, c.Ho, c.Wo, c.Cout)
         self.p.emit(H.op_conv_fwd(c, x0, x1, w, b, y, res=res, res_mode=res_mode))
@@ -135,7 +136,7 @@ class Builder:
         if gw is not None:
             wsb = c.wgrad_ws_bytes()
             self.p.need_ws(wsb)
-            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc), ws_slot=4, wsb_slot=14)
+            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc), ws_slot=4, wsb_slot=len(c.fields()) + 1)
         gb = self.Gr.get(cx.wname + ".bias")
         if gb is not None:
             M = c.N * c.Ho * c.Wo

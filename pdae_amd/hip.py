@@ -24,7 +24,11 @@ class PdaeOp(ctypes.Structure):
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("N", "Hi", "Wi", "C0", "C1", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad", "up")]
+                ("N", "Hi", "Wi", "C0", "C1", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad", "up", "math")]
+
+
+MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2, 3      # pdae_conv_desc.math
+MATH_NAMES = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
 
 
 class PdaeError(RuntimeError):
@@ -112,12 +116,13 @@ def ops_array(ops):
 class Conv:
     """Geometry of one convolution over NHWC activations (pdae_conv_desc)."""
 
-    def __init__(self, N, Hi, Wi, C0, C1, Cout, k=3, stride=1, pad=None, up=False):
+    def __init__(self, N, Hi, Wi, C0, C1, Cout, k=3, stride=1, pad=None, up=False, math=0):
         pad = k // 2 if pad is None else pad
         Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
         self.N, self.Hi, self.Wi, self.C0, self.C1, self.Cout = N, Hi, Wi, C0, C1, Cout
         self.KH = self.KW = k
         self.stride, self.pad, self.up = stride, pad, int(up)
+        self.math = int(math)       # MATH_F32 / MATH_BF16 / MATH_BF16X3 / MATH_BF16X6
         self.Ho = (Hl + 2 * pad - k) // stride + 1
         self.Wo = (Wl + 2 * pad - k) // stride + 1
         self.Hl, self.Wl = Hl, Wl
@@ -127,7 +132,7 @@ class Conv:
         return self.C0 + self.C1
 
     def fields(self):
-        return [self.N, self.Hi, self.Wi, self.C0, self.C1, self.Ho, self.Wo, self.Cout, self.KH, self.KW, self.stride, self.pad, self.up]
+        return [self.N, self.Hi, self.Wi, self.C0, self.C1, self.Ho, self.Wo, self.Cout, self.KH, self.KW, self.stride, self.pad, self.up, self.math]
 
     def cdesc(self):
         d = ConvDesc()

@@ -30,7 +30,7 @@ def test_header_symbols_exported(L):
 def test_struct_layout_matches_header():
     from pdae_amd import hip
     assert ctypes.sizeof(hip.PdaeOp) == 8 + 20 * 8 + 24 * 8 + 12 * 8
-    assert ctypes.sizeof(hip.ConvDesc) == 13 * 4
+    assert ctypes.sizeof(hip.ConvDesc) == 14 * 4
 
 
 def test_invalid_arguments_fail_loudly(L):

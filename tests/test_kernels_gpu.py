@@ -370,3 +370,40 @@ def test_softmax_colsum_layout_misc(H):
     buf = torch.ones(64, device="cuda"); dst = torch.zeros(64, device="cuda")
     H.run(H.op_copy(buf, dst, 256)); H.run(H.op_memset(buf, 256))
     assert dst.sum().item() == 64 and buf.sum().item() == 0
+
+
+MATH_TOL = {1: 2e-2, 2: 1e-4, 3: 1e-5}     # bf16 | 2 planes (3 products) | 3 exact planes (6 products): fp32 grade
+
+
+@pytest.mark.parametrize("math_mode", [1, 2, 3])
+@pytest.mark.parametrize("case", [(2, 12, 12, 64, 0, 96, 3, 1, 0, 0), (1, 10, 14, 32, 64, 64, 3, 1, 0, 64), (2, 8, 8, 32, 0, 32, 3, 1, 1, 0),
+                                  (2, 16, 16, 64, 0, 128, 3, 2, 0, 0), (2, 9, 9, 64, 32, 32, 1, 1, 0, 0), (3, 32, 32, 128, 0, 128, 3, 1, 0, 128),
+                                  (4, 64, 48, 64, 0, 160, 3, 1, 0, 0), (3, 32, 32, 96, 0, 64, 3, 1, 1, 0), (6, 32, 32, 32, 0, 256, 3, 1, 0, 0)])
+def test_conv_bf16_split_modes(H, case, math_mode):
+    """The bf16-MFMA split-operand variants of conv fwd / dgrad / wgrad against fp64."""
+    N, Hh, W, C0, C1, Cout, k, stride, up, tile = case
+    Cin = C0 + C1
+    tol = MATH_TOL[math_mode]
+    x = rn(1, N, Cin, Hh, W)
+    w = rn(2, Cout, Cin, k, k, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rn(3, Cout, scale=0.1)
+    c = H.Conv(N, Hh, W, C0, C1, Cout, k=k, stride=stride, up=bool(up), math=math_mode)
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous()
+    x1 = xh[..., C0:].contiguous() if C1 else None
+    wd, bd = nhwc(w).cuda(), b.cuda()
+    y = torch.empty(N, c.Ho, c.Wo, Cout, device="cuda")
+    H.run(H.op_conv_fwd(c, x0, x1, wd, bd, y, tile=tile))
+    assert rel_err(nchw(y), ref_conv(x, w, b, stride, k // 2, up)) < tol
+    wr = w.double().requires_grad_(True)
+    dy = rn(5, N, Cout, c.Ho, c.Wo)
+    xl = (F.interpolate(x, scale_factor=2, mode="nearest") if up else x).double().clone().requires_grad_(True)
+    (F.conv2d(xl, wr, None, stride=stride, padding=k // 2) * dy.double()).sum().backward()
+    dyd = nhwc(dy).cuda()
+    dx = torch.empty(N, c.Hl, c.Wl, Cin, device="cuda")
+    H.run(H.op_conv_dgrad(c, dyd, wd, dx, tile=tile))
+    assert rel_err(nchw(dx), xl.grad) < tol
+    wsb = c.wgrad_ws_bytes()
+    dw = torch.empty_like(wd)
+    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb))
+    assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2 * tol
