@@ -22,6 +22,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define PBN 128
 #define PTHREADS 512
 #define PA_LD ((PNPIX * 8 + PTHREADS - 1) / PTHREADS)   // float4 loads per thread for the patch: 6
+// 80-byte rows = five 16-byte slots, slot order rotated by (row >> 2) (see igemm.hip BSLOT): the dgrad weight panel is
+// stored transposed with lanes 4 rows apart, which would otherwise be a 16-way bank conflict
+#define PSLOT(row, slot) ((row) * PLDH + ((((slot) + ((row) >> 2)) % 5) << 3))
+#define PPLANE(rows) ((rows) * PLDH)
 
 __device__ __forceinline__ float p_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 __device__ __forceinline__ unsigned p_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
@@ -57,8 +61,8 @@ struct PatchParams {
 template <int NS>
 __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  constexpr int SA = NS * PNPIX * PLDH;          // A patch planes
-  constexpr int SB = NS * PBN * PLDH;            // one B buffer
+  constexpr int SA = NS * PPLANE(PNPIX);        // A patch planes
+  constexpr int SB = NS * PPLANE(PBN);          // one B buffer
   unsigned short* sA = smem;
   unsigned short* sB = smem + SA;                // two buffers: sB, sB + SB
 
@@ -107,7 +111,7 @@ __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P)
         p_split2<NS>(apre[l].x, apre[l].y, a);
         p_split2<NS>(apre[l].z, apre[l].w, b);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sA[(p * PNPIX + pix) * PLDH + qd * 4]) = make_uint2(a[p], b[p]);
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sA[p * PPLANE(PNPIX) + PSLOT(pix, qd >> 1) + (qd & 1) * 4]) = make_uint2(a[p], b[p]);
       }
     }
   };
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P)
       p_split2<NS>(bpre[0].x, bpre[0].y, a); p_split2<NS>(bpre[0].z, bpre[0].w, b);
       p_split2<NS>(bpre[1].x, bpre[1].y, c); p_split2<NS>(bpre[1].z, bpre[1].w, d);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(&sb[(p * PBN + nl) * PLDH + k8]) = make_uint4(a[p], b[p], c[p], d[p]);
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(&sb[p * PPLANE(PBN) + PSLOT(nl, k8 >> 3)]) = make_uint4(a[p], b[p], c[p], d[p]);
     } else {
       int nl = (t & 31) * 4, kr = (t >> 5) * 2;
       const float e0[4] = {bpre[0].x, bpre[0].y, bpre[0].z, bpre[0].w};
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P)
         unsigned a[NS];
         p_split2<NS>(e0[j], e1[j], a);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&sb[(p * PBN + nl + j) * PLDH + kr]) = a[p];
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&sb[p * PPLANE(PBN) + PSLOT(nl + j, kr >> 3) + (kr & 7)]) = a[p];
       }
     }
   };
@@ -190,12 +194,12 @@ __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P)
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int p = 0; p < NS; ++p)
-            af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[(p * PNPIX + apix[a] + ashift) * PLDH + kc * 16 + h * 8]);
+            af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int p = 0; p < NS; ++p)
-            bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sb[(p * PBN + (wn * 2 + b) * 32 + li) * PLDH + kc * 16 + h * 8]);
+            bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sb[p * PPLANE(PBN) + PSLOT((wn * 2 + b) * 32 + li, kc * 2 + h)]);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -249,7 +253,7 @@ __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P)
 }
 
 template <int NS> static int launch_ns(const PatchParams& P, hipStream_t s) {
-  const size_t smem = (size_t)(NS * PNPIX * PLDH + 2 * NS * PBN * PLDH) * sizeof(unsigned short);
+  const size_t smem = (size_t)(NS * PPLANE(PNPIX) + 2 * NS * PPLANE(PBN)) * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
