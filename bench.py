@@ -33,6 +33,8 @@ sys.path.insert(0, ROOT)
 FFHQ128 = dict(input_channel=3, base_channel=128, channel_multiplier=[1, 1, 2, 3, 4], num_residual_blocks_of_a_block=2,
                attention_resolutions=[8], num_heads=1, head_channel=-1, use_new_attention_order=False, dropout=0.1)
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
+MFMA_PER_PRODUCT = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
 TRAIN_GFLOP_PER_IMG = 481.4         # fwd 258.4 + 2 x 110.7 (shift-branch bwd) + 3 x 0.549 (encoder)
 FWD_GFLOP_PER_IMG = 258.4
 
@@ -141,8 +143,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--math", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16"],
+                    help="conv arithmetic on fp32 tensors (default bf16x6 = exact 3-plane split, fp32 grade; f32 = f32 MFMA)")
     args = ap.parse_args()
 
+    if args.math:
+        os.environ["PDAE_CONV_MATH"] = args.math
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,9 +229,18 @@ def main():
         n_ig = sum(1 for f in fl if f > 0)
         # the single heaviest launch (conv3x3 on the 128x128 grid)
         kbig = max(range(st.n_bwd), key=lambda k: fl[k])
-        out["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (f32 MFMA implicit GEMM: conv fwd/dgrad/wgrad, dense GEMM)",
-                           "achieved": round(ig_fl / ig_ms / 1e9, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ig_fl / ig_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        from pdae_amd import hip as H
+        math = os.environ.get("PDAE_CONV_MATH", H.DEFAULT_MATH)
+        npm = MFMA_PER_PRODUCT[math]
+        # peak for the arithmetic actually executed: f32 MFMA 157.3 TF, or the dense bf16 MFMA peak divided by the number of
+        # bf16 MFMAs issued per algorithmic product (6 for the exact 3-plane split)
+        peak = PEAK_F32_MFMA_TFLOPS if math == "f32" else PEAK_BF16_MFMA_TFLOPS / npm
+        out["dtype"] = "f32" if math == "f32" else ("bf16" if math == "bf16" else f"f32 as {math} split-bf16 MFMA, fp32 accumulate")
+        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3p_kernel + igemm(_bf)_kernel (implicit-GEMM conv fwd/dgrad/wgrad, dense GEMM)",
+                           "math": math, "achieved": round(ig_fl / ig_ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                           "frac": round(ig_fl / ig_ms / 1e9 / peak, 4), "traffic": None,
+                           "peak_note": "algorithmic TFLOP/s; peak = dense MFMA peak of the executed dtype / MFMAs per product",
+                           "frac_of_f32_mfma_peak": round(ig_fl / ig_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                            "launches_per_step": n_ig, "algorithmic_gflop_per_step": round(ig_fl / 1e9, 1),
                            "family_ms_per_step": round(ig_ms, 3), "all_ops_ms_per_step": round(sum(durs), 3),
                            "heaviest_launch": {"gflop": round(fl[kbig] / 1e9, 2), "ms": round(durs[kbig], 4),

@@ -8,20 +8,22 @@
 // the previous tap's MFMAs: one barrier per tap (~48 MFMAs per wave in the 6-product mode).
 //
 // Replaces F.conv2d(k=3, padding=1) of model/module.py:242,265 (+ nearest upsample :169) and its input gradient.
+#include <stdlib.h>
+
 #include "common.h"
 #include "igemm.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Two geometries (template PTH):
+//   PTH = 16 : 16x16-pixel tile, 512 threads (4x2 waves), weight panel double-buffered, one block per CU (139 KB LDS at NS=3)
+//   PTH =  8 :  8x16-pixel tile, 256 threads (2x2 waves), weight panel single-buffered, 74 KB LDS -> TWO independent blocks
+//              per CU, so one block's staging / barrier phases run under the other block's MFMAs
 #define PLDH 40                 // bf16 per LDS row (32 + 8 pad): 80-byte rows
-#define PTH 16
 #define PTW 16
 #define PPW (PTW + 2)
-#define PNPIX ((PTH + 2) * (PTW + 2))     // 324
 #define PBN 128
-#define PTHREADS 512
-#define PA_LD ((PNPIX * 8 + PTHREADS - 1) / PTHREADS)   // float4 loads per thread for the patch: 6
 // 80-byte rows = five 16-byte slots, slot order rotated by (row >> 2) (see igemm.hip BSLOT): the dgrad weight panel is
 // stored transposed with lanes 4 rows apart, which would otherwise be a 16-way bank conflict
 #define PSLOT(row, slot) ((row) * PLDH + ((((slot) + ((row) >> 2)) % 5) << 3))
@@ -58,8 +60,13 @@ struct PatchParams {
   int tiles_x, tiles_y, tiles_n;
 };
 
-template <int NS>
-__global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P) {
+template <int NS, int PTH>
+__global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P) {
+  constexpr int PTHREADS = PTH * 32;                      // 512 | 256
+  constexpr int PNPIX = (PTH + 2) * PPW;                  // 324 | 180
+  constexpr int PA_LD = (PNPIX * 8 + PTHREADS - 1) / PTHREADS;
+  constexpr int BREP = 512 / PTHREADS;                    // weight-panel passes per thread
+  constexpr bool DBUF = PTH == 16;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   constexpr int SA = NS * PPLANE(PNPIX);        // A patch planes
   constexpr int SB = NS * PPLANE(PBN);          // one B buffer
@@ -117,43 +124,51 @@ __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P)
   };
 
   // ---- B panel of one (chunk, tap): 32 k x 128 n
-  float4 bpre[2];
   const int T9 = 9;
-  auto b_gload = [&](int chunk, int tap) {
-    if (P.wmode == 0) {                 // forward: row n, 8 consecutive k
-      int n = n0 + (t >> 2), k8 = (t & 3) * 8;
-      if (n < P.Nout) {
-        const float* src = P.w + ((size_t)n * T9 + tap) * C + (chunk << 5) + k8;
-        bpre[0] = *reinterpret_cast<const float4*>(src);
-        bpre[1] = *reinterpret_cast<const float4*>(src + 4);
-      } else { bpre[0] = bpre[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    } else {                            // dgrad: k = output channel of the forward conv, taps flipped; two adjacent k rows, 4 n
-      int n4 = n0 + (t & 31) * 4, kr = (t >> 5) * 2;
-      if (n4 < P.Nout) {                // Nout % 4 == 0
-        const float* src = P.w + ((size_t)((chunk << 5) + kr) * T9 + (T9 - 1 - tap)) * P.wN + n4;
-        bpre[0] = *reinterpret_cast<const float4*>(src);
-        bpre[1] = *reinterpret_cast<const float4*>(src + (size_t)T9 * P.wN);
-      } else { bpre[0] = bpre[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  auto b_gload = [&](float4 (&bpre)[2 * BREP], int chunk, int tap) {
+#pragma unroll
+    for (int rep = 0; rep < BREP; ++rep) {
+      const int tt = t + PTHREADS * rep;
+      if (P.wmode == 0) {                 // forward: row n, 8 consecutive k
+        int n = n0 + (tt >> 2), k8 = (tt & 3) * 8;
+        if (n < P.Nout) {
+          const float* src = P.w + ((size_t)n * T9 + tap) * C + (chunk << 5) + k8;
+          bpre[2 * rep] = *reinterpret_cast<const float4*>(src);
+          bpre[2 * rep + 1] = *reinterpret_cast<const float4*>(src + 4);
+        } else { bpre[2 * rep] = bpre[2 * rep + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      } else {                            // dgrad: k = output channel of the forward conv, taps flipped; two adjacent k rows, 4 n
+        int n4 = n0 + (tt & 31) * 4, kr = (tt >> 5) * 2;
+        if (n4 < P.Nout) {                // Nout % 4 == 0
+          const float* src = P.w + ((size_t)((chunk << 5) + kr) * T9 + (T9 - 1 - tap)) * P.wN + n4;
+          bpre[2 * rep] = *reinterpret_cast<const float4*>(src);
+          bpre[2 * rep + 1] = *reinterpret_cast<const float4*>(src + (size_t)T9 * P.wN);
+        } else { bpre[2 * rep] = bpre[2 * rep + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      }
     }
   };
-  auto b_lstore = [&](unsigned short* sb) {
-    if (P.wmode == 0) {
-      int nl = t >> 2, k8 = (t & 3) * 8;
-      unsigned a[NS], b[NS], c[NS], d[NS];
-      p_split2<NS>(bpre[0].x, bpre[0].y, a); p_split2<NS>(bpre[0].z, bpre[0].w, b);
-      p_split2<NS>(bpre[1].x, bpre[1].y, c); p_split2<NS>(bpre[1].z, bpre[1].w, d);
+  auto b_lstore = [&](const float4 (&bpre)[2 * BREP], unsigned short* sb) {
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(&sb[p * PPLANE(PBN) + PSLOT(nl, k8 >> 3)]) = make_uint4(a[p], b[p], c[p], d[p]);
-    } else {
-      int nl = (t & 31) * 4, kr = (t >> 5) * 2;
-      const float e0[4] = {bpre[0].x, bpre[0].y, bpre[0].z, bpre[0].w};
-      const float e1[4] = {bpre[1].x, bpre[1].y, bpre[1].z, bpre[1].w};
+    for (int rep = 0; rep < BREP; ++rep) {
+      const int tt = t + PTHREADS * rep;
+      const float4 v0 = bpre[2 * rep], v1 = bpre[2 * rep + 1];
+      if (P.wmode == 0) {
+        int nl = tt >> 2, k8 = (tt & 3) * 8;
+        unsigned a[NS], b[NS], c[NS], d[NS];
+        p_split2<NS>(v0.x, v0.y, a); p_split2<NS>(v0.z, v0.w, b);
+        p_split2<NS>(v1.x, v1.y, c); p_split2<NS>(v1.z, v1.w, d);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned a[NS];
-        p_split2<NS>(e0[j], e1[j], a);
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(&sb[p * PPLANE(PBN) + PSLOT(nl, k8 >> 3)]) = make_uint4(a[p], b[p], c[p], d[p]);
+      } else {
+        int nl = (tt & 31) * 4, kr = (tt >> 5) * 2;
+        const float e0[4] = {v0.x, v0.y, v0.z, v0.w};
+        const float e1[4] = {v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&sb[p * PPLANE(PBN) + PSLOT(nl + j, kr >> 3) + (kr & 7)]) = a[p];
+        for (int j = 0; j < 4; ++j) {
+          unsigned a[NS];
+          p_split2<NS>(e0[j], e1[j], a);
+#pragma unroll
+          for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&sb[p * PPLANE(PBN) + PSLOT(nl + j, kr >> 3) + (kr & 7)]) = a[p];
+        }
       }
     }
   };
@@ -172,58 +187,67 @@ __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P)
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int nchunk = C >> 5;
-  a_gload(0);
-  b_gload(0, 0);
-  a_lstore();
-  b_lstore(sB);
-  __syncthreads();
+  const int total = 9 * nchunk;                   // (chunk, tap) steps
+  float4 r0[2 * BREP], r1[2 * BREP];              // weight panels in flight: the panel of step s+2 is loaded during step s,
+                                                  // stored to LDS during step s+1 -- its L2 latency is off the critical path
+  auto compute = [&](int tap, const unsigned short* sb) {
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const int ashift = dy * PPW + dx;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      bf16x8 af[2][NS], bfr[2][NS];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+          af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+          bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sb[p * PPLANE(PBN) + PSLOT((wn * 2 + b) * 32 + li, kc * 2 + h)]);
+#define PDAE_MMA(PA, PB)                                                                                          \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)                    \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA], bfr[b][PB], acc[a][b], 0, 0, 0);
+      if constexpr (NS == 3) { PDAE_MMA(1, 1) PDAE_MMA(0, 2) PDAE_MMA(2, 0) }
+      if constexpr (NS >= 2) { PDAE_MMA(0, 1) PDAE_MMA(1, 0) }
+      PDAE_MMA(0, 0)
+#undef PDAE_MMA
+    }
+  };
   int buf = 0;
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    if (chunk + 1 < nchunk) a_gload((chunk + 1) << 5);          // next patch in flight during the 9 taps
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const bool more = (tap < 8) || (chunk + 1 < nchunk);
-      if (more) { if (tap < 8) b_gload(chunk, tap + 1); else b_gload(chunk + 1, 0); }
-      const int dy = tap / 3, dx = tap - dy * 3;
-      const unsigned short* sb = sB + buf * SB;
-      const int ashift = dy * PPW + dx;
-#pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        bf16x8 af[2][NS], bfr[2][NS];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int p = 0; p < NS; ++p)
-            af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int p = 0; p < NS; ++p)
-            bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sb[p * PPLANE(PBN) + PSLOT((wn * 2 + b) * 32 + li, kc * 2 + h)]);
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            if constexpr (NS == 3) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bfr[b][1], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][2], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bfr[b][0], acc[a][b], 0, 0, 0);
-            }
-            if constexpr (NS >= 2) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][1], acc[a][b], 0, 0, 0);
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bfr[b][0], acc[a][b], 0, 0, 0);
-            }
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bfr[b][0], acc[a][b], 0, 0, 0);
-          }
-      }
-      if (more) b_lstore(sB + (buf ^ 1) * SB);                   // other buffer: nobody reads it during this tap
+  // one (chunk, tap) step.  rl: register set that receives the panel of step s+2; rs: set holding the panel of step s+1
+  auto step = [&](int s, float4 (&rl)[2 * BREP], const float4 (&rs)[2 * BREP]) {
+    const int chunk = s / 9, tap = s - chunk * 9;
+    if (s + 2 < total) { const int c2 = (s + 2) / 9; b_gload(rl, c2, s + 2 - c2 * 9); }
+    if (tap == 0 && chunk + 1 < nchunk) a_gload((chunk + 1) << 5);          // next patch in flight during the 9 taps
+    compute(tap, DBUF ? sB + buf * SB : sB);
+    if constexpr (DBUF) {
+      if (s + 1 < total) b_lstore(rs, sB + (buf ^ 1) * SB);                  // other buffer: nobody reads it during this step
       if (tap == 8 && chunk + 1 < nchunk) {
-        __syncthreads();                                         // every wave is done with the current patch
+        __syncthreads();                                                     // every wave is done with the current patch
         a_lstore();
       }
       __syncthreads();
       buf ^= 1;
+    } else {
+      if (s + 1 < total) {
+        __syncthreads();                                                     // every wave is done reading the panel (and the patch)
+        b_lstore(rs, sB);
+        if (tap == 8) a_lstore();
+        __syncthreads();
+      }
     }
+  };
+  a_gload(0);
+  b_gload(r0, 0, 0);
+  if (total > 1) b_gload(r1, 0, 1);
+  a_lstore();
+  b_lstore(r0, sB);
+  __syncthreads();
+  for (int s = 0; s < total; s += 2) {
+    step(s, r0, r1);
+    if (s + 1 < total) step(s + 1, r1, r0);
   }
 
   // ---- epilogue
@@ -252,25 +276,32 @@ __global__ void __launch_bounds__(PTHREADS) conv3x3p_kernel(const PatchParams P)
   }
 }
 
-template <int NS> static int launch_ns(const PatchParams& P, hipStream_t s) {
-  const size_t smem = (size_t)(NS * PPLANE(PNPIX) + 2 * NS * PPLANE(PBN)) * sizeof(unsigned short);
+template <int NS, int PTH> static int launch_ns(const PatchParams& P, hipStream_t s) {
+  constexpr int NPIX = (PTH + 2) * PPW;
+  const size_t smem = (size_t)(NS * PPLANE(NPIX) + (PTH == 16 ? 2 : 1) * NS * PPLANE(PBN)) * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS, PTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3p: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   dim3 grid(P.N * P.tiles_y * P.tiles_x * P.tiles_n);
-  hipLaunchKernelGGL(conv3x3p_kernel<NS>, grid, dim3(PTHREADS), smem, s, P);
+  hipLaunchKernelGGL((conv3x3p_kernel<NS, PTH>), grid, dim3(PTH * 32), smem, s, P);
   return pdae_launch_status("conv3x3p");
+}
+
+static int patch_th() {                        // PDAE_P3_TH = 8 | 16 overrides the tile height (tuning aid)
+  static int th = -1;
+  if (th < 0) { const char* e = getenv("PDAE_P3_TH"); th = e ? atoi(e) : 0; }
+  return th;
 }
 
 // eligibility: 3x3, stride 1, pad 1, one source, channels % 32, spatial tile-aligned and enough tiles to fill the chip
 bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout) {
   if (math < 1 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || C1 != 0) return false;
-  if ((C & 31) || (H % PTH) || (W % PTW) || (Nout & 3) || Nout < 32) return false;
-  long long blocks = (long long)N * (H / PTH) * (W / PTW) * ((Nout + PBN - 1) / PBN);
-  return blocks >= 192;
+  if ((C & 31) || (H % 8) || (W % PTW) || (Nout & 3) || Nout < 32) return false;
+  long long blocks = (long long)N * (H / 8) * (W / PTW) * ((Nout + PBN - 1) / PBN);
+  return blocks >= 256;
 }
 
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* w, int wmode, int wN, int Nout,
@@ -278,8 +309,13 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   PatchParams P;
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.w = w; P.wmode = wmode; P.wN = wN; P.Nout = Nout;
   P.y = y; P.bias = bias; P.res = res; P.res_mode = res_mode; P.accumulate = accumulate;
-  P.tiles_x = W / PTW; P.tiles_y = H / PTH; P.tiles_n = (Nout + PBN - 1) / PBN;
-  if (math == 1) return launch_ns<1>(P, s);
-  if (math == 2) return launch_ns<2>(P, s);
-  return launch_ns<3>(P, s);
+  int th = patch_th();
+  if (th != 8 && th != 16) th = 16;
+  if (H % th) th = 8;
+  P.tiles_x = W / PTW; P.tiles_y = H / th; P.tiles_n = (Nout + PBN - 1) / PBN;
+#define PDAE_P3(NS_) (th == 16 ? launch_ns<NS_, 16>(P, s) : launch_ns<NS_, 8>(P, s))
+  if (math == 1) return PDAE_P3(1);
+  if (math == 2) return PDAE_P3(2);
+  return PDAE_P3(3);
+#undef PDAE_P3
 }

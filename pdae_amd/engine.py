@@ -110,7 +110,7 @@ class Builder:
     def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False, math=None):
         self.p = plan
         self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
-        self.math = H.MATH_NAMES[os.environ.get("PDAE_CONV_MATH", "f32")] if math is None else int(math)
+        self.math = H.MATH_NAMES[os.environ.get("PDAE_CONV_MATH", H.DEFAULT_MATH)] if math is None else int(math)
         self.P = params
         self.Gr = grads or {}
         self.save = save          # keep activations for backward (else buffers are recycled)

@@ -29,6 +29,10 @@ class ConvDesc(ctypes.Structure):
 
 MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2, 3      # pdae_conv_desc.math
 MATH_NAMES = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
+# default arithmetic of the conv GEMMs on fp32 tensors: every fp32 operand is split EXACTLY into three bf16 planes and the six
+# leading plane products are accumulated in fp32 on the bf16 MFMA pipe (error ~2^-23 per product, i.e. fp32 grade; it passes the
+# same parity gates as the exact f32-MFMA kernels, which remain selectable with PDAE_CONV_MATH=f32)
+DEFAULT_MATH = "bf16x6"
 
 
 class PdaeError(RuntimeError):

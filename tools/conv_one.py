@@ -5,7 +5,7 @@ import torch
 from pdae_amd import hip as H
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 kind = sys.argv[2] if len(sys.argv) > 2 else "fwd"
-N, S, C0, Cout, k = 32, 128, 128, 128, 3
+N, S, C0, Cout, k = 32, 64, 256, 256, 3
 x0 = torch.randn(N, S, S, C0, device="cuda"); w = torch.randn(Cout, k, k, C0, device="cuda") / (C0 * 9) ** 0.5
 b = torch.randn(Cout, device="cuda"); y = torch.empty(N, S, S, Cout, device="cuda"); dy = torch.randn_like(y)
 dx = torch.empty_like(x0); dw = torch.empty_like(w)
