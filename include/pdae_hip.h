@@ -48,8 +48,11 @@ typedef struct pdae_conv_desc {
 int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const float* bias, const float* res,
                     int res_mode, float* y, int tile, pdae_stream_t stream);
 /* dx[N,Hl,Wl,ci_cnt] (+)= dL/d(conv input channels ci_off..ci_off+ci_cnt) on the LOGICAL input grid (Hl = 2*Hi when up). */
-int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, float* dx, int ci_off, int ci_cnt, int accumulate, int tile,
-                      pdae_stream_t stream);
+int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const float* w_t, float* dx, int ci_off, int ci_cnt, int accumulate,
+                      int tile, pdae_stream_t stream);
+/* w_t (optional): wt[Cin][KH][KW][Cout] with wt[ci][T-1-tap][co] = w[co][tap][ci], written by pdae_conv_wtranspose; when present the data
+ * gradient of an eligible 3x3 stride-1 convolution runs as a forward convolution of dy with w_t (fast LDS-patch kernel). */
+int pdae_conv_wtranspose(const float* w, int Cout, int taps, int Cin, float* w_t, pdae_stream_t stream);
 /* dw[Cout][KH][KW][Cin] (+)= sum over pixels; split-K over pixels through the workspace, reduced in fixed order. */
 size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d);
 int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, int accumulate, void* ws,
@@ -114,7 +117,7 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_WTRANSPOSE
 };
 typedef struct pdae_op {
   int32_t kind;

@@ -17,16 +17,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Two geometries (template PTH):
-//   PTH = 16 : 16x16-pixel tile, 512 threads (4x2 waves), weight panel double-buffered, one block per CU (139 KB LDS at NS=3)
+//   PTH = 16 : 16x16-pixel tile, 512 threads (4x2 waves), weight panel double-buffered, one block per CU (148 KB LDS at NS=3)
 //   PTH =  8 :  8x16-pixel tile, 256 threads (2x2 waves), weight panel single-buffered, 74 KB LDS -> TWO independent blocks
 //              per CU, so one block's staging / barrier phases run under the other block's MFMAs
 #define PLDH 40                 // bf16 per LDS row (32 + 8 pad): 80-byte rows
 #define PTW 16
-#define PPW (PTW + 2)
+#define PPW 20                  // patch pitch in pixels (18 used): with the 4x8 fragment blocks below every ds_read_b128 is conflict-free
 #define PBN 128
-// 80-byte rows = five 16-byte slots, slot order rotated by (row >> 2) (see igemm.hip BSLOT): the dgrad weight panel is
-// stored transposed with lanes 4 rows apart, which would otherwise be a 16-way bank conflict
-#define PSLOT(row, slot) ((row) * PLDH + ((((slot) + ((row) >> 2)) % 5) << 3))
+#define PSLOT(row, slot) ((row) * PLDH + ((slot) << 3))       // bf16 offset of 16-byte k-slot `slot` of `row`
 #define PPLANE(rows) ((rows) * PLDH)
 
 __device__ __forceinline__ float p_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
@@ -53,8 +51,7 @@ template <int NS> __device__ __forceinline__ void p_split2(float e0, float e1, u
 struct PatchParams {
   const float* x; int N, Hs, Ws, C;     // stored input [N,Hs,Ws,C]
   int H, W, up;                         // output (= logical input) size; up: stored = logical >> 1
-  const float* w; int wmode;            // 0: forward weights [Nout][9][C]; 1: dgrad, weights [C][9][wN] read as B[k=(tap',co)][n]
-  int wN;                               // dgrad: innermost weight dimension (forward Cin)
+  const float* w;                       // weights [Nout][9][C] (for dgrad: the tap-flipped transposed copy, pdae_conv3x3_wtranspose)
   int Nout;                             // GEMM N
   float* y; const float* bias; const float* res; int res_mode; int accumulate;
   int tiles_x, tiles_y, tiles_n;
@@ -96,7 +93,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
     if (pix < PNPIX) {
       int py = pix / PPW, px = pix - py * PPW;
       int ly = y0 - 1 + py, lx = x0 - 1 + px;
-      if ((unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
+      if (px < PTW + 2 && (unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
         int sy = P.up ? ly >> 1 : ly, sx = P.up ? lx >> 1 : lx;
         aoff[l] = ((long long)(img * P.Hs + sy) * P.Ws + sx) * C + qd * 4;
       }
@@ -125,25 +122,17 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
 
   // ---- B panel of one (chunk, tap): 32 k x 128 n
   const int T9 = 9;
+  // weight panel of one (chunk, tap): 128 rows (output channels) x 32 k, K-contiguous in memory ([Nout][9][C])
   auto b_gload = [&](float4 (&bpre)[2 * BREP], int chunk, int tap) {
 #pragma unroll
     for (int rep = 0; rep < BREP; ++rep) {
       const int tt = t + PTHREADS * rep;
-      if (P.wmode == 0) {                 // forward: row n, 8 consecutive k
-        int n = n0 + (tt >> 2), k8 = (tt & 3) * 8;
-        if (n < P.Nout) {
-          const float* src = P.w + ((size_t)n * T9 + tap) * C + (chunk << 5) + k8;
-          bpre[2 * rep] = *reinterpret_cast<const float4*>(src);
-          bpre[2 * rep + 1] = *reinterpret_cast<const float4*>(src + 4);
-        } else { bpre[2 * rep] = bpre[2 * rep + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-      } else {                            // dgrad: k = output channel of the forward conv, taps flipped; two adjacent k rows, 4 n
-        int n4 = n0 + (tt & 31) * 4, kr = (tt >> 5) * 2;
-        if (n4 < P.Nout) {                // Nout % 4 == 0
-          const float* src = P.w + ((size_t)((chunk << 5) + kr) * T9 + (T9 - 1 - tap)) * P.wN + n4;
-          bpre[2 * rep] = *reinterpret_cast<const float4*>(src);
-          bpre[2 * rep + 1] = *reinterpret_cast<const float4*>(src + (size_t)T9 * P.wN);
-        } else { bpre[2 * rep] = bpre[2 * rep + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-      }
+      int n = n0 + (tt >> 2), k8 = (tt & 3) * 8;
+      if (n < P.Nout) {
+        const float* src = P.w + ((size_t)n * T9 + tap) * C + (chunk << 5) + k8;
+        bpre[2 * rep] = *reinterpret_cast<const float4*>(src);
+        bpre[2 * rep + 1] = *reinterpret_cast<const float4*>(src + 4);
+      } else { bpre[2 * rep] = bpre[2 * rep + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
   };
   auto b_lstore = [&](const float4 (&bpre)[2 * BREP], unsigned short* sb) {
@@ -151,32 +140,21 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
     for (int rep = 0; rep < BREP; ++rep) {
       const int tt = t + PTHREADS * rep;
       const float4 v0 = bpre[2 * rep], v1 = bpre[2 * rep + 1];
-      if (P.wmode == 0) {
-        int nl = tt >> 2, k8 = (tt & 3) * 8;
-        unsigned a[NS], b[NS], c[NS], d[NS];
-        p_split2<NS>(v0.x, v0.y, a); p_split2<NS>(v0.z, v0.w, b);
-        p_split2<NS>(v1.x, v1.y, c); p_split2<NS>(v1.z, v1.w, d);
+      int nl = tt >> 2, k8 = (tt & 3) * 8;
+      unsigned a[NS], b[NS], c[NS], d[NS];
+      p_split2<NS>(v0.x, v0.y, a); p_split2<NS>(v0.z, v0.w, b);
+      p_split2<NS>(v1.x, v1.y, c); p_split2<NS>(v1.z, v1.w, d);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(&sb[p * PPLANE(PBN) + PSLOT(nl, k8 >> 3)]) = make_uint4(a[p], b[p], c[p], d[p]);
-      } else {
-        int nl = (tt & 31) * 4, kr = (tt >> 5) * 2;
-        const float e0[4] = {v0.x, v0.y, v0.z, v0.w};
-        const float e1[4] = {v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          unsigned a[NS];
-          p_split2<NS>(e0[j], e1[j], a);
-#pragma unroll
-          for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&sb[p * PPLANE(PBN) + PSLOT(nl + j, kr >> 3) + (kr & 7)]) = a[p];
-        }
-      }
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(&sb[p * PPLANE(PBN) + PSLOT(nl, k8 >> 3)]) = make_uint4(a[p], b[p], c[p], d[p]);
     }
   };
 
   // ---- A fragment rows of this wave
+  // MFMA row i of 32-row group g = wm*2+a <-> pixel (by*8 + i/4, bx*4 + i%4), (bx, by) = (g & 3, g >> 2): with the 20-pixel
+  // pitch and 80-byte rows the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots for all 9 tap shifts
   int apix[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) { int m = (wm * 2 + a) * 32 + li; apix[a] = (m >> 4) * PPW + (m & 15); }
+  for (int a = 0; a < 2; ++a) { int g = wm * 2 + a; apix[a] = ((g >> 2) * 8 + (li >> 2)) * PPW + (g & 3) * 4 + (li & 3); }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -255,8 +233,8 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   for (int a = 0; a < 2; ++a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = (wm * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int oy = y0 + (m >> 4), ox = x0 + (m & 15);
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h, g = wm * 2 + a;
+      const int oy = y0 + (g >> 2) * 8 + (i >> 2), ox = x0 + (g & 3) * 4 + (i & 3);
       if (oy >= P.H || ox >= P.W) continue;
       const long long row = ((long long)img * P.H + oy) * P.W + ox;
       long long rrow = row;
@@ -304,10 +282,10 @@ bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, i
   return blocks >= 256;
 }
 
-int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* w, int wmode, int wN, int Nout,
+int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* w, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s) {
   PatchParams P;
-  P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.w = w; P.wmode = wmode; P.wN = wN; P.Nout = Nout;
+  P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.w = w; P.Nout = Nout;
   P.y = y; P.bias = bias; P.res = res; P.res_mode = res_mode; P.accumulate = accumulate;
   int th = patch_th();
   if (th != 8 && th != 16) th = 16;

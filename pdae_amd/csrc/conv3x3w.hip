@@ -1,0 +1,247 @@
+// Weight gradient of a 3x3 / stride-1 / pad-1 convolution on the bf16 MFMA pipe with split fp32 operands.
+//
+//   dW[co][tap][ci] = sum over pixels p of  dY[p][co] * X[p + tap][ci]
+//
+// The contraction runs over PIXELS while both tensors are pixel-major in memory ([pixel][channel], NHWC), i.e. both
+// GEMM operands arrive "transposed".  Instead of transposing through LDS stores (igemm.hip wgrad path: 16 KB gathers and
+// two barriers per 32 pixels, every tap re-reading dY and X), this kernel keeps the natural layout in LDS and lets the
+// gfx950 transposing LDS read build the MFMA fragments:
+//   ds_read_b64_tr_b16: within a 16-lane group lane i passes the address of row (i>>2), columns (i&3)*4..+3 and receives
+//   the 4-row column i (verified on MI355X by tools/probes/tr_probe.hip for arbitrary row strides).
+// Per 8x16-pixel tile the block stages dY[128 px][128 co] and the haloed X patch [10x18 px][32 ci] once (NS bf16 planes each,
+// see igemm.hip) and all nine taps read shifted pixel rows of the same patch.  Block = 8 waves: wave (a, kh) owns output
+// channels a*32..+31 for all 9 taps (9 accumulator tiles) and the k-chunks (tile rows) of parity kh; the two kh partial sums
+// go to separate split-K slabs, reduced in fixed order by splitk_reduce_kernel.
+//
+// Replaces the weight-gradient of F.conv2d(k=3, padding=1) (model/module.py:242,265).
+#include "common.h"
+#include "igemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define WTH 8
+#define WTW 16
+#define WPW (WTW + 2)
+#define WNPIX ((WTH + 2) * WPW)      // 180 patch pixels
+#define WTPIX (WTH * WTW)            // 128 tile pixels
+#define WSX 40                       // X row stride (bf16): 32 ci + 8 pad
+#define WSY 136                      // dY row stride (bf16): 128 co + 8 pad
+#define WTHREADS 512
+#define WX_LD ((WNPIX * 8 + WTHREADS - 1) / WTHREADS)    // 3 float4 per thread
+#define WY_LD (WTPIX * 32 / WTHREADS)                    // 8 float4 per thread
+
+__device__ __forceinline__ float w_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+__device__ __forceinline__ unsigned w_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
+__device__ __forceinline__ unsigned w_rn(float a, float b) {
+  unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
+  return (unsigned)x | ((unsigned)y << 16);
+}
+template <int NS> __device__ __forceinline__ void w_split2(float e0, float e1, unsigned (&w)[NS]) {
+  if constexpr (NS == 1) { w[0] = w_rn(e0, e1); }
+  else {
+    float h0 = w_trunc(e0), h1 = w_trunc(e1);
+    float r0 = e0 - h0, r1 = e1 - h1;
+    w[0] = w_hi16(h0, h1);
+    if constexpr (NS == 2) { w[1] = w_rn(r0, r1); }
+    else {
+      float m0 = w_trunc(r0), m1 = w_trunc(r1);
+      w[1] = w_hi16(m0, m1);
+      w[2] = w_hi16(r0 - m0, r1 - m1);
+    }
+  }
+}
+
+// two transposing reads -> 8 consecutive k (pixel rows r0..r0+7 as seen by this lane's half) of this lane's column
+__device__ __forceinline__ bf16x8 tr_frag(unsigned addr_lo, unsigned addr_hi) {
+  unsigned long long v0, v1;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(v0), "=&v"(v1) : "v"(addr_lo), "v"(addr_hi) : "memory");
+  uint4 u = make_uint4((unsigned)v0, (unsigned)(v0 >> 32), (unsigned)v1, (unsigned)(v1 >> 32));
+  return __builtin_bit_cast(bf16x8, u);
+}
+
+struct WgradParams {
+  const float* x; int N, Hs, Ws, C;      // stored input [N,Hs,Ws,C] (C = Cin)
+  int H, W, up;                          // conv grid (output size == logical input size)
+  const float* dy; int Cout;             // dY [N,H,W,Cout]
+  float* ws;                             // split-K slabs [2*splits][Cout][9][C]
+  int tiles_x, tiles_y, ntiles;          // pixel tiles per image / total
+  int tiles_per_split, splits;
+  int co_tiles, ci_chunks;
+};
+
+template <int NS>
+__global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  constexpr int SX = NS * WNPIX * WSX;
+  unsigned short* sX = smem;                 // [NS][180][WSX]
+  unsigned short* sY = smem + SX;            // [NS][128][WSY]
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int a = wv >> 1, kh = wv & 1;        // output-channel tile, k-chunk parity
+  const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
+
+  int bid = blockIdx.x;
+  const int ci_chunk = bid % P.ci_chunks; bid /= P.ci_chunks;
+  const int co_tile = bid % P.co_tiles; const int split = bid / P.co_tiles;
+  const int ci0 = ci_chunk * 32, co0 = co_tile * 128;
+  const int C = P.C, Cout = P.Cout;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+  // lane-constant parts of the transposing-read addresses (bytes)
+  const unsigned y_lane = (unsigned)(((h * 8 + (i16 >> 2)) * WSY + a * 32 + g16 * 16 + (i16 & 3) * 4) * 2);
+  const unsigned x_lane = (unsigned)(((h * 8 + (i16 >> 2)) * WSX + g16 * 16 + (i16 & 3) * 4) * 2);
+  const unsigned sX_base = 0u, sY_base = (unsigned)(SX * 2);   // LDS byte offsets: the dynamic segment is the only LDS of this kernel
+
+  float4 xpre[WX_LD], ypre[WY_LD];
+  auto gload = [&](int tile) {
+    int img = tile / (P.tiles_y * P.tiles_x); int rem = tile - img * P.tiles_y * P.tiles_x;
+    int ty = rem / P.tiles_x, tx = rem - ty * P.tiles_x;
+    const int y0 = ty * WTH, x0 = tx * WTW;
+#pragma unroll
+    for (int l = 0; l < WX_LD; ++l) {
+      int idx = t + WTHREADS * l; int pix = idx >> 3, qd = idx & 7;
+      xpre[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pix < WNPIX) {
+        int py = pix / WPW, px = pix - py * WPW;
+        int ly = y0 - 1 + py, lx = x0 - 1 + px;
+        if ((unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
+          int sy = P.up ? ly >> 1 : ly, sx = P.up ? lx >> 1 : lx;
+          xpre[l] = *reinterpret_cast<const float4*>(P.x + ((size_t)(img * P.Hs + sy) * P.Ws + sx) * C + ci0 + qd * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < WY_LD; ++l) {
+      int idx = t + WTHREADS * l; int pix = idx >> 5, c4 = idx & 31;
+      int oy = y0 + (pix >> 4), ox = x0 + (pix & 15);
+      int co = co0 + c4 * 4;
+      ypre[l] = (co < Cout) ? *reinterpret_cast<const float4*>(P.dy + ((size_t)(img * P.H + oy) * P.W + ox) * Cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int l = 0; l < WX_LD; ++l) {
+      int idx = t + WTHREADS * l; int pix = idx >> 3, qd = idx & 7;
+      if (pix < WNPIX) {
+        unsigned u[NS], v[NS];
+        w_split2<NS>(xpre[l].x, xpre[l].y, u); w_split2<NS>(xpre[l].z, xpre[l].w, v);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sX[(p * WNPIX + pix) * WSX + qd * 4]) = make_uint2(u[p], v[p]);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < WY_LD; ++l) {
+      int idx = t + WTHREADS * l; int pix = idx >> 5, c4 = idx & 31;
+      unsigned u[NS], v[NS];
+      w_split2<NS>(ypre[l].x, ypre[l].y, u); w_split2<NS>(ypre[l].z, ypre[l].w, v);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + c4 * 4]) = make_uint2(u[p], v[p]);
+    }
+  };
+
+  const int t_beg = split * P.tiles_per_split;
+  const int t_end = min(P.ntiles, t_beg + P.tiles_per_split);
+  if (t_beg < t_end) gload(t_beg);
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    __syncthreads();                          // previous tile's fragments have been consumed
+    lstore();
+    __syncthreads();
+    if (tile + 1 < t_end) gload(tile + 1);    // next tile in flight under ~200 MFMAs per wave
+#pragma unroll 1
+    for (int kq = 0; kq < 4; ++kq) {
+      const int kc = kq * 2 + kh;             // tile row handled by this wave (16 pixels = one k-chunk)
+      bf16x8 af[NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        unsigned ad = sY_base + y_lane + (unsigned)((p * WTPIX + kc * 16) * WSY * 2);
+        af[p] = tr_frag(ad, ad + 4 * WSY * 2);
+      }
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3, dx = tp - dy * 3;
+        bf16x8 bfr[NS];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+          unsigned ad = sX_base + x_lane + (unsigned)((p * WNPIX + (kc + dy) * WPW + dx) * WSX * 2);
+          bfr[p] = tr_frag(ad, ad + 4 * WSX * 2);
+        }
+        if constexpr (NS == 3) {
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[1], acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[2], acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[0], acc[tp], 0, 0, 0);
+        }
+        if constexpr (NS >= 2) {
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], acc[tp], 0, 0, 0);
+        }
+        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], acc[tp], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: slab (split*2 + kh) of the workspace, layout [Cout][9][C]
+  float* slab = P.ws + (size_t)(split * 2 + kh) * Cout * 9 * C;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < Cout) slab[((size_t)co * 9 + tp) * C + ci0 + li] = acc[tp][r];
+    }
+}
+
+static void wgradp_plan(int N, int H, int W, int C, int Cout, int& splits, int& tiles_per_split) {
+  const int ntiles = N * (H / WTH) * (W / WTW);
+  const int base = ((Cout + 127) / 128) * (C / 32);
+  int want = (256 + base - 1) / base;                 // one block per CU (147 KB of LDS at NS=3)
+  int maxs = ntiles / 4; if (maxs < 1) maxs = 1;      // at least 4 tiles per block
+  if (want > maxs) want = maxs;
+  if (want > 128) want = 128;
+  tiles_per_split = (ntiles + want - 1) / want;
+  splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
+}
+
+bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Cout) {
+  if (math < 1 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || C1 != 0) return false;
+  if ((C & 31) || (H % WTH) || (W % WTW) || (Cout & 3) || Cout < 32) return false;
+  return (long long)N * (H / WTH) * (W / WTW) >= 64;
+}
+
+size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout) {
+  int splits, tps;
+  wgradp_plan(N, H, W, C, Cout, splits, tps);
+  return (size_t)splits * 2 * Cout * 9 * C * sizeof(float);
+}
+
+template <int NS> static int launch_w(const WgradParams& P, hipStream_t s) {
+  const size_t smem = (size_t)(NS * WNPIX * WSX + NS * WTPIX * WSY) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3w_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { pdae_set_error("conv3x3w: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3x3w_kernel<NS>, dim3(P.splits * P.co_tiles * P.ci_chunks), dim3(WTHREADS), smem, s, P);
+  return pdae_launch_status("conv3x3w");
+}
+
+int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
+                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+  WgradParams P;
+  P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.dy = dy; P.Cout = Cout; P.ws = ws;
+  P.tiles_x = W / WTW; P.tiles_y = H / WTH; P.ntiles = N * P.tiles_x * P.tiles_y;
+  wgradp_plan(N, H, W, C, Cout, P.splits, P.tiles_per_split);
+  P.co_tiles = (Cout + 127) / 128; P.ci_chunks = C / 32;
+  const size_t need = (size_t)P.splits * 2 * Cout * 9 * C * sizeof(float);
+  if (!ws || ws_bytes < need) { pdae_set_error("conv3x3w: workspace too small (%zu < %zu)", ws_bytes, need); return PDAE_EINVAL; }
+  int e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : launch_w<3>(P, s));
+  if (e) return e;
+  return igemm_splitk_reduce(ws, dw, (long long)Cout * 9 * C, P.splits * 2, accumulate, s);
+}

@@ -274,45 +274,95 @@ int k_softmax_bwd(const float* p, float* dp, long long rows, int T, hipStream_t 
 
 // ---------------------------------------------------------------------------------------------
 // column sums of a row-major [M][C] matrix (bias gradients), two deterministic stages.
-// stage 1: block b owns a contiguous row range; its 256 threads are (row lanes) x (column threads), reduced
-// through LDS in fixed order.  stage 2: one thread per column adds the <=256 block partials.
+// stage 1: block b owns a contiguous row range; its 256 threads are (row lanes) x (column threads, float4 wide when C % 4 == 0),
+//          reduced through LDS in fixed order.  stage 2: 8 lanes per column add the <= 1024 block partials, fixed order.
 // ---------------------------------------------------------------------------------------------
-#define COLSUM_MAXB 256
+#define COLSUM_MAXB 1024
+template <int V>   // V = 4: float4 columns, V = 1: scalar
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ x, long long M, int C, int rows_per, float* __restrict__ part) {
-  __shared__ float red[256];
+  __shared__ float red[256 * V];
   const long long r0 = (long long)blockIdx.x * rows_per;
   long long r1 = r0 + rows_per; if (r1 > M) r1 = M;
-  const int CT = C < 256 ? C : 256;            // column threads
+  const int CV = C / V;                        // vector columns
+  const int CT = CV < 256 ? CV : 256;          // column threads
   const int RL = 256 / CT;                     // row lanes
   const int t = threadIdx.x, ct = t % CT, rl = t / CT;
-  for (int c0 = 0; c0 < C; c0 += CT) {
+  for (int c0 = 0; c0 < CV; c0 += CT) {
     const int c = c0 + ct;
-    float a = 0.f;
-    if (rl < RL && c < C)
-      for (long long r = r0 + rl; r < r1; r += RL) a += x[r * C + c];
-    red[t] = a;
+    float a[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) a[j] = 0.f;
+    if (rl < RL && c < CV) {
+      for (long long r = r0 + rl; r < r1; r += RL) {
+        if constexpr (V == 4) {
+          float4 v = *reinterpret_cast<const float4*>(x + r * C + c * 4);
+          a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+        } else {
+          a[0] += x[r * C + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[t * V + j] = a[j];
     __syncthreads();
-    if (rl == 0 && c < C) {
-      float s = 0.f;
-      for (int l = 0; l < RL; ++l) s += red[l * CT + ct];
-      part[(size_t)blockIdx.x * C + c] = s;
+    if (rl == 0 && c < CV) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float s = 0.f;
+        for (int l = 0; l < RL; ++l) s += red[(l * CT + ct) * V + j];
+        part[(size_t)blockIdx.x * C + c * V + j] = s;
+      }
     }
     __syncthreads();
   }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out, int acc) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out, int acc) {
+  __shared__ float red[256];
+  const int t = threadIdx.x, cl = t & 31, lane = t >> 5;          // 32 columns x 8 lanes per block
+  const int c = blockIdx.x * 32 + cl;
   float a = 0.f;
-  for (int b = 0; b < nb; ++b) a += part[(size_t)b * C + c];
-  out[c] = acc ? out[c] + a : a;
+  if (c < C)
+    for (int b = lane; b < nb; b += 8) a += part[(size_t)b * C + c];
+  red[t] = a;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    float s = 0.f;
+    for (int l = 0; l < 8; ++l) s += red[l * 32 + cl];
+    out[c] = acc ? out[c] + s : s;
+  }
 }
 size_t k_colsum_workspace_floats(long long M, int C) { return (size_t)COLSUM_MAXB * C; }
 int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws, hipStream_t st) {
-  long long want = (M * C + 65535) / 65536;          // >= 64K elements per block
+  long long want = (M * C + 16383) / 16384;          // >= 16K elements per block
   int nb = (int)(want < 1 ? 1 : (want > COLSUM_MAXB ? COLSUM_MAXB : want));
   int rows_per = cdiv(M, nb); nb = cdiv(M, rows_per);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, M, C, rows_per, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, nb, C, out, acc);
+  if ((C & 3) == 0 && ((uintptr_t)x & 15) == 0)
+    hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(nb), dim3(256), 0, st, x, M, C, rows_per, ws);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, M, C, rows_per, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, ws, nb, C, out, acc);
   return pdae_launch_status("colsum");
+}
+
+// ---------------------------------------------------------------------------------------------
+// wt[ci][T-1-tap][co] = w[co][tap][ci]: transposed, tap-flipped copy of a conv weight, so that the data gradient of a
+// stride-1 convolution is itself a plain forward convolution of dY with wt (conv3x3p.hip)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wtranspose_kernel(const float* __restrict__ w, int Cout, int T, int Cin, float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z, c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    int co = o0 + r, ci = c0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + tap) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int ci = c0 + r, co = o0 + tx;
+    if (ci < Cin && co < Cout) wt[((size_t)ci * T + (T - 1 - tap)) * Cout + co] = tile[tx][r];
+  }
+}
+int k_wtranspose(const float* w, int Cout, int T, int Cin, float* wt, hipStream_t st) {
+  hipLaunchKernelGGL(wtranspose_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), T), dim3(256), 0, st, w, Cout, T, Cin, wt);
+  return pdae_launch_status("wtranspose");
 }

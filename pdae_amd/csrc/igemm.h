@@ -51,5 +51,11 @@ int igemm_dense(int transA, int transB, const GemmParams& P, int zdim, hipStream
 
 // conv3x3p.hip: 3x3 stride-1 "patch" kernel on the bf16 MFMA pipe (math modes 1..3)
 bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout);
-int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* w, int wmode, int wN, int Nout,
+int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* w, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s);
+
+// conv3x3w.hip: 3x3 stride-1 weight gradient with transposing LDS reads (math modes 1..3)
+bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Cout);
+size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout);
+int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
+                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s);

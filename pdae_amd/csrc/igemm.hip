@@ -46,8 +46,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // rows that is a 16-way LDS bank conflict, hence the slot rotation below
 #define BPLANE(BO) ((BO) * LDH)
 // An 80-byte row holds five 16-byte slots (four of data + one of padding); the slot order is rotated by (row >> 2) so that
-// rows 4 apart land on different banks.  BSLOT(row, slot) = bf16 offset of 16-byte k-slot `slot` (8 bf16) of `row`.
-#define BSLOT(row, slot) ((row) * LDH + ((((slot) + ((row) >> 2)) % 5) << 3))
+// rows 4 apart land on different banks (only for the outer-contiguous operands: plain rows are conflict-free for ds_read_b128).
+// BSLOT(row, slot, rot) = bf16 offset of 16-byte k-slot `slot` (8 bf16) of `row`.
+#define BSLOT(row, slot, rot) ((row) * LDH + (((rot) ? ((slot) + ((row) >> 2)) % 5 : (slot)) << 3))
 
 __device__ __forceinline__ float trunc_bf(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
@@ -79,7 +80,7 @@ template <int NS, int BO, int R> __device__ __forceinline__ void store_bf_kc(uns
     split2<NS>(v[r].z, v[r].w, b);
 #pragma unroll
     for (int p = 0; p < NS; ++p)
-      *reinterpret_cast<uint2*>(&s[p * BPLANE(BO) + BSLOT(row0 + 32 * r, kq >> 1) + (kq & 1) * 4]) = make_uint2(a[p], b[p]);
+      *reinterpret_cast<uint2*>(&s[p * BPLANE(BO) + BSLOT(row0 + 32 * r, kq >> 1, 0) + (kq & 1) * 4]) = make_uint2(a[p], b[p]);
   }
 }
 // outer-contiguous loaders with k-adjacent rows: v[r] = 4 consecutive outer indices at k = krow0*R + r  -> transpose while storing
@@ -95,12 +96,12 @@ template <int NS, int BO, int R> __device__ __forceinline__ void store_bf_oc(uns
       split2<NS>(e[0], e[1], a);
       split2<NS>(e[2], e[3], b);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&s[p * BPLANE(BO) + BSLOT(row, krow0 >> 1) + (krow0 & 1) * 4]) = make_uint2(a[p], b[p]);
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&s[p * BPLANE(BO) + BSLOT(row, krow0 >> 1, 1) + (krow0 & 1) * 4]) = make_uint2(a[p], b[p]);
     } else {
       unsigned a[NS];
       split2<NS>(e[0], e[1], a);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&s[p * BPLANE(BO) + BSLOT(row, krow0 >> 2) + (krow0 & 3) * 2]) = a[p];
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<unsigned*>(&s[p * BPLANE(BO) + BSLOT(row, krow0 >> 2, 1) + (krow0 & 3) * 2]) = a[p];
     }
   }
 }
@@ -488,12 +489,12 @@ __global__ void __launch_bounds__(256) igemm_bf_kernel(const GemmParams P) {
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int p = 0; p < NS; ++p)
-          af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[p * BPLANE(BM) + BSLOT((wm * TM + a) * 32 + li, kc * 2 + h)]);
+          af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[p * BPLANE(BM) + BSLOT((wm * TM + a) * 32 + li, kc * 2 + h, !LA::KC)]);
 #pragma unroll
       for (int b = 0; b < TN; ++b)
 #pragma unroll
         for (int p = 0; p < NS; ++p)
-          bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sB[p * BPLANE(BN) + BSLOT((wn * TN + b) * 32 + li, kc * 2 + h)]);
+          bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sB[p * BPLANE(BN) + BSLOT((wn * TN + b) * 32 + li, kc * 2 + h, !LB::KC)]);
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll

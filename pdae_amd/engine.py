@@ -148,7 +148,15 @@ class Builder:
         ci_cnt = c.Cin if ci_cnt is None else ci_cnt
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
-        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate))
+        w_t = None
+        if c.math > 0 and c.KH == 3 and c.stride == 1 and ci_off == 0 and ci_cnt == c.Cin:
+            # the data gradient runs as a forward convolution of dy with the transposed, tap-flipped weights; the copy is refreshed
+            # right here (weights change every optimizer step), 2 x 4 bytes per parameter -- noise next to the convolution itself
+            w_t = self.p.buf(w.numel())
+            self.p.emit(H.op_wtranspose(w, c.Cout, c.KH * c.KW, c.Cin, w_t))
+        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate, w_t=w_t))
+        if w_t is not None:
+            self.p.free(w_t)
         return dx
 
     def linear(self, x, wname, pre_bias=True):

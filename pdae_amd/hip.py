@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
- OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY) = range(1, 27)
+ OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_WTRANSPOSE) = range(1, 28)
 
 
 class PdaeOp(ctypes.Structure):
@@ -65,7 +65,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv_wtranspose", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_timestep_embedding", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_adam_ema", "pdae_run_ops"]
@@ -153,8 +153,12 @@ def op_conv_fwd(c, x0, x1, w, bias, y, res=None, res_mode=0, tile=0):
     return make_op(OP_CONV_FWD, [x0, x1, w, bias, res, y], c.fields() + [res_mode, tile])
 
 
-def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0):
-    return make_op(OP_CONV_DGRAD, [dy, w, dx], c.fields() + [ci_off, c.Cin if ci_cnt is None else ci_cnt, accumulate, tile])
+def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0, w_t=None):
+    return make_op(OP_CONV_DGRAD, [dy, w, dx, w_t], c.fields() + [ci_off, c.Cin if ci_cnt is None else ci_cnt, accumulate, tile])
+
+
+def op_wtranspose(w, Cout, taps, Cin, w_t):
+    return make_op(OP_WTRANSPOSE, [w, w_t], [Cout, taps, Cin])
 
 
 def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0):

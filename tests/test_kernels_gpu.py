@@ -403,6 +403,13 @@ def test_conv_bf16_split_modes(H, case, math_mode):
     dx = torch.empty(N, c.Hl, c.Wl, Cin, device="cuda")
     H.run(H.op_conv_dgrad(c, dyd, wd, dx, tile=tile))
     assert rel_err(nchw(dx), xl.grad) < tol
+    if k == 3 and stride == 1:      # the fast path: forward patch kernel on the transposed, tap-flipped weight copy
+        w_t = torch.empty(Cin * 9 * Cout, device="cuda")
+        H.run(H.op_wtranspose(wd, Cout, 9, Cin, w_t))
+        assert torch.equal(w_t.view(Cin, 3, 3, Cout).cpu(), w.flip(2, 3).permute(1, 2, 3, 0).contiguous())
+        dx2 = torch.empty(N, c.Hl, c.Wl, Cin, device="cuda")
+        H.run(H.op_conv_dgrad(c, dyd, wd, dx2, w_t=w_t))
+        assert rel_err(nchw(dx2), xl.grad) < tol
     wsb = c.wgrad_ws_bytes()
     dw = torch.empty_like(wd)
     H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb))
