@@ -41,15 +41,40 @@ static void fwd_geom(ConvGeom& g, const pdae_conv_desc* d, const float* x0, cons
   g.Ho = d->Ho; g.Wo = d->Wo; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.up = d->up; g.dil = 0;
 }
 
-extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const float* bias, const float* res,
-                               int res_mode, float* y, int tile, pdae_stream_t stream) {
+// patch-kernel eligibility of the forward (transposed = 0) / data-gradient (transposed = 1) convolution of d
+static bool patch_ok(const pdae_conv_desc* d, int transposed, bool fill) {
+  if (!transposed) return conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout, fill);
+  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
+  return conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, 0, d->Cout, Hl, Wl, d->N, d->C0 + d->C1, fill);
+}
+
+extern "C" size_t pdae_conv3x3_wprep_bytes(const pdae_conv_desc* d, int flags) {
+  const int transposed = flags & PDAE_WPREP_TRANSPOSED;
+  if (!d || check_desc(d) || !patch_ok(d, transposed, !(flags & PDAE_WPREP_FORCE))) return 0;
+  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
+  return transposed ? conv3x3p_wprep_bytes(d->math, d->C0 + d->C1, d->Cout, Hl, Wl, d->N)
+                    : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
+}
+
+extern "C" int pdae_conv3x3_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  const int transposed = flags & PDAE_WPREP_TRANSPOSED;
+  PDAE_CHECK_ARG(w && wp, "conv3x3_wprep: null pointer");
+  PDAE_CHECK_ARG(patch_ok(d, transposed, false), "conv3x3_wprep: convolution shape not eligible for the patch kernel");
+  if (transposed) return conv3x3p_wprep(d->math, w, d->C0 + d->C1, d->Cout, 1, (unsigned short*)wp, S(stream));
+  return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream));
+}
+
+extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
+                               const float* res, int res_mode, float* y, int tile, pdae_stream_t stream) {
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd: res_mode 2 needs even output");
-  if (tile == 0 && conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout))
-    return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, w, d->Cout, y, bias, res_mode ? res : nullptr,
-                           res_mode, 0, S(stream));
+  PDAE_CHECK_ARG(!wp || (tile == 0 && patch_ok(d, 0, false)), "conv2d_fwd: wp given but the convolution is not eligible for the patch kernel");
+  if (wp)
+    return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
+                           res_mode ? res : nullptr, res_mode, 0, S(stream));
   GemmParams P;
   memset(&P, 0, sizeof(P));
   fwd_geom(P.a.g, d, x0, x1);
@@ -61,20 +86,18 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   return igemm_conv_fwd(P, tile, d->math, S(stream));
 }
 
-extern "C" int pdae_conv_wtranspose(const float* w, int Cout, int taps, int Cin, float* w_t, pdae_stream_t stream) {
-  PDAE_CHECK_ARG(w && w_t && Cout > 0 && taps > 0 && Cin > 0, "conv_wtranspose: bad arguments");
-  return k_wtranspose(w, Cout, taps, Cin, w_t, S(stream));
-}
-
-extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const float* w_t, float* dx, int ci_off, int ci_cnt,
+extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
                                  int accumulate, int tile, pdae_stream_t stream) {
   if (int e = check_desc(d)) return e;
   const int Cin = d->C0 + d->C1;
   PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
   PDAE_CHECK_ARG(d->stride == 1 || (Hl == 2 * d->Ho && Wl == 2 * d->Wo), "conv2d_dgrad: stride 2 needs even input");
-  if (w_t && tile == 0 && ci_off == 0 && ci_cnt == Cin && conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, 0, d->Cout, Hl, Wl, d->N, Cin))
-    return conv3x3p_launch(d->math, dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, w_t, Cin, dx, nullptr, nullptr, 0, accumulate, S(stream));
+  PDAE_CHECK_ARG(!wp_t || (tile == 0 && ci_off == 0 && ci_cnt == Cin && patch_ok(d, 1, false)),
+                 "conv2d_dgrad: wp_t given but the convolution is not eligible for the patch kernel");
+  if (wp_t)
+    return conv3x3p_launch(d->math, dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, (const unsigned short*)wp_t, Cin, dx, nullptr, nullptr, 0,
+                           accumulate, S(stream));
   GemmParams P;
   memset(&P, 0, sizeof(P));
   ConvGeom& g = P.a.g;
@@ -251,8 +274,8 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
 #define FM(k) ((float*)p[k])
   pdae_conv_desc d;
   switch (o.kind) {
-    case PDAE_OP_CONV_FWD: desc_from(i, d); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), F(3), F(4), (int)i[14], FM(5), (int)i[15], st);
-    case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), F(3), FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], st);
+    case PDAE_OP_CONV_FWD: desc_from(i, d); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), p[6], F(3), F(4), (int)i[14], FM(5), (int)i[15], st);
+    case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), p[3], FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], st);
     case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), (int)i[14], p[4], (size_t)i[15], st);
     case PDAE_OP_GEMM:
       return pdae_gemm((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), i[5], i[6], i[7], F(1), i[8], i[9], i[10], FM(2),
@@ -287,7 +310,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_SOFTMAX: return pdae_softmax(FM(0), i[0], (int)i[1], st);
     case PDAE_OP_SOFTMAX_BWD: return pdae_softmax_bwd(F(0), FM(1), i[0], (int)i[1], st);
     case PDAE_OP_COLSUM: return pdae_colsum(F(0), i[0], (int)i[1], FM(1), (int)i[2], p[2], st);
-    case PDAE_OP_WTRANSPOSE: return pdae_conv_wtranspose(F(0), (int)i[0], (int)i[1], (int)i[2], FM(1), st);
+    case PDAE_OP_CONV3X3_WPREP: desc_from(i, d); return pdae_conv3x3_wprep(&d, F(0), (int)i[14], p[1], st);
     case PDAE_OP_MEMSET: {
       hipError_t e = hipMemsetAsync(p[0], 0, (size_t)i[0], S(st));
       if (e != hipSuccess) { pdae_set_error("memset: %s", hipGetErrorString(e)); return (int)e; }

@@ -4,8 +4,10 @@
 // Block = 512 threads (8 waves as 4(M) x 2(N)), output tile = 16x16 pixels x 128 output channels.
 // For every 32-channel chunk of the input the 18x18-pixel halo patch is staged in LDS ONCE (as NS bf16 planes, see
 // igemm.hip) and all 9 taps read their shifted A fragments straight out of it, so the input crosses L2->CU ~1.3x
-// instead of 9x; the weight panel of one tap (32 x 128) is double-buffered in LDS with its global load in flight under
-// the previous tap's MFMAs: one barrier per tap (~48 MFMAs per wave in the 6-product mode).
+// instead of 9x.  The weights are pre-split into bf16 planes in MFMA-FRAGMENT ORDER by conv3x3p_wprep (one 1 KB
+// contiguous block per (chunk, tap, k-half, 32-channel tile)), so every wave loads its B fragments straight from L2 with
+// fully coalesced 16-byte loads, prefetched one k-step ahead: no weight traffic through LDS and NO barrier inside a
+// chunk -- the waves drift apart and hide each other's LDS / VALU phases (barriers only when the patch is restaged).
 //
 // Replaces F.conv2d(k=3, padding=1) of model/module.py:242,265 (+ nearest upsample :169) and its input gradient.
 #include <stdlib.h>
@@ -16,10 +18,13 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Two geometries (template PTH):
-//   PTH = 16 : 16x16-pixel tile, 512 threads (4x2 waves), weight panel double-buffered, one block per CU (148 KB LDS at NS=3)
-//   PTH =  8 :  8x16-pixel tile, 256 threads (2x2 waves), weight panel single-buffered, 74 KB LDS -> TWO independent blocks
-//              per CU, so one block's staging / barrier phases run under the other block's MFMAs
+// Geometries (template PTH, W8):
+//   PTH = 16      : 16x16-pixel tile, 512 threads (4x2 waves), 86 KB LDS at NS=3 (one block per CU)
+//   PTH =  8      :  8x16-pixel tile, 256 threads (2x2 waves), 48 KB LDS (several independent blocks per CU)
+//   PTH =  8, W8  :  8-pixel-wide images: the tile is 8 rows of TWO images side by side (their 10-pixel halo rows fill the
+//                    20-pixel patch pitch exactly), so the 8x8 bottleneck layers run on the same kernel
+// Small layers (few tiles) are additionally split over ranges of input-channel chunks (split-K): every split writes its
+// partial tile to a slab behind the prepared weights and conv3x3p_reduce adds the slabs, bias and residual in fixed order.
 #define PLDH 40                 // bf16 per LDS row (32 + 8 pad): 80-byte rows
 #define PTW 16
 #define PPW 20                  // patch pitch in pixels (18 used): with the 4x8 fragment blocks below every ds_read_b128 is conflict-free
@@ -51,24 +56,23 @@ template <int NS> __device__ __forceinline__ void p_split2(float e0, float e1, u
 struct PatchParams {
   const float* x; int N, Hs, Ws, C;     // stored input [N,Hs,Ws,C]
   int H, W, up;                         // output (= logical input) size; up: stored = logical >> 1
-  const float* w;                       // weights [Nout][9][C] (for dgrad: the tap-flipped transposed copy, pdae_conv3x3_wtranspose)
+  const unsigned short* wp;             // pre-split weights [NS][C/32][9][2][NT][64][8] bf16 (conv3x3p_wprep)
+  int NT;                               // 32-channel output tiles in wp (= ceil(Nout/32))
   int Nout;                             // GEMM N
   float* y; const float* bias; const float* res; int res_mode; int accumulate;
   int tiles_x, tiles_y, tiles_n;
+  int splits, cps;                      // split-K: `splits` ranges of `cps` chunks; splits > 1 => raw partials to slab[split][M][Nout]
+  float* slab;
 };
 
-template <int NS, int PTH>
+template <int NS, int PTH, bool W8>
 __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P) {
   constexpr int PTHREADS = PTH * 32;                      // 512 | 256
   constexpr int PNPIX = (PTH + 2) * PPW;                  // 324 | 180
   constexpr int PA_LD = (PNPIX * 8 + PTHREADS - 1) / PTHREADS;
-  constexpr int BREP = 512 / PTHREADS;                    // weight-panel passes per thread
-  constexpr bool DBUF = PTH == 16;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   constexpr int SA = NS * PPLANE(PNPIX);        // A patch planes
-  constexpr int SB = NS * PPLANE(PBN);          // one B buffer
   unsigned short* sA = smem;
-  unsigned short* sB = smem + SA;                // two buffers: sB, sB + SB
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
   const int wm = wv >> 1, wn = wv & 1;           // 4 x 2 waves; wave tile = 64 pixels x 64 channels
@@ -79,7 +83,9 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
   const int tn_i = tid % P.tiles_n; tid /= P.tiles_n;
   const int tx_i = tid % P.tiles_x; tid /= P.tiles_x;
-  const int ty_i = tid % P.tiles_y; const int img = tid / P.tiles_y;
+  const int ty_i = tid % P.tiles_y; tid /= P.tiles_y;
+  const int nimg = W8 ? (P.N + 1) >> 1 : P.N;
+  const int img = (tid % nimg) * (W8 ? 2 : 1), sp = tid / nimg;         // W8: img = first image of the pair
   const int y0 = ty_i * PTH, x0 = tx_i * PTW, n0 = tn_i * PBN;
   const int C = P.C;
 
@@ -92,10 +98,12 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
     aoff[l] = -1;
     if (pix < PNPIX) {
       int py = pix / PPW, px = pix - py * PPW;
-      int ly = y0 - 1 + py, lx = x0 - 1 + px;
-      if (px < PTW + 2 && (unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
+      int ly = y0 - 1 + py, lx = x0 - 1 + px, im = img;
+      bool okx = px < PTW + 2;
+      if constexpr (W8) { const int sub = px >= 10; im = img + sub; lx = px - 1 - 10 * sub; okx = im < P.N; }
+      if (okx && (unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
         int sy = P.up ? ly >> 1 : ly, sx = P.up ? lx >> 1 : lx;
-        aoff[l] = ((long long)(img * P.Hs + sy) * P.Ws + sx) * C + qd * 4;
+        aoff[l] = ((long long)(im * P.Hs + sy) * P.Ws + sx) * C + qd * 4;
       }
     }
   }
@@ -121,40 +129,14 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   };
 
   // ---- B panel of one (chunk, tap): 32 k x 128 n
-  const int T9 = 9;
-  // weight panel of one (chunk, tap): 128 rows (output channels) x 32 k, K-contiguous in memory ([Nout][9][C])
-  auto b_gload = [&](float4 (&bpre)[2 * BREP], int chunk, int tap) {
-#pragma unroll
-    for (int rep = 0; rep < BREP; ++rep) {
-      const int tt = t + PTHREADS * rep;
-      int n = n0 + (tt >> 2), k8 = (tt & 3) * 8;
-      if (n < P.Nout) {
-        const float* src = P.w + ((size_t)n * T9 + tap) * C + (chunk << 5) + k8;
-        bpre[2 * rep] = *reinterpret_cast<const float4*>(src);
-        bpre[2 * rep + 1] = *reinterpret_cast<const float4*>(src + 4);
-      } else { bpre[2 * rep] = bpre[2 * rep + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    }
-  };
-  auto b_lstore = [&](const float4 (&bpre)[2 * BREP], unsigned short* sb) {
-#pragma unroll
-    for (int rep = 0; rep < BREP; ++rep) {
-      const int tt = t + PTHREADS * rep;
-      const float4 v0 = bpre[2 * rep], v1 = bpre[2 * rep + 1];
-      int nl = tt >> 2, k8 = (tt & 3) * 8;
-      unsigned a[NS], b[NS], c[NS], d[NS];
-      p_split2<NS>(v0.x, v0.y, a); p_split2<NS>(v0.z, v0.w, b);
-      p_split2<NS>(v1.x, v1.y, c); p_split2<NS>(v1.z, v1.w, d);
-#pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(&sb[p * PPLANE(PBN) + PSLOT(nl, k8 >> 3)]) = make_uint4(a[p], b[p], c[p], d[p]);
-    }
-  };
-
-  // ---- A fragment rows of this wave
   // MFMA row i of 32-row group g = wm*2+a <-> pixel (by*8 + i/4, bx*4 + i%4), (bx, by) = (g & 3, g >> 2): with the 20-pixel
   // pitch and 80-byte rows the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots for all 9 tap shifts
   int apix[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) { int g = wm * 2 + a; apix[a] = ((g >> 2) * 8 + (li >> 2)) * PPW + (g & 3) * 4 + (li & 3); }
+  for (int a = 0; a < 2; ++a) {
+    const int g = wm * 2 + a, bx = g & 3;
+    apix[a] = ((g >> 2) * 8 + (li >> 2)) * PPW + (W8 ? (bx >> 1) * 10 + (bx & 1) * 4 : bx * 4) + (li & 3);
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -165,80 +147,90 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int nchunk = C >> 5;
-  const int total = 9 * nchunk;                   // (chunk, tap) steps
-  float4 r0[2 * BREP], r1[2 * BREP];              // weight panels in flight: the panel of step s+2 is loaded during step s,
-                                                  // stored to LDS during step s+1 -- its L2 latency is off the critical path
-  auto compute = [&](int tap, const unsigned short* sb) {
+  const int c_begin = sp * P.cps, c_end = min(nchunk, c_begin + P.cps);
+  const int s_begin = 18 * c_begin, total = 18 * c_end;     // (chunk, tap, k-half) steps of 16 k each
+  // B fragments of step s: wp[p][chunk][tap][kc][nt][lane] -> one uint4 (8 bf16) per lane, tile and plane
+  const int nt0 = (n0 >> 5) + wn * 2;
+  const size_t plane_stride = (size_t)nchunk * 18 * P.NT * 512;      // bf16 elements per plane
+  auto ldb = [&](uint4 (&bq)[2][NS], int s) {
+    const unsigned short* base = P.wp + ((size_t)s * P.NT + nt0) * 512 + lane * 8;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        bq[b][p] = (nt0 + b < P.NT) ? *reinterpret_cast<const uint4*>(base + p * plane_stride + b * 512) : make_uint4(0u, 0u, 0u, 0u);
+      }
+  };
+  auto step = [&](int s, const uint4 (&bq)[2][NS], uint4 (&bn)[2][NS]) {
+    if (s + 1 < total) ldb(bn, s + 1);            // next step's weights in flight under this step's MFMAs
+    const int ct = s >> 1, kc = s & 1;
+    const int chunk = ct / 9, tap = ct - chunk * 9;
     const int dy = tap / 3, dx = tap - dy * 3;
     const int ashift = dy * PPW + dx;
+    bf16x8 af[2][NS];
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc) {
-      bf16x8 af[2][NS], bfr[2][NS];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int p = 0; p < NS; ++p)
+        af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
 #pragma unroll
-        for (int p = 0; p < NS; ++p)
-          af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int p = 0; p < NS; ++p)
-          bfr[b][p] = *reinterpret_cast<const bf16x8*>(&sb[p * PPLANE(PBN) + PSLOT((wn * 2 + b) * 32 + li, kc * 2 + h)]);
-#define PDAE_MMA(PA, PB)                                                                                          \
-  _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)                    \
-      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA], bfr[b][PB], acc[a][b], 0, 0, 0);
-      if constexpr (NS == 3) { PDAE_MMA(1, 1) PDAE_MMA(0, 2) PDAE_MMA(2, 0) }
-      if constexpr (NS >= 2) { PDAE_MMA(0, 1) PDAE_MMA(1, 0) }
-      PDAE_MMA(0, 0)
-#undef PDAE_MMA
-    }
-  };
-  int buf = 0;
-  // one (chunk, tap) step.  rl: register set that receives the panel of step s+2; rs: set holding the panel of step s+1
-  auto step = [&](int s, float4 (&rl)[2 * BREP], const float4 (&rs)[2 * BREP]) {
-    const int chunk = s / 9, tap = s - chunk * 9;
-    if (s + 2 < total) { const int c2 = (s + 2) / 9; b_gload(rl, c2, s + 2 - c2 * 9); }
-    if (tap == 0 && chunk + 1 < nchunk) a_gload((chunk + 1) << 5);          // next patch in flight during the 9 taps
-    compute(tap, DBUF ? sB + buf * SB : sB);
-    if constexpr (DBUF) {
-      if (s + 1 < total) b_lstore(rs, sB + (buf ^ 1) * SB);                  // other buffer: nobody reads it during this step
-      if (tap == 8 && chunk + 1 < nchunk) {
-        __syncthreads();                                                     // every wave is done with the current patch
-        a_lstore();
+      for (int b = 0; b < 2; ++b) {
+#define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[b][P_])
+        if constexpr (NS == 3) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], PDAE_B(1), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(2), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], PDAE_B(0), acc[a][b], 0, 0, 0);
+        }
+        if constexpr (NS >= 2) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(1), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], PDAE_B(0), acc[a][b], 0, 0, 0);
+        }
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(0), acc[a][b], 0, 0, 0);
+#undef PDAE_B
       }
+    // patch hand-over at the end of a chunk: the only barriers of the kernel
+    if ((s + 1) % 18 == 0 && s + 1 < total) {
+      __syncthreads();                            // every wave is done with the current patch
+      a_lstore();
       __syncthreads();
-      buf ^= 1;
-    } else {
-      if (s + 1 < total) {
-        __syncthreads();                                                     // every wave is done reading the panel (and the patch)
-        b_lstore(rs, sB);
-        if (tap == 8) a_lstore();
-        __syncthreads();
-      }
+      if (chunk + 2 < c_end) a_gload((chunk + 2) << 5);
     }
   };
-  a_gload(0);
-  b_gload(r0, 0, 0);
-  if (total > 1) b_gload(r1, 0, 1);
+  uint4 q0[2][NS], q1[2][NS];
+  a_gload(c_begin << 5);
+  ldb(q0, s_begin);
   a_lstore();
-  b_lstore(r0, sB);
   __syncthreads();
-  for (int s = 0; s < total; s += 2) {
-    step(s, r0, r1);
-    if (s + 1 < total) step(s + 1, r1, r0);
+  if (c_begin + 1 < c_end) a_gload((c_begin + 1) << 5);
+  for (int s = s_begin; s < total; s += 2) {      // an even number of steps
+    step(s, q0, q1);
+    step(s + 1, q1, q0);
   }
 
   // ---- epilogue
+  const long long Mtot = (long long)P.N * P.H * P.W;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * h, g = wm * 2 + a;
-      const int oy = y0 + (g >> 2) * 8 + (i >> 2), ox = x0 + (g & 3) * 4 + (i & 3);
-      if (oy >= P.H || ox >= P.W) continue;
-      const long long row = ((long long)img * P.H + oy) * P.W + ox;
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h, g = wm * 2 + a, bx = g & 3;
+      const int oy = y0 + (g >> 2) * 8 + (i >> 2);
+      const int ox = W8 ? (bx & 1) * 4 + (i & 3) : x0 + bx * 4 + (i & 3);
+      const int im = W8 ? img + (bx >> 1) : img;
+      if (oy >= P.H || ox >= P.W || im >= P.N) continue;
+      const long long row = ((long long)im * P.H + oy) * P.W + ox;
+      if (P.splits > 1) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int col = n0 + (wn * 2 + b) * 32 + li;
+          if (col < P.Nout) P.slab[((long long)sp * Mtot + row) * P.Nout + col] = acc[a][b][r];
+        }
+        continue;
+      }
       long long rrow = row;
-      if (P.res_mode == 2) rrow = ((long long)img * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
+      if (P.res_mode == 2) rrow = ((long long)im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int col = n0 + (wn * 2 + b) * 32 + li;
@@ -254,17 +246,49 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   }
 }
 
-template <int NS, int PTH> static int launch_ns(const PatchParams& P, hipStream_t s) {
+// y = sum of the split slabs (fixed order) + bias + residual (+ y)
+__global__ void __launch_bounds__(256) conv3x3p_reduce_kernel(const PatchParams P) {
+  const int n4 = P.Nout >> 2;
+  const long long Mtot = (long long)P.N * P.H * P.W, total = Mtot * n4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / n4; const int col = (int)(i - row * n4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(P.slab + row * P.Nout + col);
+    for (int k = 1; k < P.splits; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(P.slab + ((long long)k * Mtot + row) * P.Nout + col);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (P.bias) { const float4 u = *reinterpret_cast<const float4*>(P.bias + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    if (P.res_mode) {
+      long long rrow = row;
+      if (P.res_mode == 2) {
+        const int ox = (int)(row % P.W); const long long t2 = row / P.W; const int oy = (int)(t2 % P.H); const long long im = t2 / P.H;
+        rrow = (im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
+      }
+      const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    float4* dst = reinterpret_cast<float4*>(P.y + row * P.Nout + col);
+    if (P.accumulate) { const float4 u = *dst; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    *dst = v;
+  }
+}
+
+template <int NS, int PTH, bool W8> static int launch_ns(const PatchParams& P, hipStream_t s) {
   constexpr int NPIX = (PTH + 2) * PPW;
-  const size_t smem = (size_t)(NS * PPLANE(NPIX) + (PTH == 16 ? 2 : 1) * NS * PPLANE(PBN)) * sizeof(unsigned short);
+  const size_t smem = (size_t)(NS * PPLANE(NPIX)) * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS, PTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS, PTH, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3p: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  dim3 grid(P.N * P.tiles_y * P.tiles_x * P.tiles_n);
-  hipLaunchKernelGGL((conv3x3p_kernel<NS, PTH>), grid, dim3(PTH * 32), smem, s, P);
+  const int nimg = W8 ? (P.N + 1) / 2 : P.N;
+  dim3 grid(nimg * P.tiles_y * P.tiles_x * P.tiles_n * P.splits);
+  hipLaunchKernelGGL((conv3x3p_kernel<NS, PTH, W8>), grid, dim3(PTH * 32), smem, s, P);
+  if (P.splits > 1) {
+    const long long total = (long long)P.N * P.H * P.W * (P.Nout >> 2);
+    long long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(conv3x3p_reduce_kernel, dim3((int)nb), dim3(256), 0, s, P);
+  }
   return pdae_launch_status("conv3x3p");
 }
 
@@ -274,26 +298,105 @@ static int patch_th() {                        // PDAE_P3_TH = 8 | 16 overrides 
   return th;
 }
 
-// eligibility: 3x3, stride 1, pad 1, one source, channels % 32, spatial tile-aligned and enough tiles to fill the chip
-bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout) {
-  if (math < 1 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || C1 != 0) return false;
-  if ((C & 31) || (H % 8) || (W % PTW) || (Nout & 3) || Nout < 32) return false;
-  long long blocks = (long long)N * (H / 8) * (W / PTW) * ((Nout + PBN - 1) / PBN);
-  return blocks >= 256;
+// launch plan of one convolution: tile geometry and split-K factor, a pure function of the shape (shared by the workspace
+// query and the launch)
+struct PatchPlan { int th, w8, tiles_x, tiles_y, tiles_n, splits, cps; long long blocks; };
+static PatchPlan patch_plan(int C, int H, int W, int N, int Nout) {
+  PatchPlan q;
+  q.w8 = W == 8;
+  q.th = patch_th();
+  if (q.th != 8 && q.th != 16) q.th = 8;       // 8x16 tiles: two independent 4-wave blocks per CU overlap each other's staging phases
+  if (q.w8 || (H % q.th)) q.th = 8;
+  q.tiles_x = q.w8 ? 1 : W / PTW; q.tiles_y = H / q.th; q.tiles_n = (Nout + PBN - 1) / PBN;
+  const long long base = (long long)(q.w8 ? (N + 1) / 2 : N) * q.tiles_x * q.tiles_y * q.tiles_n;
+  const int nchunk = C >> 5, slots = q.th == 8 ? 512 : 256;            // resident blocks of a full chip
+  int want = base >= slots * 3 / 4 ? 1 : (int)((slots + base - 1) / base);
+  if (want > nchunk) want = nchunk;
+  if (want > 16) want = 16;
+  q.cps = (nchunk + want - 1) / want;
+  q.splits = (nchunk + q.cps - 1) / q.cps;
+  q.blocks = base * q.splits;
+  return q;
 }
 
-int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* w, int Nout,
+// eligibility: 3x3, stride 1, pad 1, one source, channels % 32, spatial tile-aligned (W % 16, or W == 8 for image pairs);
+// fill: also enough blocks to occupy the chip (fill = false: shape eligibility only)
+bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout, bool fill) {
+  if (math < 1 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || C1 != 0) return false;
+  if ((C & 31) || (H % 8) || ((W % PTW) && W != 8) || (Nout & 3)) return false;
+  if (!fill) return true;
+  return Nout >= 32 && patch_plan(C, H, W, N, Nout).blocks >= 256;
+}
+
+static size_t slab_bytes(int C, int H, int W, int N, int Nout) {
+  const PatchPlan q = patch_plan(C, H, W, N, Nout);
+  return q.splits > 1 ? (size_t)q.splits * N * H * W * Nout * sizeof(float) : 0;
+}
+
+static size_t prep_bytes(int math, int Nout, int C) {
+  const int NS = math < 1 ? 1 : (math > 3 ? 3 : math);
+  const size_t b = (size_t)NS * (C >> 5) * 18 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short);
+  return (b + 255) & ~(size_t)255;
+}
+
+// prepared weights + split-K slabs of the convolution (one buffer: [planes | slabs])
+size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { return prep_bytes(math, Nout, C) + slab_bytes(C, H, W, N, Nout); }
+
+int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s) {
   PatchParams P;
-  P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.w = w; P.Nout = Nout;
+  P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.wp = wp; P.NT = (Nout + 31) / 32; P.Nout = Nout;
   P.y = y; P.bias = bias; P.res = res; P.res_mode = res_mode; P.accumulate = accumulate;
-  int th = patch_th();
-  if (th != 8 && th != 16) th = 16;
-  if (H % th) th = 8;
-  P.tiles_x = W / PTW; P.tiles_y = H / th; P.tiles_n = (Nout + PBN - 1) / PBN;
-#define PDAE_P3(NS_) (th == 16 ? launch_ns<NS_, 16>(P, s) : launch_ns<NS_, 8>(P, s))
+  const PatchPlan q = patch_plan(C, H, W, N, Nout);
+  P.tiles_x = q.tiles_x; P.tiles_y = q.tiles_y; P.tiles_n = q.tiles_n; P.splits = q.splits; P.cps = q.cps;
+  P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));
+#define PDAE_P3(NS_) (q.w8 ? launch_ns<NS_, 8, true>(P, s) : q.th == 16 ? launch_ns<NS_, 16, false>(P, s) : launch_ns<NS_, 8, false>(P, s))
   if (math == 1) return PDAE_P3(1);
   if (math == 2) return PDAE_P3(2);
   return PDAE_P3(3);
 #undef PDAE_P3
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation: w [Nout][9][C] fp32 (or, transposed: the data-gradient weights of w [C][9][Nout])  ->  wp [NS][C/32][9][2][NT][64][8] bf16 planes in MFMA B-fragment order
+// (lane l of a wave holds k = (l>>5)*8 + j, j = 0..7, of output channel nt*32 + (l&31)).  One thread per fragment slot.
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+__global__ void __launch_bounds__(256) conv3x3p_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed, unsigned short* __restrict__ wp) {
+  const size_t nslot = (size_t)(C >> 5) * 18 * NT * 64;
+  const size_t plane_stride = nslot * 8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63); size_t r = i >> 6;
+    const int nt = (int)(r % NT); r /= NT;
+    const int kc = (int)(r & 1); r >>= 1;
+    const int tap = (int)(r % 9); const int chunk = (int)(r / 9);
+    const int n = nt * 32 + (lane & 31), c = (chunk << 5) + kc * 16 + (lane >> 5) * 8;
+    float e[8];
+    if (n < Nout && transposed) {               // GEMM weight w'[n][tap][c] = w[c][8 - tap][n]   (w stored [C][9][Nout])
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = w[((size_t)(c + j) * 9 + (8 - tap)) * Nout + n];
+    } else if (n < Nout) {
+      const float4 v0 = *reinterpret_cast<const float4*>(w + ((size_t)n * 9 + tap) * C + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(w + ((size_t)n * 9 + tap) * C + c + 4);
+      e[0] = v0.x; e[1] = v0.y; e[2] = v0.z; e[3] = v0.w; e[4] = v1.x; e[5] = v1.y; e[6] = v1.z; e[7] = v1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    }
+    unsigned a[NS], b[NS], cc[NS], d[NS];
+    p_split2<NS>(e[0], e[1], a); p_split2<NS>(e[2], e[3], b); p_split2<NS>(e[4], e[5], cc); p_split2<NS>(e[6], e[7], d);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
+  }
+}
+
+int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s) {
+  const int NT = (Nout + 31) / 32;
+  const size_t nslot = (size_t)(C >> 5) * 18 * NT * 64;
+  int grid = (int)((nslot + 255) / 256); if (grid > 4096) grid = 4096;
+  if (math == 1) hipLaunchKernelGGL(conv3x3p_wprep_kernel<1>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wp);
+  else if (math == 2) hipLaunchKernelGGL(conv3x3p_wprep_kernel<2>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wp);
+  else hipLaunchKernelGGL(conv3x3p_wprep_kernel<3>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wp);
+  return pdae_launch_status("conv3x3p_wprep");
 }

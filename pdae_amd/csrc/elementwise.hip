@@ -344,25 +344,3 @@ int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws,
   return pdae_launch_status("colsum");
 }
 
-// ---------------------------------------------------------------------------------------------
-// wt[ci][T-1-tap][co] = w[co][tap][ci]: transposed, tap-flipped copy of a conv weight, so that the data gradient of a
-// stride-1 convolution is itself a plain forward convolution of dY with wt (conv3x3p.hip)
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) wtranspose_kernel(const float* __restrict__ w, int Cout, int T, int Cin, float* __restrict__ wt) {
-  __shared__ float tile[32][33];
-  const int tap = blockIdx.z, c0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) {
-    int co = o0 + r, ci = c0 + tx;
-    tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + tap) * Cin + ci] : 0.f;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    int ci = c0 + r, co = o0 + tx;
-    if (ci < Cin && co < Cout) wt[((size_t)ci * T + (T - 1 - tap)) * Cout + co] = tile[tx][r];
-  }
-}
-int k_wtranspose(const float* w, int Cout, int T, int Cin, float* wt, hipStream_t st) {
-  hipLaunchKernelGGL(wtranspose_kernel, dim3(cdiv(Cin, 32), cdiv(Cout, 32), T), dim3(256), 0, st, w, Cout, T, Cin, wt);
-  return pdae_launch_status("wtranspose");
-}

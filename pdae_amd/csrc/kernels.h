@@ -35,4 +35,3 @@ int k_softmax(float* s, long long rows, int T, hipStream_t st);
 int k_softmax_bwd(const float* p, float* dp, long long rows, int T, hipStream_t st);
 size_t k_colsum_workspace_floats(long long M, int C);
 int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws, hipStream_t st);
-int k_wtranspose(const float* w, int Cout, int T, int Cin, float* wt, hipStream_t st);

@@ -126,8 +126,22 @@ class Builder:
         c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=k, stride=stride, up=up, math=self.math)
         assert w.numel() == c.Cout * k * k * c.Cin, (wname, tuple(w.shape), c.Cin)
         y = self.p.buf(N, c.Ho, c.Wo, c.Cout)
-        self.p.emit(H.op_conv_fwd(c, x0, x1, w, b, y, res=res, res_mode=res_mode))
+        wp = self._wprep(c, w, 0)
+        self.p.emit(H.op_conv_fwd(c, x0, x1, w, b, y, res=res, res_mode=res_mode, wp=wp))
+        if wp is not None:
+            self.p.free(wp)
         return y, NS(c=c, x0=x0, x1=x1, wname=wname, y=y)
+
+    def _wprep(self, c, w, transposed):
+        """Fragment-ordered bf16 planes of w for the patch kernel (None when the conv is not eligible).  Refreshed right before
+        every use -- the weights change each optimizer step and the copy costs ~10 bytes per parameter, noise next to the
+        convolution itself -- so no cache has to be kept coherent with the optimizer."""
+        nbytes = c.wprep_bytes(transposed)
+        if nbytes == 0:
+            return None
+        wp = self.p.buf((nbytes + 3) // 4)
+        self.p.emit(H.op_conv3x3_wprep(c, w, transposed, wp))
+        return wp
 
     def conv_bwd_params(self, cx, dy):
         """dW, db of a conv stage (only if the parameter is trained by this plan)."""
@@ -148,15 +162,10 @@ class Builder:
         ci_cnt = c.Cin if ci_cnt is None else ci_cnt
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
-        w_t = None
-        if c.math > 0 and c.KH == 3 and c.stride == 1 and ci_off == 0 and ci_cnt == c.Cin:
-            # the data gradient runs as a forward convolution of dy with the transposed, tap-flipped weights; the copy is refreshed
-            # right here (weights change every optimizer step), 2 x 4 bytes per parameter -- noise next to the convolution itself
-            w_t = self.p.buf(w.numel())
-            self.p.emit(H.op_wtranspose(w, c.Cout, c.KH * c.KW, c.Cin, w_t))
-        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate, w_t=w_t))
-        if w_t is not None:
-            self.p.free(w_t)
+        wp_t = self._wprep(c, w, 1) if (ci_off == 0 and ci_cnt == c.Cin) else None
+        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate, wp_t=wp_t))
+        if wp_t is not None:
+            self.p.free(wp_t)
         return dx
 
     def linear(self, x, wname, pre_bias=True):

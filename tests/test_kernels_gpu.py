@@ -378,7 +378,9 @@ MATH_TOL = {1: 2e-2, 2: 1e-4, 3: 1e-5}     # bf16 | 2 planes (3 products) | 3 ex
 @pytest.mark.parametrize("math_mode", [1, 2, 3])
 @pytest.mark.parametrize("case", [(2, 12, 12, 64, 0, 96, 3, 1, 0, 0), (1, 10, 14, 32, 64, 64, 3, 1, 0, 64), (2, 8, 8, 32, 0, 32, 3, 1, 1, 0),
                                   (2, 16, 16, 64, 0, 128, 3, 2, 0, 0), (2, 9, 9, 64, 32, 32, 1, 1, 0, 0), (3, 32, 32, 128, 0, 128, 3, 1, 0, 128),
-                                  (4, 64, 48, 64, 0, 160, 3, 1, 0, 0), (3, 32, 32, 96, 0, 64, 3, 1, 1, 0), (6, 32, 32, 32, 0, 256, 3, 1, 0, 0)])
+                                  (4, 64, 48, 64, 0, 160, 3, 1, 0, 0), (3, 32, 32, 96, 0, 64, 3, 1, 1, 0), (6, 32, 32, 32, 0, 256, 3, 1, 0, 0), (2, 24, 32, 64, 0, 64, 3, 1, 0, 0),
+                                  (4, 8, 8, 128, 0, 64, 3, 1, 0, 0), (3, 8, 8, 64, 0, 32, 3, 1, 0, 0), (2, 4, 4, 64, 0, 64, 3, 1, 1, 0),
+                                  (2, 16, 16, 96, 0, 64, 3, 1, 0, 0), (8, 64, 64, 32, 0, 32, 3, 1, 0, 0)])
 def test_conv_bf16_split_modes(H, case, math_mode):
     """The bf16-MFMA split-operand variants of conv fwd / dgrad / wgrad against fp64."""
     N, Hh, W, C0, C1, Cout, k, stride, up, tile = case
@@ -403,12 +405,22 @@ def test_conv_bf16_split_modes(H, case, math_mode):
     dx = torch.empty(N, c.Hl, c.Wl, Cin, device="cuda")
     H.run(H.op_conv_dgrad(c, dyd, wd, dx, tile=tile))
     assert rel_err(nchw(dx), xl.grad) < tol
-    if k == 3 and stride == 1:      # the fast path: forward patch kernel on the transposed, tap-flipped weight copy
-        w_t = torch.empty(Cin * 9 * Cout, device="cuda")
-        H.run(H.op_wtranspose(wd, Cout, 9, Cin, w_t))
-        assert torch.equal(w_t.view(Cin, 3, 3, Cout).cpu(), w.flip(2, 3).permute(1, 2, 3, 0).contiguous())
+    # the fast path: LDS-patch kernel on fragment-ordered pre-split weights (forced: these shapes are too small to be chosen by the
+    # fill heuristic), forward and -- on the transposed, tap-flipped weights -- data gradient
+    nb = c.wprep_bytes(0, force=True)
+    assert (nb > 0) == (k == 3 and stride == 1 and C1 == 0 and C0 % 32 == 0 and c.Ho % 8 == 0 and (c.Wo % 16 == 0 or c.Wo == 8))
+    if nb:
+        wp = torch.empty(nb // 4, device="cuda")
+        H.run(H.op_conv3x3_wprep(c, wd, 0, wp))
+        y2 = torch.empty_like(y)
+        H.run(H.op_conv_fwd(c, x0, x1, wd, bd, y2, wp=wp))
+        assert rel_err(nchw(y2), ref_conv(x, w, b, stride, k // 2, up)) < tol
+    nb = c.wprep_bytes(1, force=True)
+    if nb:
+        wp_t = torch.empty(nb // 4, device="cuda")
+        H.run(H.op_conv3x3_wprep(c, wd, 1, wp_t))
         dx2 = torch.empty(N, c.Hl, c.Wl, Cin, device="cuda")
-        H.run(H.op_conv_dgrad(c, dyd, wd, dx2, w_t=w_t))
+        H.run(H.op_conv_dgrad(c, dyd, wd, dx2, wp_t=wp_t))
         assert rel_err(nchw(dx2), xl.grad) < tol
     wsb = c.wgrad_ws_bytes()
     dw = torch.empty_like(wd)

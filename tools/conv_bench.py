@@ -33,9 +33,11 @@ for (N, S, C0, C1, Cout, k) in SHAPES:
     for m, name in [(0, "f32"), (3, "x6"), (2, "x3"), (1, "bf16")]:
         c = H.Conv(N, S, S, C0, C1, Cout, k=k, math=m)
         wsb = c.wgrad_ws_bytes(); wsp = torch.empty(wsb // 4 + 16, device="cuda")
-        w_t = None
-        if m > 0 and k == 3:
-            w_t = torch.empty(w.numel(), device="cuda"); H.run(H.op_wtranspose(w, Cout, k * k, Cin, w_t))
-        tf = [fl / timeit(op) / 1e9 for op in (H.op_conv_fwd(c, x0, x1, w, b, y), H.op_conv_dgrad(c, dy, w, dx, w_t=w_t), H.op_conv_wgrad(c, x0, x1, dy, dw, wsp, wsb))]
+        wp = wp_t = None
+        if c.wprep_bytes(0):
+            wp = torch.empty(c.wprep_bytes(0) // 4, device="cuda"); H.run(H.op_conv3x3_wprep(c, w, 0, wp))
+        if c.wprep_bytes(1):
+            wp_t = torch.empty(c.wprep_bytes(1) // 4, device="cuda"); H.run(H.op_conv3x3_wprep(c, w, 1, wp_t))
+        tf = [fl / timeit(op) / 1e9 for op in (H.op_conv_fwd(c, x0, x1, w, b, y, wp=wp), H.op_conv_dgrad(c, dy, w, dx, wp_t=wp_t), H.op_conv_wgrad(c, x0, x1, dy, dw, wsp, wsb))]
         line += f"  {name}: fwd {tf[0]:6.1f} dgrad {tf[1]:6.1f} wgrad {tf[2]:6.1f} |"
     print(line, flush=True)
