@@ -16,6 +16,7 @@
 #include "kernels.h"
 
 struct Src2 { const float* x0; const float* x1; int C0, C1; };
+#define UNR 4        // memory-level parallelism of the streaming loops: independent float4 loads per thread
 
 __device__ __forceinline__ float4 ld4(const Src2& s, size_t pix, int c) {
   return c < s.C0 ? *reinterpret_cast<const float4*>(s.x0 + pix * s.C0 + c)
@@ -64,13 +65,19 @@ __global__ void __launch_bounds__(256) gn_stats_partial_kernel(Src2 s, int HW, i
     float K[4], s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 4; ++j) K[j] = ld1(s, base, ((c + j) / cg) * cg);
-    for (int p = p0 + pl; p < p1; p += PL) {
-      float4 v = ld4(s, base + p, c);
-      float d;
-      d = v.x - K[0]; s1[0] += d; s2[0] += d * d;
-      d = v.y - K[1]; s1[1] += d; s2[1] += d * d;
-      d = v.z - K[2]; s1[2] += d; s2[2] += d * d;
-      d = v.w - K[3]; s1[3] += d; s2[3] += d * d;
+    for (int p = p0 + pl; p < p1; p += UNR * PL) {            // UNR independent 16-byte loads in flight per thread
+      float4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) if (p + u * PL < p1) v[u] = ld4(s, base + p + u * PL, c);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (p + u * PL >= p1) break;
+        float d;
+        d = v[u].x - K[0]; s1[0] += d; s2[0] += d * d;
+        d = v[u].y - K[1]; s1[1] += d; s2[1] += d * d;
+        d = v[u].z - K[2]; s1[2] += d; s2[2] += d * d;
+        d = v[u].w - K[3]; s1[3] += d; s2[3] += d * d;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[(pl * C + c + j) * 2] = s1[j]; red[(pl * C + c + j) * 2 + 1] = s2[j]; }
@@ -162,6 +169,37 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(Src2 s, int N, int H, int
   }
 }
 
+// mode-0 apply, streaming form: block = (pixel chunk, sample), thread = (channel quad, pixel lane) so the per-(n,c)
+// coefficients live in registers and UNR independent loads are in flight per thread
+__global__ void __launch_bounds__(256) gn_apply_stream_kernel(Src2 s, int HW, int C, int N, int chunk, const float* __restrict__ coef, int act,
+                                                              float* __restrict__ y, float drop_p, unsigned long long seed,
+                                                              unsigned long long offset) {
+  const int n = blockIdx.y, NQ = C >> 2, PL = 256 / NQ;
+  const int t = threadIdx.x, q = t % NQ, pl = t / NQ, c = q * 4;
+  if (pl >= PL) return;
+  const size_t NC = (size_t)N * C, base = (size_t)n * HW;
+  const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const float4 mu = *reinterpret_cast<const float4*>(coef + (size_t)n * C + c);
+  const float4 a = *reinterpret_cast<const float4*>(coef + NC + (size_t)n * C + c);
+  const float4 b = *reinterpret_cast<const float4*>(coef + 2 * NC + (size_t)n * C + c);
+  const int p0 = blockIdx.x * chunk, p1 = min(HW, p0 + chunk);
+  for (int p = p0 + pl; p < p1; p += UNR * PL) {
+    float4 x[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) if (p + u * PL < p1) x[u] = ld4(s, base + p + u * PL, c);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (p + u * PL >= p1) break;
+      const size_t pix = base + p + u * PL;
+      float4 o;
+      o.x = a.x * (x[u].x - mu.x) + b.x; o.y = a.y * (x[u].y - mu.y) + b.y; o.z = a.z * (x[u].z - mu.z) + b.z; o.w = a.w * (x[u].w - mu.w) + b.w;
+      if (act) { o.x = siluf(o.x); o.y = siluf(o.y); o.z = siluf(o.z); o.w = siluf(o.w); }
+      if (drop_p > 0.f) { float4 m = drop_mask(seed, offset, pix * NQ + q, drop_p, dscale); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
+      *reinterpret_cast<float4*>(y + pix * C + c) = o;
+    }
+  }
+}
+
 // gradient wrt the activated tensor at input-resolution pixel (n,py,px):
 //   mode 0: dA[pix]; mode 1 (y was pooled): dA[pool pix]/4; mode 2 (consumer read y nearest-upsampled): sum of the 4 children
 __device__ __forceinline__ float4 fetch_da(const float* __restrict__ dA, int mode, int n, int py, int px, int H, int W, int C, int c) {
@@ -204,14 +242,23 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(Src2 s, int H, int W
     const float4 a = *reinterpret_cast<const float4*>(coef + NC + (size_t)n * C + c);
     const float4 b = *reinterpret_cast<const float4*>(coef + 2 * NC + (size_t)n * C + c);
     float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    for (int p = p0 + pl; p < p1; p += PL) {
-      int py = p / W, px = p - py * W;
-      size_t pix = (size_t)n * HW + p;
-      float4 x = ld4(s, pix, c);
-      float4 xm = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
-      float4 dv = compute_dv(fetch_da(dA, mode, n, py, px, H, W, C, c), xm, a, b, act, drop_p, dscale, seed, offset, pix * NQ + q);
-      s0[0] += dv.x; s0[1] += dv.y; s0[2] += dv.z; s0[3] += dv.w;
-      s1[0] += dv.x * xm.x; s1[1] += dv.y * xm.y; s1[2] += dv.z * xm.z; s1[3] += dv.w * xm.w;
+    for (int p = p0 + pl; p < p1; p += UNR * PL) {
+      float4 x[UNR], da[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int pp = p + u * PL;
+        if (pp < p1) { const int py = pp / W, px = pp - py * W; x[u] = ld4(s, (size_t)n * HW + pp, c); da[u] = fetch_da(dA, mode, n, py, px, H, W, C, c); }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int pp = p + u * PL;
+        if (pp >= p1) break;
+        const size_t pix = (size_t)n * HW + pp;
+        float4 xm = make_float4(x[u].x - mu.x, x[u].y - mu.y, x[u].z - mu.z, x[u].w - mu.w);
+        float4 dv = compute_dv(da[u], xm, a, b, act, drop_p, dscale, seed, offset, pix * NQ + q);
+        s0[0] += dv.x; s0[1] += dv.y; s0[2] += dv.z; s0[3] += dv.w;
+        s1[0] += dv.x * xm.x; s1[1] += dv.y * xm.y; s1[2] += dv.z * xm.z; s1[3] += dv.w * xm.w;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[(pl * C + c + j) * 2] = s0[j]; red[(pl * C + c + j) * 2 + 1] = s1[j]; }
@@ -273,38 +320,55 @@ __global__ void gn_bwd_param_kernel(int N, int C, const float* __restrict__ pgb,
   dgamma[c] = a; dbeta[c] = b;
 }
 
-// dx = a*dv - c1 - (x-mu)*c2 (+ add, resampled like dA); split into the two concat sources.
-__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H, int W, int C, const float* __restrict__ coef,
+// dx = a*dv - c1 - (x-mu)*c2 (+ add, resampled like dA); split into the two concat sources.  Streaming form as gn_apply_stream.
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H, int W, int C, int chunk, const float* __restrict__ coef,
                                                            const float* __restrict__ c12, const float* __restrict__ dA, int act, int mode,
                                                            float drop_p, unsigned long long seed, unsigned long long offset,
                                                            const float* __restrict__ add, float* __restrict__ dx0, int acc0,
                                                            float* __restrict__ dx1, int acc1) {
-  const int NQ = C >> 2, HW = H * W;
-  const size_t total = (size_t)N * HW * NQ, NC = (size_t)N * C;
+  const int n = blockIdx.y, NQ = C >> 2, PL = 256 / NQ, HW = H * W;
+  const int t = threadIdx.x, q = t % NQ, pl = t / NQ, c = q * 4;
+  if (pl >= PL) return;
+  float* dbase; int accf, Cd, cd;
+  if (c < s.C0) { dbase = dx0; accf = acc0; Cd = s.C0; cd = c; }
+  else { dbase = dx1; accf = acc1; Cd = s.C1; cd = c - s.C0; }
+  if (!dbase) return;
+  const size_t NC = (size_t)N * C;
   const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    int q = (int)(i % NQ); size_t pix = i / NQ; int c = q * 4;
-    int n = (int)(pix / HW); int p = (int)(pix - (size_t)n * HW); int py = p / W, px = p - py * W;
-    float* dst; int accf;
-    if (c < s.C0) { dst = dx0 ? dx0 + pix * s.C0 + c : nullptr; accf = acc0; }
-    else { dst = dx1 ? dx1 + pix * s.C1 + (c - s.C0) : nullptr; accf = acc1; }
-    if (!dst) continue;
-    const float4 mu = *reinterpret_cast<const float4*>(coef + (size_t)n * C + c);
-    const float4 a = *reinterpret_cast<const float4*>(coef + NC + (size_t)n * C + c);
-    const float4 b = *reinterpret_cast<const float4*>(coef + 2 * NC + (size_t)n * C + c);
-    const float* cp = c12 + ((size_t)n * C + c) * 2;
-    const float4 ca = *reinterpret_cast<const float4*>(cp), cb = *reinterpret_cast<const float4*>(cp + 4);   // c1,c2 interleaved
-    float4 x = ld4(s, pix, c);
-    float4 xm = make_float4(x.x - mu.x, x.y - mu.y, x.z - mu.z, x.w - mu.w);
-    float4 dv = compute_dv(fetch_da(dA, mode, n, py, px, H, W, C, c), xm, a, b, act, drop_p, dscale, seed, offset, i);
-    float4 o;
-    o.x = a.x * dv.x - ca.x - xm.x * ca.y;
-    o.y = a.y * dv.y - ca.z - xm.y * ca.w;
-    o.z = a.z * dv.z - cb.x - xm.z * cb.y;
-    o.w = a.w * dv.w - cb.z - xm.w * cb.w;
-    if (add) { float4 ad = fetch_da(add, mode, n, py, px, H, W, C, c); o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w; }
-    if (accf) { float4 e = *reinterpret_cast<const float4*>(dst); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
-    *reinterpret_cast<float4*>(dst) = o;
+  const float4 mu = *reinterpret_cast<const float4*>(coef + (size_t)n * C + c);
+  const float4 a = *reinterpret_cast<const float4*>(coef + NC + (size_t)n * C + c);
+  const float4 b = *reinterpret_cast<const float4*>(coef + 2 * NC + (size_t)n * C + c);
+  const float* cp = c12 + ((size_t)n * C + c) * 2;
+  const float4 ca = *reinterpret_cast<const float4*>(cp), cb = *reinterpret_cast<const float4*>(cp + 4);   // c1,c2 interleaved
+  const int p0 = blockIdx.x * chunk, p1 = min(HW, p0 + chunk);
+  for (int p = p0 + pl; p < p1; p += UNR * PL) {
+    float4 x[UNR], da[UNR], ad[UNR], ex[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int pp = p + u * PL;
+      if (pp < p1) {
+        const int py = pp / W, px = pp - py * W; const size_t pix = (size_t)n * HW + pp;
+        x[u] = ld4(s, pix, c); da[u] = fetch_da(dA, mode, n, py, px, H, W, C, c);
+        if (add) ad[u] = fetch_da(add, mode, n, py, px, H, W, C, c);
+        if (accf) ex[u] = *reinterpret_cast<const float4*>(dbase + pix * Cd + cd);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int pp = p + u * PL;
+      if (pp >= p1) break;
+      const size_t pix = (size_t)n * HW + pp;
+      float4 xm = make_float4(x[u].x - mu.x, x[u].y - mu.y, x[u].z - mu.z, x[u].w - mu.w);
+      float4 dv = compute_dv(da[u], xm, a, b, act, drop_p, dscale, seed, offset, pix * NQ + q);
+      float4 o;
+      o.x = a.x * dv.x - ca.x - xm.x * ca.y;
+      o.y = a.y * dv.y - ca.z - xm.y * ca.w;
+      o.z = a.z * dv.z - cb.x - xm.z * cb.y;
+      o.w = a.w * dv.w - cb.z - xm.w * cb.w;
+      if (add) { o.x += ad[u].x; o.y += ad[u].y; o.z += ad[u].z; o.w += ad[u].w; }
+      if (accf) { o.x += ex[u].x; o.y += ex[u].y; o.z += ex[u].z; o.w += ex[u].w; }
+      *reinterpret_cast<float4*>(dbase + pix * Cd + cd) = o;
+    }
   }
 }
 
@@ -314,6 +378,13 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H,
 static int stats_chunks(int HW, int C) {
   long long el = (long long)HW * C;
   int S = (int)(el / 16384); if (S < 1) S = 1; if (S > 64) S = 64; if (S > HW) S = HW;
+  return S;
+}
+
+// pixel chunks per sample of the streaming apply kernels: ~64 KB of the tensor per block, enough blocks to fill the chip
+static int stream_chunks(int HW, int C) {
+  long long el = (long long)HW * C;
+  int S = (int)(el / 16384); if (S < 1) S = 1; if (S > HW) S = HW;
   return S;
 }
 
@@ -352,6 +423,13 @@ int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, i
   PDAE_CHECK_ARG(mode == 0 || (mode == 1 && (H % 2) == 0 && (W % 2) == 0 && drop_p == 0.f), "gn_apply: bad mode/shape");
   const int C = C0 + C1;
   Src2 s{x0, x1, C0, C1};
+  if (mode == 0 && xpool == nullptr) {
+    const int HW = H * W;
+    int S = stream_chunks(HW, C), chunk = cdiv(HW, S);
+    S = cdiv(HW, chunk);
+    hipLaunchKernelGGL(gn_apply_stream_kernel, dim3(S, N), dim3(256), 0, st, s, HW, C, N, chunk, coef, act, y, drop_p, seed, offset);
+    return pdae_launch_status("gn_apply");
+  }
   size_t total = (size_t)N * (mode ? (H / 2) * (W / 2) : H * W) * (C / 4);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, s, N, H, W, C, coef, act, mode, y, xpool, drop_p, seed, offset);
   return pdae_launch_status("gn_apply");
@@ -374,8 +452,9 @@ int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int
   if (dgamma)
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, N, C, pgb, dgamma, dbeta, acc_param);
   if (dx0 || dx1) {
-    size_t total = (size_t)N * HW * (C / 4);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, s, N, H, W, C, coef, c12, dA, act, mode, drop_p, seed, offset,
+    int Sa = stream_chunks(HW, C), chunk_a = cdiv(HW, Sa);
+    Sa = cdiv(HW, chunk_a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(Sa, N), dim3(256), 0, st, s, N, H, W, C, chunk_a, coef, c12, dA, act, mode, drop_p, seed, offset,
                        add, dx0, acc0, dx1, acc1);
   }
   return pdae_launch_status("gn_bwd");
