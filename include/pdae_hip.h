@@ -89,6 +89,15 @@ int pdae_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, 
                 uint64_t seed, uint64_t offset, const float* add, float* dx0, int acc0, float* dx1, int acc1, float* dgamma, float* dbeta,
                 int acc_param, float* dss, float* dzss, void* ws, pdae_stream_t stream);
 
+/* ---- MLPSkipNet layer body (model/mlp_skip_net.py:123-141): per row of a [R][C] activation
+ *   y = act( LayerNorm_C( u * (1 + e) ) * gamma + beta );  e may be NULL (no condition), norm = 0 skips the LayerNorm, act: 1 = SiLU.
+ * fwd stores the row statistics; bwd writes du, de and the per-element terms tg = dv*xhat, tb = dv whose column sums (pdae_colsum)
+ * are d gamma / d beta. */
+int pdae_mlp_modln_fwd(const float* u, const float* e, const float* gamma, const float* beta, int R, int C, int norm, int act, float eps, float* y,
+                       float* mean, float* rstd, pdae_stream_t stream);
+int pdae_mlp_modln_bwd(const float* u, const float* e, const float* gamma, const float* beta, const float* mean, const float* rstd, const float* dy,
+                       int R, int C, int norm, int act, float* du, float* de, float* tg, float* tb, pdae_stream_t stream);
+
 /* ---- small elementwise pieces */
 int pdae_timestep_embedding(const int64_t* t, const float* freqs, int N, int dim, float* out, pdae_stream_t stream); /* module.py:66-84 */
 int pdae_silu(const float* x, float* y, size_t n, pdae_stream_t stream);
@@ -124,7 +133,7 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV3X3_WPREP
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV3X3_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD
 };
 typedef struct pdae_op {
   int32_t kind;

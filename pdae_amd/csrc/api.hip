@@ -206,6 +206,15 @@ extern "C" int pdae_timestep_embedding(const int64_t* t, const float* freqs, int
   PDAE_CHECK_ARG(t && freqs && out && N > 0 && dim > 1, "timestep_embedding: bad arguments");
   return k_timestep_embedding((const long long*)t, freqs, N, dim, out, S(stream));
 }
+extern "C" int pdae_mlp_modln_fwd(const float* u, const float* e, const float* gamma, const float* beta, int R, int C, int norm, int act, float eps,
+                                  float* y, float* mean, float* rstd, pdae_stream_t stream) {
+  return k_mlp_modln_fwd(u, e, gamma, beta, R, C, norm, act, eps, y, mean, rstd, S(stream));
+}
+extern "C" int pdae_mlp_modln_bwd(const float* u, const float* e, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                  const float* dy, int R, int C, int norm, int act, float* du, float* de, float* tg, float* tb,
+                                  pdae_stream_t stream) {
+  return k_mlp_modln_bwd(u, e, gamma, beta, mean, rstd, dy, R, C, norm, act, du, de, tg, tb, S(stream));
+}
 extern "C" int pdae_silu(const float* x, float* y, size_t n, pdae_stream_t stream) { return k_silu(x, y, n, S(stream)); }
 extern "C" int pdae_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int acc, pdae_stream_t stream) {
   return k_silu_bwd(x, dy, dx, n, acc, S(stream));
@@ -290,6 +299,10 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
                          (int)i[6], (int)i[7], (float)f[0], (uint64_t)i[11], (uint64_t)i[12], F(9), FM(10), (int)i[8], FM(11), (int)i[9], FM(12),
                          FM(13), (int)i[10], FM(14), FM(15), p[16], st);
     case PDAE_OP_TEMB: return pdae_timestep_embedding((const int64_t*)p[0], F(1), (int)i[0], (int)i[1], FM(2), st);
+    case PDAE_OP_MLP_MODLN_FWD:
+      return pdae_mlp_modln_fwd(F(0), F(1), F(2), F(3), (int)i[0], (int)i[1], (int)i[2], (int)i[3], (float)f[0], FM(4), FM(5), FM(6), st);
+    case PDAE_OP_MLP_MODLN_BWD:
+      return pdae_mlp_modln_bwd(F(0), F(1), F(2), F(3), F(4), F(5), F(6), (int)i[0], (int)i[1], (int)i[2], (int)i[3], FM(7), FM(8), FM(9), FM(10), st);
     case PDAE_OP_SILU: return pdae_silu(F(0), FM(1), (size_t)i[0], st);
     case PDAE_OP_SILU_BWD: return pdae_silu_bwd(F(0), F(1), FM(2), (size_t)i[0], (int)i[1], st);
     case PDAE_OP_AXPBY: return pdae_axpby(F(0), FM(1), (size_t)i[0], (float)f[0], (float)f[1], st);

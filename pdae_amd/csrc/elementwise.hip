@@ -318,16 +318,21 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
 }
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out, int acc) {
   __shared__ float red[256];
-  const int t = threadIdx.x, cl = t & 31, lane = t >> 5;          // 32 columns x 8 lanes per block
-  const int c = blockIdx.x * 32 + cl;
-  float a = 0.f;
-  if (c < C)
-    for (int b = lane; b < nb; b += 8) a += part[(size_t)b * C + c];
-  red[t] = a;
+  const int t = threadIdx.x, cl = t & 15, lane = t >> 4;          // 16 columns x 16 lanes per block, 4 loads in flight per lane
+  const int c = blockIdx.x * 16 + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < C) {
+    int b = lane;
+    for (; b + 48 < nb; b += 64) {
+      a0 += part[(size_t)b * C + c]; a1 += part[(size_t)(b + 16) * C + c]; a2 += part[(size_t)(b + 32) * C + c]; a3 += part[(size_t)(b + 48) * C + c];
+    }
+    for (; b < nb; b += 16) a0 += part[(size_t)b * C + c];
+  }
+  red[t] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (lane == 0 && c < C) {
     float s = 0.f;
-    for (int l = 0; l < 8; ++l) s += red[l * 32 + cl];
+    for (int l = 0; l < 16; ++l) s += red[l * 16 + cl];
     out[c] = acc ? out[c] + s : s;
   }
 }
@@ -340,7 +345,7 @@ int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws,
     hipLaunchKernelGGL(colsum_partial_kernel<4>, dim3(nb), dim3(256), 0, st, x, M, C, rows_per, ws);
   else
     hipLaunchKernelGGL(colsum_partial_kernel<1>, dim3(nb), dim3(256), 0, st, x, M, C, rows_per, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, ws, nb, C, out, acc);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, ws, nb, C, out, acc);
   return pdae_launch_status("colsum");
 }
 

@@ -92,13 +92,17 @@ __global__ void __launch_bounds__(256) gn_stats_partial_kernel(Src2 s, int HW, i
   }
 }
 
-__global__ void gn_stats_finalize_kernel(Src2 s, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
-                                         float* __restrict__ mean, float* __restrict__ rstd) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per (n, group): lanes over the S <= 64 partials, butterfly-reduced in double
+__global__ void __launch_bounds__(256) gn_stats_finalize_kernel(Src2 s, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
+                                                                float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= N * G) return;
-  int n = i / G, g = i - n * G, cg = C / G;
+  const int n = i / G, g = i - n * G, cg = C / G;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < S; ++k) { const float* o = part + (((size_t)n * S + k) * G + g) * 2; a += o[0]; b += o[1]; }
+  for (int k = lane; k < S; k += 64) { const float* o = part + (((size_t)n * S + k) * G + g) * 2; a += o[0]; b += o[1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+  if (lane) return;
   double cnt = (double)cg * HW;
   double K = ld1(s, (size_t)n * HW, g * cg);
   double m = a / cnt;
@@ -405,7 +409,7 @@ int k_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, 
   int S = stats_chunks(HW, C), chunk = cdiv(HW, S);
   S = cdiv(HW, chunk);
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, N), dim3(256), 0, st, s, HW, C, G, chunk, ws);
-  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cdiv(N * G, 128)), dim3(128), 0, st, s, N, HW, C, G, S, eps, ws, mean, rstd);
+  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, st, s, N, HW, C, G, S, eps, ws, mean, rstd);
   return pdae_launch_status("gn_stats");
 }
 

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
- OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV3X3_WPREP) = range(1, 28)
+ OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV3X3_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD) = range(1, 30)
 
 
 class PdaeOp(ctypes.Structure):
@@ -68,7 +68,7 @@ def lib():
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
            "pdae_conv2d_wgrad", "pdae_conv3x3_wprep_bytes", "pdae_conv3x3_wprep", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
-           "pdae_timestep_embedding", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
+           "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_adam_ema", "pdae_run_ops"]
 
@@ -196,6 +196,14 @@ def op_gn_bwd(x0, C0, x1, C1, N, H, W, G, coef, rstd, gamma, beta, ss, zss, dA, 
               dx1=None, acc1=0, dgamma=None, dbeta=None, acc_param=0, dss=None, dzss=None, drop_p=0.0, seed=0, offset=0):
     return make_op(OP_GN_BWD, [x0, x1, coef, rstd, gamma, beta, ss, zss, dA, add, dx0, dx1, dgamma, dbeta, dss, dzss, ws],
                    [C0, C1, N, H, W, G, act, mode, acc0, acc1, acc_param, seed, offset], [drop_p])
+
+
+def op_mlp_modln_fwd(u, e, gamma, beta, R, C, norm, act, eps, y, mean, rstd):
+    return make_op(OP_MLP_MODLN_FWD, [u, e, gamma, beta, y, mean, rstd], [R, C, norm, act], [eps])
+
+
+def op_mlp_modln_bwd(u, e, gamma, beta, mean, rstd, dy, R, C, norm, act, du, de, tg, tb):
+    return make_op(OP_MLP_MODLN_BWD, [u, e, gamma, beta, mean, rstd, dy, du, de, tg, tb], [R, C, norm, act])
 
 
 def op_temb(t, freqs, N, dim, out):
