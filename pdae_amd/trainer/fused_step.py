@@ -26,7 +26,7 @@ from ..model import graph as G
 class FusedRLStep:
     def __init__(self, gaussian_diffusion, encoder, decoder, ema_encoder, ema_decoder, batch, height, width, lr=1e-4, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=0.0, decoupled=False, ema_decay=0.9999, ema_every=1, num_iterations=1, process_group=None,
-                 bucket_mb=48):
+                 bucket_mb=48, math=None):
         gd = gaussian_diffusion
         self.gd, self.enc, self.dec, self.ema_enc, self.ema_dec = gd, encoder, decoder, ema_encoder, ema_decoder
         self.N, self.Hh, self.W = batch, height, width
@@ -49,8 +49,8 @@ class FusedRLStep:
         self.noise = p.buf(N, Hh, W, Cimg)
         self.t = p.buf(N, dtype=torch.int64)
         self.loss = p.buf(1)
-        Be = Builder(p, encoder.P, encoder.grads(), save=True, acc_grads=acc)
-        Bd = Builder(p, decoder.P, decoder.grads(), save=False, drop_p=drop, acc_grads=acc)
+        Be = Builder(p, encoder.P, encoder.grads(), save=True, acc_grads=acc, math=math)
+        Bd = Builder(p, decoder.P, decoder.grads(), save=False, drop_p=drop, acc_grads=acc, math=math)
         # ---- forward
         z, ex = G.encoder_forward(Be, encoder.NAME, self.x0)
         x_t = p.buf(N, Hh, W, Cimg)
@@ -258,6 +258,62 @@ class FusedRegularStep:
             self.cond.copy_(condition)
         if p.drop_ops:
             p.set_dropout(random.getrandbits(31), self.step_count)
+        p.run(0, self.n_bwd)
+        if self.world > 1:
+            dist.all_reduce(self.net.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+        step = self.step_count + 1
+        op = p.arr[self.adam_idx]
+        op.f[5] = self.lr / (1.0 - self.b1 ** step)
+        op.f[6] = 1.0 / math.sqrt(1.0 - self.b2 ** step)
+        op.f[7] = 1.0 / self.world
+        p.run(self.n_bwd, p.n)
+        self.step_count = step
+        return self.loss
+
+
+class FusedLatentStep:
+    """One optimisation step of the latent DPM (config #5, trainer/train_latent_diffusion.py:95-178 +
+    gaussian_diffusion.py:373-398): q_sample on the latent schedule (constant beta 0.008) -> MLPSkipNet fwd -> L1 ->
+    backward -> all-reduce -> Adam / AdamW -> EMA, one plan.  `z_0` is the already normalised latent."""
+
+    def __init__(self, gaussian_diffusion, net, ema_net, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decoupled=True,
+                 ema_decay=0.9999, process_group=None):
+        gd = gaussian_diffusion
+        lcfg = gd.latent_diffusion_config
+        self.gd, self.net, self.ema = gd, net, ema_net
+        self.N, self.timesteps = batch, lcfg["timesteps"]
+        self.lr, self.b1, self.b2 = lr, betas[0], betas[1]
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.step_count = 0
+        ic = net.cfg["input_channel"]
+        p = Plan(net.device)
+        self.plan = p
+        self.z0, self.noise = p.buf(batch, ic), p.buf(batch, ic)
+        self.t = p.buf(batch, dtype=torch.int64)
+        self.loss = p.buf(1)
+        B = Builder(p, net.P, net.grads(), save=True)
+        z_t = p.buf(batch, ic)
+        p.emit(H.op_q_sample(self.z0, self.noise, self.t, lcfg["sqrt_alphas_cumprod"], lcfg["sqrt_one_minus_alphas_cumprod"], batch, ic, z_t))
+        fx = net._emit_forward(B, z_t, self.t)
+        d_out = p.buf(batch, ic)
+        p.emit(H.op_loss(self.noise, fx.out, None, None, None, None, batch, ic, self.loss, None, deps=d_out, l1=1), ws_slot=9)
+        net._emit_backward(B, fx, d_out)
+        self.n_bwd = len(p.recs)
+        self.m, self.v = [torch.zeros_like(net.flat_train)], [torch.zeros_like(net.flat_train)]
+        self.flat_nets = [net]
+        self.adam_idx = p.emit(H.op_adam_ema(net.flat_train, net.flat_grad, self.m[0], self.v[0], ema_net.flat_train if ema_net is not None else None,
+                                             net.flat_train.numel(), lr, self.b1, self.b2, eps, weight_decay, int(decoupled), lr, 1.0, 1.0, ema_decay))
+        p.compile()
+
+    def step(self, z_0, t=None, noise=None):
+        p = self.plan
+        self.z0.copy_(z_0)
+        self.t.copy_(torch.randint(0, self.timesteps, (self.N,), device=self.z0.device, dtype=torch.long) if t is None else t)
+        if noise is None:
+            self.noise.normal_()
+        else:
+            self.noise.copy_(noise)
         p.run(0, self.n_bwd)
         if self.world > 1:
             dist.all_reduce(self.net.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)

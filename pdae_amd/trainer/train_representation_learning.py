@@ -13,6 +13,7 @@ import time
 import torch
 
 from .. import dataset as dataset_module
+from .. import hip as H
 from ..diffusion.gaussian_diffusion import GaussianDiffusion
 from ..model.representation_learning import decoder as decoder_module
 from ..model.representation_learning import encoder as encoder_module
@@ -79,10 +80,12 @@ class RepresentationLearningTrainer:
         oc, rc = self.config["optimizer_config"], self.config["runner_config"]
         size = self.config["train_dataset_config"]["image_size"]
         self.opt = dict(lr=float(oc["lr"]), betas=eval(oc["adam_betas"]), eps=float(oc["adam_eps"]), weight_decay=float(oc["weight_decay"]))
-        if oc.get("enable_amp", False):
-            raise NotImplementedError("fp16 autocast (enable_amp) is disabled in every shipped reference config and not built")
+        # enable_amp (torch.cuda.amp autocast + GradScaler in the reference, train_representation_learning.py:48-49,94) maps to the
+        # bf16-operand / fp32-accumulate MFMA mode of the convolutions: bf16 keeps the fp32 exponent range, so no loss scaling is
+        # needed and the "scaler" checkpoint entry stays empty.  Default (False): fp32-grade split-bf16x6 arithmetic.
+        math = H.MATH_NAMES["bf16"] if oc.get("enable_amp", False) else None
         self.fused = FusedRLStep(self.gaussian_diffusion, self.encoder, self.decoder, self.ema_encoder, self.ema_decoder, self.batch_size, size, size,
-                                 ema_decay=float(rc["ema_decay"]), ema_every=int(rc["ema_every"]), num_iterations=int(rc["num_iterations"]), **self.opt)
+                                 ema_decay=float(rc["ema_decay"]), ema_every=int(rc["ema_every"]), num_iterations=int(rc["num_iterations"]), math=math, **self.opt)
 
     # ------------------------------------------------------------------ loop (train_representation_learning.py:72-156)
     def train(self):
