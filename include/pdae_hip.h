@@ -43,21 +43,23 @@ typedef struct pdae_conv_desc {
                            * 3 = 3 exact bf16 planes, 6 products (~2^-23 per product, fp32 grade).  fp32 accumulate in all modes. */
 } pdae_conv_desc;
 
-/* Fast path of 3x3 / stride-1 / pad-1 convolutions in the bf16 modes (math >= 1): the LDS-patch kernel (conv3x3p.hip) reads
- * its weights pre-split into bf16 planes in MFMA-fragment order.  pdae_conv3x3_wprep_bytes returns the size of that copy for
- * the forward (flags = 0) or data-gradient (PDAE_WPREP_TRANSPOSED) convolution of d, or 0 when the convolution is not eligible
- * (then pass wp = NULL and the generic implicit-GEMM kernel runs).  pdae_conv3x3_wprep writes it from the fp32 weights
- * w [Cout][KH][KW][Cin]; it must be re-run whenever w changes (it is ~0.1% of the convolution's time). */
+/* Fast paths in the bf16 modes (math >= 1): 3x3 / stride-1 / pad-1 convolutions run on the LDS-patch kernel (conv3x3p.hip) and 1x1
+ * convolutions on the register-direct kernel (conv1x1.hip).  Both read their weights pre-split into bf16 planes in MFMA-fragment
+ * order.  pdae_conv_wprep_bytes returns the size of that copy (+ split-K scratch) for the forward (flags = 0) or data-gradient
+ * (PDAE_WPREP_TRANSPOSED) convolution of d, or 0 when the convolution is not eligible (then pass wp = NULL and the generic
+ * implicit-GEMM kernel runs).  pdae_conv_wprep writes it from the fp32 weights w [Cout][KH][KW][Cin]; it must be re-run whenever w
+ * changes (it is ~1% of the convolution's time). */
 #define PDAE_WPREP_TRANSPOSED 1   /* weights for the data gradient */
 #define PDAE_WPREP_FORCE 2        /* _bytes: shape eligibility only, ignore the "enough tiles to fill 256 CUs" heuristic */
-size_t pdae_conv3x3_wprep_bytes(const pdae_conv_desc* d, int flags);
-int pdae_conv3x3_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream);
+size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags);
+int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream);
 /* y[N,Ho,Wo,Cout] = conv(x) + bias (+ res).  res_mode: 0 none, 1 res[N,Ho,Wo,Cout], 2 res stored at half resolution
- * (the x_upd(x) skip of an up-ResBlock, module.py:279-284,297).  tile: 0 = auto, 64 or 128.  wp: NULL or pdae_conv3x3_wprep(d, w, 0). */
+ * (the x_upd(x) skip of an up-ResBlock, module.py:279-284,297).  tile: 0 = auto, 64 or 128.  wp: NULL or pdae_conv_wprep(d, w, 0). */
 int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
                     const float* res, int res_mode, float* y, int tile, pdae_stream_t stream);
 /* dx[N,Hl,Wl,ci_cnt] (+)= dL/d(conv input channels ci_off..ci_off+ci_cnt) on the LOGICAL input grid (Hl = 2*Hi when up).
- * wp_t: NULL or pdae_conv3x3_wprep(d, w, 1): the data gradient then runs as a forward patch convolution of dy. */
+ * wp_t: NULL or pdae_conv_wprep(d, w, PDAE_WPREP_TRANSPOSED): the data gradient then runs as a forward convolution of dy (3x3: the
+ * whole channel range only; 1x1: any 32-aligned ci_off). */
 int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
                       int accumulate, int tile, pdae_stream_t stream);
 /* dw[Cout][KH][KW][Cin] (+)= sum over pixels; split-K over pixels through the workspace, reduced in fixed order. */
@@ -133,7 +135,7 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV3X3_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD
 };
 typedef struct pdae_op {
   int32_t kind;

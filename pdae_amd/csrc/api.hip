@@ -41,28 +41,46 @@ static void fwd_geom(ConvGeom& g, const pdae_conv_desc* d, const float* x0, cons
   g.Ho = d->Ho; g.Wo = d->Wo; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.up = d->up; g.dil = 0;
 }
 
-// patch-kernel eligibility of the forward (transposed = 0) / data-gradient (transposed = 1) convolution of d
-static bool patch_ok(const pdae_conv_desc* d, int transposed, bool fill) {
-  if (!transposed) return conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout, fill);
-  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
-  return conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, 0, d->Cout, Hl, Wl, d->N, d->C0 + d->C1, fill);
+// fast-path kind of the forward (transposed = 0) / data-gradient (transposed = 1) convolution of d:
+//   3 = LDS-patch 3x3 kernel (conv3x3p.hip), 1 = register-direct 1x1 kernel (conv1x1.hip), 0 = generic implicit GEMM only
+static int fast_kind(const pdae_conv_desc* d, int transposed, bool fill) {
+  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
+  if (!transposed) {
+    if (conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout, fill)) return 3;
+    if (conv1x1_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->up, d->C0, d->C1, d->Cout)) return 1;
+    return 0;
+  }
+  if (conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, 0, d->Cout, Hl, Wl, d->N, Cin, fill)) return 3;
+  if (conv1x1_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->up, d->Cout, 0, Cin)) return 1;
+  return 0;
 }
 
-extern "C" size_t pdae_conv3x3_wprep_bytes(const pdae_conv_desc* d, int flags) {
+extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
-  if (!d || check_desc(d) || !patch_ok(d, transposed, !(flags & PDAE_WPREP_FORCE))) return 0;
-  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
-  return transposed ? conv3x3p_wprep_bytes(d->math, d->C0 + d->C1, d->Cout, Hl, Wl, d->N)
-                    : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
+  if (!d || check_desc(d)) return 0;
+  const int kind = fast_kind(d, transposed, !(flags & PDAE_WPREP_FORCE));
+  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
+  if (kind == 3)
+    return transposed ? conv3x3p_wprep_bytes(d->math, Cin, d->Cout, Hl, Wl, d->N) : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
+  if (kind == 1) {
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    return transposed ? conv1x1_wprep_bytes(d->math, Cin, d->Cout, M) : conv1x1_wprep_bytes(d->math, d->Cout, Cin, M);
+  }
+  return 0;
 }
 
-extern "C" int pdae_conv3x3_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream) {
+extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream) {
   if (int e = check_desc(d)) return e;
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
-  PDAE_CHECK_ARG(w && wp, "conv3x3_wprep: null pointer");
-  PDAE_CHECK_ARG(patch_ok(d, transposed, false), "conv3x3_wprep: convolution shape not eligible for the patch kernel");
-  if (transposed) return conv3x3p_wprep(d->math, w, d->C0 + d->C1, d->Cout, 1, (unsigned short*)wp, S(stream));
-  return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream));
+  PDAE_CHECK_ARG(w && wp, "conv_wprep: null pointer");
+  const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
+  PDAE_CHECK_ARG(kind != 0, "conv_wprep: convolution shape not eligible for a prepared-weight kernel");
+  if (kind == 3) {
+    if (transposed) return conv3x3p_wprep(d->math, w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
+    return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream));
+  }
+  if (transposed) return conv1x1_wprep(d->math, w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
+  return conv1x1_wprep(d->math, w, d->Cout, Cin, 0, (unsigned short*)wp, S(stream));
 }
 
 extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
@@ -71,10 +89,14 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd: res_mode 2 needs even output");
-  PDAE_CHECK_ARG(!wp || (tile == 0 && patch_ok(d, 0, false)), "conv2d_fwd: wp given but the convolution is not eligible for the patch kernel");
-  if (wp)
+  const int kind = wp ? fast_kind(d, 0, false) : 0;
+  PDAE_CHECK_ARG(!wp || (tile == 0 && kind != 0), "conv2d_fwd: wp given but the convolution is not eligible for a prepared-weight kernel");
+  if (kind == 3)
     return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
                            res_mode ? res : nullptr, res_mode, 0, S(stream));
+  if (kind == 1)
+    return conv1x1_launch(d->math, x0, d->C0, x1, d->C1, (long long)d->N * d->Ho * d->Wo, (const unsigned short*)wp, d->Cout, 0, d->Cout, y, bias,
+                          res_mode ? res : nullptr, res_mode, d->Ho, d->Wo, 0, S(stream));
   GemmParams P;
   memset(&P, 0, sizeof(P));
   fwd_geom(P.a.g, d, x0, x1);
@@ -93,11 +115,15 @@ extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const
   PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
   PDAE_CHECK_ARG(d->stride == 1 || (Hl == 2 * d->Ho && Wl == 2 * d->Wo), "conv2d_dgrad: stride 2 needs even input");
-  PDAE_CHECK_ARG(!wp_t || (tile == 0 && ci_off == 0 && ci_cnt == Cin && patch_ok(d, 1, false)),
-                 "conv2d_dgrad: wp_t given but the convolution is not eligible for the patch kernel");
-  if (wp_t)
+  const int kind = wp_t ? fast_kind(d, 1, false) : 0;
+  PDAE_CHECK_ARG(!wp_t || (tile == 0 && ((kind == 3 && ci_off == 0 && ci_cnt == Cin) || (kind == 1 && (ci_off & 31) == 0 && (ci_cnt & 3) == 0))),
+                 "conv2d_dgrad: wp_t given but the convolution / channel range is not eligible for a prepared-weight kernel");
+  if (kind == 3)
     return conv3x3p_launch(d->math, dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, (const unsigned short*)wp_t, Cin, dx, nullptr, nullptr, 0,
                            accumulate, S(stream));
+  if (kind == 1)
+    return conv1x1_launch(d->math, dy, d->Cout, nullptr, 0, (long long)d->N * d->Ho * d->Wo, (const unsigned short*)wp_t, Cin, ci_off, ci_cnt, dx,
+                          nullptr, nullptr, 0, d->Ho, d->Wo, accumulate, S(stream));
   GemmParams P;
   memset(&P, 0, sizeof(P));
   ConvGeom& g = P.a.g;
@@ -323,7 +349,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_SOFTMAX: return pdae_softmax(FM(0), i[0], (int)i[1], st);
     case PDAE_OP_SOFTMAX_BWD: return pdae_softmax_bwd(F(0), FM(1), i[0], (int)i[1], st);
     case PDAE_OP_COLSUM: return pdae_colsum(F(0), i[0], (int)i[1], FM(1), (int)i[2], p[2], st);
-    case PDAE_OP_CONV3X3_WPREP: desc_from(i, d); return pdae_conv3x3_wprep(&d, F(0), (int)i[14], p[1], st);
+    case PDAE_OP_CONV_WPREP: desc_from(i, d); return pdae_conv_wprep(&d, F(0), (int)i[14], p[1], st);
     case PDAE_OP_MEMSET: {
       hipError_t e = hipMemsetAsync(p[0], 0, (size_t)i[0], S(st));
       if (e != hipSuccess) { pdae_set_error("memset: %s", hipGetErrorString(e)); return (int)e; }

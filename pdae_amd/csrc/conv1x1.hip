@@ -1,0 +1,316 @@
+// 1x1 convolution (forward and data gradient) for gfx950 on the bf16 MFMA pipe with split fp32 operands.
+//
+// In NHWC a 1x1 convolution is the GEMM  Y[M = pixels][Nout] = X[M][C] * W[Nout][C]^T.  Block = 256 threads (2x2 waves),
+// tile = 128 pixels x 128 output channels.  Per stage of 64 input channels the 128 x 64 activation tile is loaded with fully
+// coalesced float4 loads (16 lanes per pixel row), split into bf16 planes and staged in LDS (144-byte rows: every
+// ds_read_b128 of a 16-lane group is conflict-free); the next stage's loads are in flight under the MFMAs.  B fragments come
+// straight from L2 out of the fragment-ordered prepared weights (conv1x1_wprep, same idea as conv3x3p_wprep), so the only
+// barriers are the two per stage that hand the activation tile over.  The torch.cat of the decoder skip (unet.py:200) is two
+// base pointers.  (A row-per-lane "register-direct" A load was measured first: 32 different cache lines per load
+// instruction make it TA-bound, 45 TFLOP/s; the LDS transpose costs less.)
+//
+// Replaces F.conv2d(k=1) / conv1d(k=1) of model/module.py:276,412,420 (ResBlock skip, attention qkv / proj) and their dX.
+#include "common.h"
+#include "igemm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float q_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+__device__ __forceinline__ unsigned q_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
+__device__ __forceinline__ unsigned q_rn(float a, float b) {
+  unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
+  return (unsigned)x | ((unsigned)y << 16);
+}
+template <int NS> __device__ __forceinline__ void q_split2(float e0, float e1, unsigned (&w)[NS]) {
+  if constexpr (NS == 1) { w[0] = q_rn(e0, e1); }
+  else {
+    float h0 = q_trunc(e0), h1 = q_trunc(e1);
+    float r0 = e0 - h0, r1 = e1 - h1;
+    w[0] = q_hi16(h0, h1);
+    if constexpr (NS == 2) { w[1] = q_rn(r0, r1); }
+    else {
+      float m0 = q_trunc(r0), m1 = q_trunc(r1);
+      w[1] = q_hi16(m0, m1);
+      w[2] = q_hi16(r0 - m0, r1 - m1);
+    }
+  }
+}
+
+struct PointParams {
+  const float* x0; const float* x1; int C0, C1;     // A = [x0 | x1] rows of M pixels
+  long long M; int C;                                // C = C0 + C1 (multiple of 16)
+  const unsigned short* wp; int NT;                  // prepared weights [NS][C/16][NT][64][8], NT 32-channel tiles in it
+  int nt_off, Nout;                                  // output channels = prepared rows nt_off*32 .. + Nout
+  float* y; const float* bias; const float* res; int accumulate;
+  int res_mode, H, W;                                // res_mode 2: residual stored at half resolution (needs the image geometry)
+  int tiles_m, tiles_n, splits, sps;                 // split-K: `splits` ranges of `sps` 16-channel steps
+  float* slab;
+};
+
+// pixel row of the half-resolution residual (x_upd(x) skip of an up-ResBlock, module.py:279-284,297)
+__device__ __forceinline__ long long half_row(long long row, int H, int W) {
+  const int ox = (int)(row % W); const long long t2 = row / W; const int oy = (int)(t2 % H); const long long im = t2 / H;
+  return (im * (H >> 1) + (oy >> 1)) * (W >> 1) + (ox >> 1);
+}
+
+#define QLDH 72                                          // bf16 per LDS row: 64 channels + 8 pad = 144 bytes
+template <int NS>
+__global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
+  __shared__ __attribute__((aligned(16))) unsigned short sA[NS * 128 * QLDH];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+  const int tn_i = tid % P.tiles_n; tid /= P.tiles_n;
+  const int tm_i = tid % P.tiles_m; const int sp = tid / P.tiles_m;
+  const long long m0 = (long long)tm_i * 128;
+  const int n0 = tn_i * 128 + wn * 64;
+  const int nsteps = P.C >> 4;
+  const int s_begin = sp * P.sps, s_end = min(nsteps, s_begin + P.sps);      // 16-channel steps; sps is a multiple of 2
+
+  // ---- A staging: thread -> (pixel row = idx >> 4, channel quad = idx & 15), 8 float4 per thread and stage
+  float4 apre[8];
+  auto a_gload = [&](int s0) {                     // stage starting at step s0 (4 steps = 64 channels, fewer at the tail)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
+      const int c = (s0 << 4) + qd * 4;
+      const long long p = m0 + row;
+      apre[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < P.M && c < (s_end << 4)) {
+        const bool first = c < P.C0;
+        apre[l] = first ? *reinterpret_cast<const float4*>(P.x0 + p * P.C0 + c) : *reinterpret_cast<const float4*>(P.x1 + p * P.C1 + (c - P.C0));
+      }
+    }
+  };
+  auto a_lstore = [&]() {
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
+      unsigned a[NS], b[NS];
+      q_split2<NS>(apre[l].x, apre[l].y, a);
+      q_split2<NS>(apre[l].z, apre[l].w, b);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sA[(p * 128 + row) * QLDH + qd * 4]) = make_uint2(a[p], b[p]);
+    }
+  };
+
+  const int nt0 = P.nt_off + (n0 >> 5);
+  const int nt_end = P.nt_off + ((P.Nout + 31) >> 5);
+  const size_t plane_stride = (size_t)nsteps * P.NT * 512;
+  auto ldb = [&](uint4 (&bq)[2][NS], int s) {
+    const unsigned short* base = P.wp + ((size_t)s * P.NT + nt0) * 512 + lane * 8;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int p = 0; p < NS; ++p)
+        bq[b][p] = (nt0 + b < nt_end) ? *reinterpret_cast<const uint4*>(base + p * plane_stride + b * 512) : make_uint4(0u, 0u, 0u, 0u);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto step = [&](int s, const uint4 (&bq)[2][NS], uint4 (&bn)[2][NS]) {
+    if (s + 1 < s_end) ldb(bn, s + 1);
+    const int ks = (s - s_begin) & 3;               // step inside the staged 64 channels
+    bf16x8 af[2][NS];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int p = 0; p < NS; ++p)
+        af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[(p * 128 + wm * 64 + a * 32 + li) * QLDH + ks * 16 + h * 8]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[b][P_])
+        if constexpr (NS == 3) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], PDAE_B(1), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(2), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], PDAE_B(0), acc[a][b], 0, 0, 0);
+        }
+        if constexpr (NS >= 2) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(1), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], PDAE_B(0), acc[a][b], 0, 0, 0);
+        }
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(0), acc[a][b], 0, 0, 0);
+#undef PDAE_B
+      }
+    // tile hand-over after every 4th step
+    if (ks == 3 && s + 1 < s_end) {
+      __syncthreads();
+      a_lstore();
+      __syncthreads();
+      if (s + 5 < s_end) a_gload(s + 5);
+    }
+  };
+
+  uint4 q0[2][NS], q1[2][NS];
+  if (s_begin < s_end) {
+    a_gload(s_begin);
+    ldb(q0, s_begin);
+    a_lstore();
+    __syncthreads();
+    if (s_begin + 4 < s_end) a_gload(s_begin + 4);
+    for (int s = s_begin; s < s_end; s += 2) {     // an even number of steps per split (C % 32 == 0)
+      step(s, q0, q1);
+      step(s + 1, q1, q0);
+    }
+  }
+  const long long mw = m0 + wm * 64;
+
+  // ---- epilogue
+  float bcol[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) { const int col = n0 + b * 32 + li; bcol[b] = (P.bias && col < P.Nout) ? P.bias[col] : 0.f; }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const long long row = mw + a * 32 + i;
+      if (row >= P.M) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int col = n0 + b * 32 + li;
+        if (col >= P.Nout) continue;
+        float val = acc[a][b][r];
+        if (P.splits > 1) { P.slab[((long long)sp * P.M + row) * P.Nout + col] = val; continue; }
+        val += bcol[b];
+        if (P.res) val += P.res[(P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + col];
+        float* dst = P.y + row * P.Nout + col;
+        if (P.accumulate) val += *dst;
+        *dst = val;
+      }
+    }
+  }
+}
+
+// y = sum of the split slabs (fixed order) + bias + residual (+ y)
+__global__ void __launch_bounds__(256) conv1x1_reduce_kernel(const PointParams P) {
+  const int n4 = P.Nout >> 2;
+  const long long total = P.M * n4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / n4; const int col = (int)(i - row * n4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(P.slab + row * P.Nout + col);
+    for (int k = 1; k < P.splits; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(P.slab + ((long long)k * P.M + row) * P.Nout + col);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (P.bias) { const float4 u = *reinterpret_cast<const float4*>(P.bias + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    if (P.res) { const float4 u = *reinterpret_cast<const float4*>(P.res + (P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    float4* dst = reinterpret_cast<float4*>(P.y + row * P.Nout + col);
+    if (P.accumulate) { const float4 u = *dst; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    *dst = v;
+  }
+}
+
+// weight preparation: GEMM weight w'[n][c] -> [NS][C/16][NT][64][8] bf16 planes in B-fragment order.
+//   transposed = 0: w' = w [Nout][C];   transposed = 1 (data gradient): w'[n][c] = w[c][n], w stored [C][Nout]
+template <int NS>
+__global__ void __launch_bounds__(256) conv1x1_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed,
+                                                            unsigned short* __restrict__ wp) {
+  const size_t nslot = (size_t)(C >> 4) * NT * 64;
+  const size_t plane_stride = nslot * 8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63); size_t r = i >> 6;
+    const int nt = (int)(r % NT); const int s = (int)(r / NT);
+    const int n = nt * 32 + (lane & 31), c = (s << 4) + (lane >> 5) * 8;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0.f;
+    if (n < Nout) {
+      if (transposed) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = w[(size_t)(c + j) * Nout + n];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = w[(size_t)n * C + c + j];
+      }
+    }
+    unsigned a[NS], b[NS], cc[NS], d[NS];
+    q_split2<NS>(e[0], e[1], a); q_split2<NS>(e[2], e[3], b); q_split2<NS>(e[4], e[5], cc); q_split2<NS>(e[6], e[7], d);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct PointPlan { int tiles_m, tiles_n, splits, sps; long long blocks; };
+static PointPlan point_plan(long long M, int C, int Nout) {
+  PointPlan q;
+  q.tiles_m = (int)((M + 127) / 128); q.tiles_n = (Nout + 127) / 128;
+  const long long base = (long long)q.tiles_m * q.tiles_n;
+  const int nsteps = C >> 4;
+  int want = base >= 384 ? 1 : (int)((512 + base - 1) / base);
+  if (want > nsteps / 2) want = nsteps / 2;             // at least 2 steps (32 channels) per split
+  if (want < 1) want = 1;
+  if (want > 16) want = 16;
+  q.sps = (nsteps + want - 1) / want;
+  q.sps = (q.sps + 3) & ~3;                              // whole 64-channel stages per split
+  q.splits = (nsteps + q.sps - 1) / q.sps;
+  q.blocks = base * q.splits;
+  return q;
+}
+
+// eligibility: 1x1, stride 1, no pad / upsample, both sources multiples of 32 channels, Nout % 4
+bool conv1x1_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, int C1, int Nout) {
+  if (math < 1 || KH != 1 || KW != 1 || stride != 1 || pad != 0 || up) return false;
+  return (C0 & 31) == 0 && (C1 & 31) == 0 && (Nout & 3) == 0 && Nout >= 32;
+}
+
+static size_t point_prep_bytes(int math, int Nrows, int C) {
+  const int NS = math < 1 ? 1 : (math > 3 ? 3 : math);
+  const size_t b = (size_t)NS * (C >> 4) * ((Nrows + 31) / 32) * 512 * sizeof(unsigned short);
+  return (b + 255) & ~(size_t)255;
+}
+
+// prepared weights of all Nrows GEMM-N rows + split-K slabs sized for ANY launch on a 32-aligned sub-range of the rows
+// (the data gradient of one concat source computes only that source's rows)
+size_t conv1x1_wprep_bytes(int math, int Nrows, int C, long long M) {
+  size_t slab = 0;
+  for (int nsub = 32; nsub <= ((Nrows + 31) & ~31); nsub += 32) {
+    const int n = nsub < Nrows ? nsub : Nrows;
+    const PointPlan q = point_plan(M, C, n);
+    if (q.splits > 1) { const size_t b = (size_t)q.splits * M * n * sizeof(float); if (b > slab) slab = b; }
+  }
+  return point_prep_bytes(math, Nrows, C) + slab;
+}
+
+int conv1x1_wprep(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, hipStream_t s) {
+  const int NT = (Nrows + 31) / 32;
+  const size_t nslot = (size_t)(C >> 4) * NT * 64;
+  int grid = (int)((nslot + 255) / 256); if (grid > 4096) grid = 4096;
+  if (math == 1) hipLaunchKernelGGL(conv1x1_wprep_kernel<1>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wp);
+  else if (math == 2) hipLaunchKernelGGL(conv1x1_wprep_kernel<2>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wp);
+  else hipLaunchKernelGGL(conv1x1_wprep_kernel<3>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wp);
+  return pdae_launch_status("conv1x1_wprep");
+}
+
+int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const unsigned short* wp, int Nrows, int row_off,
+                   int Nout, float* y, const float* bias, const float* res, int res_mode, int H, int W, int accumulate, hipStream_t s) {
+  PointParams P;
+  P.res_mode = res_mode; P.H = H; P.W = W;
+  P.x0 = x0; P.x1 = x1; P.C0 = C0; P.C1 = C1; P.M = M; P.C = C0 + C1; P.wp = wp; P.NT = (Nrows + 31) / 32;
+  P.nt_off = row_off >> 5; P.Nout = Nout; P.y = y; P.bias = bias; P.res = res; P.accumulate = accumulate;
+  const PointPlan q = point_plan(M, P.C, Nout);
+  P.tiles_m = q.tiles_m; P.tiles_n = q.tiles_n; P.splits = q.splits; P.sps = q.sps;
+  P.slab = (float*)((char*)wp + point_prep_bytes(math, Nrows, P.C));
+  dim3 grid(q.tiles_m * q.tiles_n * q.splits);
+#define PDAE_C1(NS_)                                                                     \
+  hipLaunchKernelGGL((conv1x1_kernel<NS_>), grid, dim3(256), 0, s, P);                    \
+  if (P.splits > 1) {                                                                    \
+    long long nb = (M * (Nout >> 2) + 255) / 256; if (nb > 4096) nb = 4096;              \
+    hipLaunchKernelGGL(conv1x1_reduce_kernel, dim3((int)nb), dim3(256), 0, s, P);        \
+  }
+  if (math == 1) { PDAE_C1(1) } else if (math == 2) { PDAE_C1(2) } else { PDAE_C1(3) }
+#undef PDAE_C1
+  return pdae_launch_status("conv1x1");
+}

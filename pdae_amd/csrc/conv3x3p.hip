@@ -31,6 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define PBN 128
 #define PSLOT(row, slot) ((row) * PLDH + ((slot) << 3))       // bf16 offset of 16-byte k-slot `slot` of `row`
 #define PPLANE(rows) ((rows) * PLDH)
+#define EPW 68                  // floats per row of the epilogue transpose tile (64 + 4 pad)
 
 __device__ __forceinline__ float p_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 __device__ __forceinline__ unsigned p_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
@@ -209,39 +210,49 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
     step(s + 1, q1, q0);
   }
 
-  // ---- epilogue
+  // ---- epilogue: every wave transposes its 32-pixel x 64-channel accumulator groups through a private LDS region (the patch is
+  // dead by now) so that global traffic is float4 per lane, 16 lanes per pixel row: 256-byte contiguous runs, 4x fewer store
+  // instructions than storing the MFMA layout directly (the dword-per-lane form is store-issue bound)
   const long long Mtot = (long long)P.N * P.H * P.W;
+  __syncthreads();                                        // all waves are done reading the patch
+  float* tw = reinterpret_cast<float*>(smem) + wv * (32 * EPW);
+  const int er = lane >> 4, ec = (lane & 15) * 4;         // read side: row within a group of 4, first of 4 channels
+  const int colb = n0 + wn * 64 + ec;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (P.bias && P.splits == 1) {
+    if (colb + 3 < P.Nout) bias4 = *reinterpret_cast<const float4*>(P.bias + colb);
+    else { float t4[4] = {0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (colb + j < P.Nout) t4[j] = P.bias[colb + j];
+           bias4 = make_float4(t4[0], t4[1], t4[2], t4[3]); }
+  }
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * h, g = wm * 2 + a, bx = g & 3;
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + b * 32 + li] = acc[a][b][r];
+    const int g = wm * 2 + a, bx = g & 3;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = it * 4 + er;
+      float4 v = *reinterpret_cast<const float4*>(&tw[i * EPW + ec]);
       const int oy = y0 + (g >> 2) * 8 + (i >> 2);
       const int ox = W8 ? (bx & 1) * 4 + (i & 3) : x0 + bx * 4 + (i & 3);
       const int im = W8 ? img + (bx >> 1) : img;
-      if (oy >= P.H || ox >= P.W || im >= P.N) continue;
+      if (oy >= P.H || ox >= P.W || im >= P.N || colb >= P.Nout) continue;
       const long long row = ((long long)im * P.H + oy) * P.W + ox;
-      if (P.splits > 1) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int col = n0 + (wn * 2 + b) * 32 + li;
-          if (col < P.Nout) P.slab[((long long)sp * Mtot + row) * P.Nout + col] = acc[a][b][r];
-        }
-        continue;
+      const bool full = colb + 3 < P.Nout;                // Nout % 4 == 0 => always true when colb < Nout
+      (void)full;
+      if (P.splits > 1) { *reinterpret_cast<float4*>(P.slab + ((long long)sp * Mtot + row) * P.Nout + colb) = v; continue; }
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      if (P.res_mode) {
+        long long rrow = row;
+        if (P.res_mode == 2) rrow = ((long long)im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
+        const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + colb);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
       }
-      long long rrow = row;
-      if (P.res_mode == 2) rrow = ((long long)im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int col = n0 + (wn * 2 + b) * 32 + li;
-        if (col >= P.Nout) continue;
-        float val = acc[a][b][r];
-        if (P.bias) val += P.bias[col];
-        if (P.res_mode) val += P.res[rrow * P.Nout + col];
-        float* dst = P.y + row * P.Nout + col;
-        if (P.accumulate) val += *dst;
-        *dst = val;
-      }
+      float4* dst = reinterpret_cast<float4*>(P.y + row * P.Nout + colb);
+      if (P.accumulate) { const float4 u = *dst; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+      *dst = v;
     }
   }
 }
@@ -274,7 +285,9 @@ __global__ void __launch_bounds__(256) conv3x3p_reduce_kernel(const PatchParams 
 
 template <int NS, int PTH, bool W8> static int launch_ns(const PatchParams& P, hipStream_t s) {
   constexpr int NPIX = (PTH + 2) * PPW;
-  const size_t smem = (size_t)(NS * PPLANE(NPIX)) * sizeof(unsigned short);
+  size_t smem = (size_t)(NS * PPLANE(NPIX)) * sizeof(unsigned short);
+  const size_t epi = (size_t)(PTH / 2) * 32 * EPW * sizeof(float);        // one 32 x 68 fp32 tile per wave
+  if (smem < epi) smem = epi;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS, PTH, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -61,3 +61,11 @@ bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, i
 size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout);
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
                     int accumulate, float* ws, size_t ws_bytes, hipStream_t s);
+
+// conv1x1.hip: register-direct 1x1 convolution (forward / data gradient) on prepared weights
+bool conv1x1_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, int C1, int Nout);
+size_t conv1x1_wprep_bytes(int math, int Nrows, int C, long long M);
+int conv1x1_wprep(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, hipStream_t s);
+int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const unsigned short* wp, int Nrows, int row_off,
+                   int Nout, float* y, const float* bias, const float* res, int res_mode, int H, int W, int accumulate, hipStream_t s);
+

@@ -140,7 +140,7 @@ class Builder:
         if nbytes == 0:
             return None
         wp = self.p.buf((nbytes + 3) // 4)
-        self.p.emit(H.op_conv3x3_wprep(c, w, transposed, wp))
+        self.p.emit(H.op_conv_wprep(c, w, transposed, wp))
         return wp
 
     def conv_bwd_params(self, cx, dy):
@@ -162,7 +162,8 @@ class Builder:
         ci_cnt = c.Cin if ci_cnt is None else ci_cnt
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
-        wp_t = self._wprep(c, w, 1) if (ci_off == 0 and ci_cnt == c.Cin) else None
+        whole = ci_off == 0 and ci_cnt == c.Cin
+        wp_t = self._wprep(c, w, 1) if (whole or (c.KH == 1 and ci_off % 32 == 0 and ci_cnt % 4 == 0)) else None
         self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate, wp_t=wp_t))
         if wp_t is not None:
             self.p.free(wp_t)

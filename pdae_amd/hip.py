@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
- OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV3X3_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD) = range(1, 30)
+ OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD) = range(1, 30)
 
 
 class PdaeOp(ctypes.Structure):
@@ -55,8 +55,8 @@ def lib():
         L.pdae_run_ops.restype = ctypes.c_int
         L.pdae_conv2d_wgrad_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
         L.pdae_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
-        L.pdae_conv3x3_wprep_bytes.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int]
-        L.pdae_conv3x3_wprep_bytes.restype = ctypes.c_size_t
+        L.pdae_conv_wprep_bytes.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int]
+        L.pdae_conv_wprep_bytes.restype = ctypes.c_size_t
         L.pdae_gn_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.pdae_gn_workspace_bytes.restype = ctypes.c_size_t
         L.pdae_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
@@ -67,7 +67,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv3x3_wprep_bytes", "pdae_conv3x3_wprep", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_adam_ema", "pdae_run_ops"]
@@ -149,7 +149,7 @@ class Conv:
     def wprep_bytes(self, transposed=0, force=False):
         """Size of the prepared-weight copy for the patch kernel; 0 = not eligible (generic kernel runs)."""
         d = self.cdesc()
-        return int(lib().pdae_conv3x3_wprep_bytes(ctypes.byref(d), int(transposed) | (2 if force else 0)))
+        return int(lib().pdae_conv_wprep_bytes(ctypes.byref(d), int(transposed) | (2 if force else 0)))
 
     def wgrad_ws_bytes(self):
         d = self.cdesc()
@@ -164,9 +164,9 @@ def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0, wp_
     return make_op(OP_CONV_DGRAD, [dy, w, dx, wp_t], c.fields() + [ci_off, c.Cin if ci_cnt is None else ci_cnt, accumulate, tile])
 
 
-def op_conv3x3_wprep(c, w, transposed, wp):
-    """Pre-split w into the MFMA-fragment-ordered bf16 planes the patch kernel reads (pdae_conv3x3_wprep)."""
-    return make_op(OP_CONV3X3_WPREP, [w, wp], c.fields() + [transposed])
+def op_conv_wprep(c, w, transposed, wp):
+    """Pre-split w into the MFMA-fragment-ordered bf16 planes the patch kernel reads (pdae_conv_wprep)."""
+    return make_op(OP_CONV_WPREP, [w, wp], c.fields() + [transposed])
 
 
 def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0):

@@ -408,17 +408,18 @@ def test_conv_bf16_split_modes(H, case, math_mode):
     # the fast path: LDS-patch kernel on fragment-ordered pre-split weights (forced: these shapes are too small to be chosen by the
     # fill heuristic), forward and -- on the transposed, tap-flipped weights -- data gradient
     nb = c.wprep_bytes(0, force=True)
-    assert (nb > 0) == (k == 3 and stride == 1 and C1 == 0 and C0 % 32 == 0 and c.Ho % 8 == 0 and (c.Wo % 16 == 0 or c.Wo == 8))
+    assert (nb > 0) == ((k == 3 and stride == 1 and C1 == 0 and C0 % 32 == 0 and c.Ho % 8 == 0 and (c.Wo % 16 == 0 or c.Wo == 8)) or
+                        (k == 1 and stride == 1 and not up and C0 % 32 == 0 and C1 % 32 == 0 and Cout % 4 == 0 and Cout >= 32))
     if nb:
         wp = torch.empty(nb // 4, device="cuda")
-        H.run(H.op_conv3x3_wprep(c, wd, 0, wp))
+        H.run(H.op_conv_wprep(c, wd, 0, wp))
         y2 = torch.empty_like(y)
         H.run(H.op_conv_fwd(c, x0, x1, wd, bd, y2, wp=wp))
         assert rel_err(nchw(y2), ref_conv(x, w, b, stride, k // 2, up)) < tol
     nb = c.wprep_bytes(1, force=True)
     if nb:
         wp_t = torch.empty(nb // 4, device="cuda")
-        H.run(H.op_conv3x3_wprep(c, wd, 1, wp_t))
+        H.run(H.op_conv_wprep(c, wd, 1, wp_t))
         dx2 = torch.empty(N, c.Hl, c.Wl, Cin, device="cuda")
         H.run(H.op_conv_dgrad(c, dyd, wd, dx2, wp_t=wp_t))
         assert rel_err(nchw(dx2), xl.grad) < tol
@@ -426,3 +427,52 @@ def test_conv_bf16_split_modes(H, case, math_mode):
     dw = torch.empty_like(wd)
     H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb))
     assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2 * tol
+
+
+@pytest.mark.parametrize("math_mode", [1, 3])
+@pytest.mark.parametrize("case", [(3, 16, 16, 128, 64, 96), (1, 8, 8, 256, 0, 64), (2, 12, 20, 64, 32, 36), (4, 32, 32, 64, 64, 160), (2, 16, 16, 96, 0, 64)])
+def test_conv1x1_kernel(H, case, math_mode):
+    """conv1x1.hip: dual-source 1x1 conv with bias / residual (full and half resolution), split-K on small layers, and the data
+    gradient on the whole channel range and on one 32-aligned concat source, against fp64."""
+    N, Hh, W, C0, C1, Cout = case
+    Cin = C0 + C1
+    tol = MATH_TOL[math_mode]
+    x = rn(1, N, Cin, Hh, W)
+    w = rn(2, Cout, Cin, 1, 1, scale=1.0 / math.sqrt(Cin))
+    b = rn(3, Cout, scale=0.1)
+    res = rn(4, N, Cout, Hh, W)
+    res2 = rn(6, N, Cout, Hh // 2, W // 2)
+    c = H.Conv(N, Hh, W, C0, C1, Cout, k=1, math=math_mode)
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous()
+    x1 = xh[..., C0:].contiguous() if C1 else None
+    wd, bd = nhwc(w).cuda(), b.cuda()
+    nb = c.wprep_bytes(0)
+    assert nb > 0
+    wp = torch.empty(nb // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 0, wp))
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    y = torch.empty(N, Hh, W, Cout, device="cuda")
+    H.run(H.op_conv_fwd(c, x0, x1, wd, bd, y, wp=wp))
+    assert rel_err(nchw(y), ref) < tol
+    H.run(H.op_conv_fwd(c, x0, x1, wd, bd, y, res=nhwc(res).cuda(), res_mode=1, wp=wp))
+    assert rel_err(nchw(y), ref + res.double()) < tol
+    H.run(H.op_conv_fwd(c, x0, x1, wd, None, y, res=nhwc(res2).cuda(), res_mode=2, wp=wp))
+    assert rel_err(nchw(y), ref - b.double().view(1, -1, 1, 1) + F.interpolate(res2.double(), scale_factor=2, mode="nearest")) < tol
+    # data gradient
+    dy = rn(5, N, Cout, Hh, W)
+    dxr = F.conv_transpose2d(dy.double(), w.double())
+    dyd = nhwc(dy).cuda()
+    nbt = c.wprep_bytes(1)
+    assert (nbt > 0) == (Cout % 32 == 0)            # dy is the A operand of the data gradient: 32-channel chunks
+    if not nbt:
+        return
+    wp_t = torch.empty(nbt // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 1, wp_t))
+    dx = torch.empty(N, Hh, W, Cin, device="cuda")
+    H.run(H.op_conv_dgrad(c, dyd, wd, dx, wp_t=wp_t))
+    assert rel_err(nchw(dx), dxr) < tol
+    if C1 and C0 % 32 == 0:
+        dx1 = torch.full((N, Hh, W, C1), 1.0, device="cuda")
+        H.run(H.op_conv_dgrad(c, dyd, wd, dx1, ci_off=C0, ci_cnt=C1, accumulate=1, wp_t=wp_t))
+        assert rel_err(nchw(dx1), dxr[:, C0:] + 1.0) < tol

@@ -35,9 +35,9 @@ for (N, S, C0, C1, Cout, k) in SHAPES:
         wsb = c.wgrad_ws_bytes(); wsp = torch.empty(wsb // 4 + 16, device="cuda")
         wp = wp_t = None
         if c.wprep_bytes(0):
-            wp = torch.empty(c.wprep_bytes(0) // 4, device="cuda"); H.run(H.op_conv3x3_wprep(c, w, 0, wp))
+            wp = torch.empty(c.wprep_bytes(0) // 4, device="cuda"); H.run(H.op_conv_wprep(c, w, 0, wp))
         if c.wprep_bytes(1):
-            wp_t = torch.empty(c.wprep_bytes(1) // 4, device="cuda"); H.run(H.op_conv3x3_wprep(c, w, 1, wp_t))
+            wp_t = torch.empty(c.wprep_bytes(1) // 4, device="cuda"); H.run(H.op_conv_wprep(c, w, 1, wp_t))
         tf = [fl / timeit(op) / 1e9 for op in (H.op_conv_fwd(c, x0, x1, w, b, y, wp=wp), H.op_conv_dgrad(c, dy, w, dx, wp_t=wp_t), H.op_conv_wgrad(c, x0, x1, dy, dw, wsp, wsb))]
         line += f"  {name}: fwd {tf[0]:6.1f} dgrad {tf[1]:6.1f} wgrad {tf[2]:6.1f} |"
     print(line, flush=True)

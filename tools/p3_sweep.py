@@ -17,7 +17,7 @@ for Cout in (128, 256):
         for m in (3, 1):
             c = H.Conv(N, S, S, C, 0, Cout, math=m)
             wp = torch.empty(c.wprep_bytes(0) // 4, device="cuda")
-            t_prep = t(H.op_conv3x3_wprep(c, w, 0, wp))
+            t_prep = t(H.op_conv_wprep(c, w, 0, wp))
             ms = t(H.op_conv_fwd(c, x, None, w, b, y, wp=wp))
             ms_nb = t(H.op_conv_fwd(c, x, None, w, None, y, wp=wp))
             print(f"Cout={Cout} Cin={C:4d} math={m}: {ms:.3f} ms (no bias {ms_nb:.3f}, prep {t_prep:.3f})  {2.0*N*S*S*Cout*9*C/ms/1e9:.1f} TF", flush=True)
