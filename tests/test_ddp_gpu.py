@@ -1,0 +1,101 @@
+"""GPU: the data-parallel training step of FusedRLStep on the real HIP kernels, world_size 2 emulated in ONE process.
+
+Two ranks cannot share one device under RCCL, so rank 1's backward is run first and its flat gradients are kept; rank 0's
+step then runs with `torch.distributed.all_reduce` replaced by a stand-in that adds rank 1's slice of the same bucket (as a
+stream-ordered device op, exactly where the RCCL all-reduce would be enqueued).  Everything else is the production path:
+forward/backward issued in segments, one all-reduce(sum) per bucket as soon as its gradients are final, 1/world folded
+into Adam.  The result must equal a single process that sees the concatenated batch (gradient of the global mean loss --
+DistributedDataParallel semantics of trainer/train_representation_learning.py:29,39).  An all-reduce issued before its
+bucket is final, a bucket missed or reduced twice, or a wrong 1/world all break the equality."""
+import copy
+
+import pytest
+import torch
+
+from tests.golden import make_fixtures_cfg as C
+
+pytestmark = pytest.mark.gpu
+CFG = dict(C.CFG_SHIFT_64, dropout=0.0)           # dropout masks are per-rank streams: switch them off for the equivalence
+
+
+def _build(batch):
+    from pdae_amd.utils import set_seed
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from pdae_amd.trainer.fused_step import FusedRLStep
+    set_seed(0)
+    dev = torch.device("cuda", 0)
+    enc = CELEBA64Encoder(device=dev, latent_dim=512)
+    dec = ShiftUNet(device=dev, latent_dim=512, **CFG)
+    with torch.no_grad():                          # zero-initialised heads would make the gradients vacuous
+        for net in (enc, dec):
+            g = torch.Generator(device="cpu").manual_seed(5)
+            for p in net.parameters():
+                if float(p.abs().max()) == 0.0:
+                    p.copy_((torch.randn(p.shape, generator=g) * 0.05).to(dev))
+    enc.train(); dec.set_train_mode()
+    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, dev)
+    st = FusedRLStep(gd, enc, dec, copy.deepcopy(enc), copy.deepcopy(dec), batch, 64, 64, bucket_mb=1)
+    return enc, dec, st
+
+
+def _data(n):
+    g = torch.Generator().manual_seed(9)
+    return (torch.rand(n, 3, 64, 64, generator=g) * 2 - 1).cuda(), torch.randint(0, 1000, (n,), generator=g).cuda(), torch.randn(n, 3, 64, 64, generator=g).cuda()
+
+
+class _Work:
+    def wait(self):
+        return True
+
+
+def test_two_rank_step_equals_single_process_on_concatenated_batch(monkeypatch):
+    from pdae_amd.trainer import fused_step as FS
+    x0, t, noise = _data(4)
+    enc0, dec0, st0 = _build(2)                    # "rank 0"
+    enc1, dec1, st1 = _build(2)                    # "rank 1": same initial weights (set_seed(0), base_trainer.py:27-28)
+    assert torch.equal(dec0.flat_train, dec1.flat_train) and len(st0.buckets) >= 3
+    st0.world = 2
+    calls = []
+
+    def fake_all_reduce(view, op=None, group=None, async_op=False):
+        for mine, other in ((dec0.flat_grad, dec1.flat_grad), (enc0.flat_grad, enc1.flat_grad)):
+            off = (view.data_ptr() - mine.data_ptr()) // 4
+            if 0 <= off and off + view.numel() <= mine.numel() and view.data_ptr() >= mine.data_ptr():
+                view += other[off:off + view.numel()]
+                calls.append((id(mine), off, view.numel()))
+                return _Work()
+        raise AssertionError("all_reduce on a tensor that is not a slice of a flat gradient buffer")
+
+    monkeypatch.setattr(FS.dist, "all_reduce", fake_all_reduce)
+    losses, grads = [], []
+    for _ in range(2):
+        # rank 1: forward + backward only (its optimizer step is irrelevant here: weights are re-synchronised below)
+        st1.load_batch(x0[2:], t[2:], noise[2:])
+        st1.plan.run(0, st1.n_bwd)
+        l1 = float(st1.loss.item())
+        l0 = float(st0.step(x0[:2], t=t[:2], noise=noise[:2]).item())
+        losses.append(0.5 * (l0 + l1))
+        grads.append((0.5 * dec0.flat_grad.double(), 0.5 * enc0.flat_grad.double()))         # reduced sum x 1/world
+        dec1.flat_train.copy_(dec0.flat_train); enc1.flat_train.copy_(enc0.flat_train)      # what rank 1 would hold after its own step
+    # every gradient element was reduced exactly once per step
+    for buf in (dec0.flat_grad, enc0.flat_grad):
+        spans = sorted((o, n) for i, o, n in calls[:len(calls) // 2] if i == id(buf))
+        assert spans[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:])) and spans[-1][0] + spans[-1][1] == buf.numel()
+    monkeypatch.undo()
+    # single process, batch 4 = the two rank batches concatenated
+    enc, dec, st = _build(4)
+    ref_losses = []
+    for k in range(2):
+        ref_losses.append(float(st.step(x0, t=t, noise=noise).item()))
+        assert abs(losses[k] - ref_losses[k]) < 1e-5 * abs(ref_losses[k])
+        for got, ref in zip(grads[k], (dec.flat_grad.double(), enc.flat_grad.double())):
+            # step 0 starts from identical weights: reduction-order noise only.  Step 1 starts from weights that differ by Adam's
+            # amplification of that noise on near-zero gradients (|g| ~ eps), hence the looser bound.
+            assert float((got - ref).norm() / ref.norm()) < (1e-5 if k == 0 else 2e-3)
+    # weights: Adam moves each weight by ~lr = 1e-4 per step in the direction sign(g), so elements whose gradient is at rounding-noise
+    # level may differ by a fraction of a step; everything else must agree to 2% of one step
+    for got, ref in ((dec0.flat_train, dec.flat_train), (enc0.flat_train, enc.flat_train), (st0.ema_dec.flat_train, st.ema_dec.flat_train)):
+        diff = (got - ref).abs()
+        assert float(diff.max()) < 1e-4 and float((diff > 2e-6).float().mean()) < 1e-3 and float(diff.mean()) < 1e-7
