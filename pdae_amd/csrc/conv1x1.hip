@@ -248,14 +248,18 @@ static PointPlan point_plan(long long M, int C, int Nout) {
   PointPlan q;
   q.tiles_m = (int)((M + 127) / 128); q.tiles_n = (Nout + 127) / 128;
   const long long base = (long long)q.tiles_m * q.tiles_n;
-  const int nsteps = C >> 4;
-  int want = base >= 384 ? 1 : (int)((512 + base - 1) / base);
-  if (want > nsteps / 2) want = nsteps / 2;             // at least 2 steps (32 channels) per split
-  if (want < 1) want = 1;
-  if (want > 16) want = 16;
-  q.sps = (nsteps + want - 1) / want;
-  q.sps = (q.sps + 3) & ~3;                              // whole 64-channel stages per split
-  q.splits = (nsteps + q.sps - 1) / q.sps;
+  const int nstage = (C + 63) >> 6;                      // 64-channel stages
+  long long best = -1; int best_s = 1;
+  for (int sN = 1; sN <= nstage && sN <= 16; ++sN) {     // minimise rounds(grid) x stages-per-block (+1 for prologue / epilogue)
+    const int per = (nstage + sN - 1) / sN, sp = (nstage + per - 1) / per;
+    if (sp != sN) continue;
+    const long long rounds = (base * sp + 511) / 512;
+    const long long cost = rounds * (per + 1);
+    if (best < 0 || cost < best) { best = cost; best_s = sN; }
+  }
+  const int per = (nstage + best_s - 1) / best_s;
+  q.sps = per * 4;                                       // 16-channel steps per split: whole stages
+  q.splits = (nstage + per - 1) / per;
   q.blocks = base * q.splits;
   return q;
 }

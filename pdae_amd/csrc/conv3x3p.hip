@@ -323,10 +323,16 @@ static PatchPlan patch_plan(int C, int H, int W, int N, int Nout) {
   q.tiles_x = q.w8 ? 1 : W / PTW; q.tiles_y = H / q.th; q.tiles_n = (Nout + PBN - 1) / PBN;
   const long long base = (long long)(q.w8 ? (N + 1) / 2 : N) * q.tiles_x * q.tiles_y * q.tiles_n;
   const int nchunk = C >> 5, slots = q.th == 8 ? 512 : 256;            // resident blocks of a full chip
-  int want = base >= slots * 3 / 4 ? 1 : (int)((slots + base - 1) / base);
-  if (want > nchunk) want = nchunk;
-  if (want > 16) want = 16;
-  q.cps = (nchunk + want - 1) / want;
+  // split-K over chunk ranges: minimise rounds(grid) x chunks-per-block (+1 chunk-time of prologue / epilogue per block)
+  long long best = -1; int best_s = 1;
+  for (int sN = 1; sN <= nchunk && sN <= 16; ++sN) {
+    const int cps = (nchunk + sN - 1) / sN, sp = (nchunk + cps - 1) / cps;
+    if (sp != sN) continue;
+    const long long rounds = (base * sp + slots - 1) / slots;
+    const long long cost = rounds * (cps + 1);
+    if (best < 0 || cost < best) { best = cost; best_s = sN; }
+  }
+  q.cps = (nchunk + best_s - 1) / best_s;
   q.splits = (nchunk + q.cps - 1) / q.cps;
   q.blocks = base * q.splits;
   return q;

@@ -197,14 +197,22 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
     }
 }
 
+// split of the pixel tiles over blocks: one block per CU (147 KB of LDS at NS=3), so the grid should fill 256 CUs in whole rounds:
+// minimise rounds(grid) x tiles-per-block (a 264-block grid costs two rounds for the work of one)
 static void wgradp_plan(int N, int H, int W, int C, int Cout, int& splits, int& tiles_per_split) {
   const int ntiles = N * (H / WTH) * (W / WTW);
   const int base = ((Cout + 127) / 128) * (C / 32);
-  int want = (256 + base - 1) / base;                 // one block per CU (147 KB of LDS at NS=3)
   int maxs = ntiles / 4; if (maxs < 1) maxs = 1;      // at least 4 tiles per block
-  if (want > maxs) want = maxs;
-  if (want > 128) want = 128;
-  tiles_per_split = (ntiles + want - 1) / want;
+  if (maxs > 128) maxs = 128;
+  long long best = -1; int best_s = 1;
+  for (int s = 1; s <= maxs; ++s) {
+    const int tps = (ntiles + s - 1) / s, sp = (ntiles + tps - 1) / tps;
+    if (sp != s) continue;
+    const long long rounds = ((long long)base * sp + 255) / 256;
+    const long long cost = rounds * (tps + 1);          // +1: per-block prologue / slab write
+    if (best < 0 || cost < best) { best = cost; best_s = s; }
+  }
+  tiles_per_split = (ntiles + best_s - 1) / best_s;
   splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
 }
 
