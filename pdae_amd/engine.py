@@ -34,6 +34,10 @@ class Plan:
         self.live = []          # every tensor ever allocated (keeps storage alive)
         self.drop_ops = []      # indices of ops carrying a dropout (seed, offset)
         self.bytes_alloc = 0
+        self.init_recs = []     # ops that depend only on frozen parameters (prepared weights), see emit_init
+        self.init_arr = None
+        self.watch = []         # modules whose _frozen_version gates a re-run of the init ops
+        self.seen = None
 
     # ---- memory
     def buf(self, *shape, dtype=torch.float32, zero=False):
@@ -54,7 +58,7 @@ class Plan:
 
     def free(self, *ts):
         for t in ts:
-            if t is not None:
+            if t is not None and not isinstance(t, NoFree):
                 self.pool.setdefault((t.numel(), t.dtype), []).append(t)
 
     def need_ws(self, nbytes):
@@ -70,10 +74,18 @@ class Plan:
             self.ws_patch.append((len(self.recs) - 1, ws_slot, wsb_slot))
         return len(self.recs) - 1
 
+    def emit_init(self, op, module):
+        """Op that only depends on `module`'s frozen parameters (prepared conv weights): runs once, and again whenever
+        module._frozen_version moves (FlatModule.load_state_dict / reset_parameters / frozen_changed)."""
+        self.init_recs.append(op)
+        if all(m is not module for m in self.watch):
+            self.watch.append(module)
+
     def compile(self):
         self.ws = torch.empty(self.ws_bytes // 4 + 64, dtype=torch.float32, device=self.device)
         self.arr = H.ops_array(self.recs)
         self.n = len(self.recs)
+        self.init_arr = H.ops_array(self.init_recs) if self.init_recs else None
         for idx, ws_slot, wsb_slot in self.ws_patch:
             self.arr[idx].p[ws_slot] = self.ws.data_ptr()
             if wsb_slot is not None:
@@ -85,6 +97,11 @@ class Plan:
         if self.device.type != "cuda":
             raise H.PdaeError("pdae_amd plans only execute on a ROCm device (no CPU fallback)")
         last = self.n if last is None else last
+        if self.init_arr is not None:
+            cur = tuple(m._frozen_version for m in self.watch)
+            if cur != self.seen:
+                H.run_ops(self.init_arr, len(self.init_recs), stream)
+                self.seen = cur
         if os.environ.get("PDAE_DEBUG_SYNC"):          # one op at a time, synchronised, index printed first
             import sys
             for k in range(first, last):
@@ -103,12 +120,24 @@ class Plan:
             self.arr[idx].i[oi] = int(step)
 
 
+class NoFree:
+    """Marks a persistent buffer handed out where pooled buffers are expected: Plan.free ignores it."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
 class Builder:
     """Emits fused stages into a Plan.  `grads` maps parameter name -> gradient tensor (same memory
     layout as the parameter); presence of a name means that parameter is trained by this plan."""
 
-    def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False, math=None):
+    def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False, math=None, frozen_of=None):
         self.p = plan
+        self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
+        self._frozen_wp = {}
         self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
         self.math = H.MATH_NAMES[os.environ.get("PDAE_CONV_MATH", H.DEFAULT_MATH)] if math is None else int(math)
         self.P = params
@@ -139,6 +168,18 @@ class Builder:
         nbytes = c.wprep_bytes(transposed)
         if nbytes == 0:
             return None
+        if self.frozen_of is not None and self.frozen_of.is_frozen_storage(w):
+            # frozen weights (the pre-trained trunk of ShiftUNet: never touched by the optimizer / EMA kernels) are prepared once
+            # per plan into a persistent buffer; Plan.run refreshes them when the module reports a parameter (re)load
+            key = (w.data_ptr(), tuple(c.fields()), int(transposed))
+            wp = self._frozen_wp.get(key)
+            if wp is None:
+                wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)
+                self.p.live.append(wp)
+                self.p.bytes_alloc += wp.numel() * 4
+                self.p.emit_init(H.op_conv_wprep(c, w, transposed, wp), self.frozen_of)
+                self._frozen_wp[key] = wp
+            return NoFree(wp)
         wp = self.p.buf((nbytes + 3) // 4)
         self.p.emit(H.op_conv_wprep(c, w, transposed, wp))
         return wp

@@ -59,7 +59,7 @@ class ShiftUNet(PlannedNet):
         x = p.buf(N, Hh, W, cfg["input_channel"])
         t = p.buf(N, dtype=torch.int64)
         z = p.buf(N, self.latent_dim)
-        B = Builder(p, self.P, self.grads() if train else None, save=False, drop_p=float(cfg["dropout"]) if dropout else 0.0)
+        B = Builder(p, self.P, self.grads() if train else None, save=False, drop_p=float(cfg["dropout"]) if dropout else 0.0, frozen_of=self)
         fx = G.unet_forward(B, cfg, x, t, self.freqs, z=z, shift=True, train_shift=bool(train), dropout=dropout)
         p.n_fwd = len(p.recs)
         p.d_shift = p.dz = None

@@ -32,6 +32,7 @@ class FlatModule(nn.Module):
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_plans", {})
+        object.__setattr__(self, "_frozen_version", 0)      # bumped whenever the frozen parameters may have changed (see Plan.watch)
 
     # ------------------------------------------------------------------ construction
     def _materialize(self, shapes, trainable_fn, device):
@@ -119,6 +120,21 @@ class FlatModule(nn.Module):
     def invalidate_plans(self):
         self._plans.clear()
 
+    def frozen_changed(self):
+        """Call after writing frozen parameters by any route other than load_state_dict / reset_parameters: plans keep prepared
+        (bf16-split, fragment-ordered) copies of the frozen convolution weights and refresh them when this counter moves."""
+        object.__setattr__(self, "_frozen_version", self._frozen_version + 1)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.frozen_changed()
+        return out
+
+    def is_frozen_storage(self, t):
+        """True when tensor t is a view of the frozen flat buffer (never written by the optimizer / EMA kernels)."""
+        lo = self.flat_frozen.data_ptr()
+        return lo <= t.data_ptr() < lo + self.flat_frozen.numel() * 4
+
     # ------------------------------------------------------------------ init (torch default init of the reference layers)
     @torch.no_grad()
     def reset_parameters(self, zero_names=()):
@@ -146,3 +162,4 @@ class FlatModule(nn.Module):
                 bound = 1.0 / math.sqrt(fan_in)                  # kaiming_uniform_(a=sqrt(5))
                 tmp = torch.empty(shape, dtype=torch.float32, device=p.device).uniform_(-bound, bound)
                 p.copy_(tmp)
+        self.frozen_changed()

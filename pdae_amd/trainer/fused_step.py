@@ -50,7 +50,7 @@ class FusedRLStep:
         self.t = p.buf(N, dtype=torch.int64)
         self.loss = p.buf(1)
         Be = Builder(p, encoder.P, encoder.grads(), save=True, acc_grads=acc, math=math)
-        Bd = Builder(p, decoder.P, decoder.grads(), save=False, drop_p=drop, acc_grads=acc, math=math)
+        Bd = Builder(p, decoder.P, decoder.grads(), save=False, drop_p=drop, acc_grads=acc, math=math, frozen_of=decoder)
         # ---- forward
         z, ex = G.encoder_forward(Be, encoder.NAME, self.x0)
         x_t = p.buf(N, Hh, W, Cimg)
