@@ -190,6 +190,8 @@ extern "C" int pdae_gemm(int transA, int transB, int M, int N, int K, float alph
                          const float* B, int64_t ldb, int64_t sBo, int64_t sBi, float* C, int64_t ldc, int64_t sCo, int64_t sCi, int batch_outer,
                          int batch_inner, const float* bias, int accumulate, pdae_stream_t stream) {
   PDAE_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0 && batch_outer > 0 && batch_inner > 0, "gemm: bad arguments");
+  if (skinny_ok(transA, transB, M, N, K, alpha, lda, ldb, A, B, batch_outer * batch_inner))
+    return skinny_launch(A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate, S(stream));
   GemmParams P;
   memset(&P, 0, sizeof(P));
   P.M = M; P.N = N; P.K = K; P.splitk = 1; P.kchunk = K; P.Bi = batch_inner;

@@ -69,3 +69,7 @@ int conv1x1_wprep(int math, const float* w, int Nrows, int C, int transposed, un
 int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const unsigned short* wp, int Nrows, int row_off,
                    int Nout, float* y, const float* bias, const float* res, int res_mode, int H, int W, int accumulate, hipStream_t s);
 
+// skinny.hip: M <= 32 linear layers (one wave per output feature)
+bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch);
+int skinny_launch(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, const float* bias, int M, int N, int K,
+                  int accumulate, hipStream_t s);

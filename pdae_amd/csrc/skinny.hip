@@ -1,0 +1,71 @@
+// Skinny linear layer  C[m][n] (+)= sum_k A[m][k] * B[n][k] + bias[n]   for M <= 32 rows (the batch):
+// timestep / semantic embedding MLPs, per-ResBlock emb_layers (model/module.py:258,337,341, unet.py:52-54, shift_unet.py:63).
+//
+// These are ~100 launches per step with M = batch = 32: a 64x64 MFMA tile walks K alone in one block (20 us of pure latency).
+// Here ONE WAVE owns one output feature n: lane l holds B[n][8l..8l+7] (+512 per pass) and accumulates the 32 partial dot products
+// against the L1/L2-resident A rows; the 32 sums are then reduced over the 64 lanes with a butterfly that HALVES the number of
+// live values per stage (16+8+4+2+1+1 = 32 DPP/permute adds instead of 32 x 6): exact fp32 FMA arithmetic, HBM/latency bound.
+#include <stdlib.h>
+
+#include "common.h"
+#include "igemm.h"
+
+#define SK_M 32
+
+__global__ void __launch_bounds__(256) skinny_nt_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
+                                                        float* __restrict__ C, long long ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                        int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[SK_M];
+#pragma unroll
+  for (int m = 0; m < SK_M; ++m) acc[m] = 0.f;
+  for (int k0 = lane * 8; k0 < K; k0 += 512) {
+    const float4 b0 = *reinterpret_cast<const float4*>(B + (long long)n * ldb + k0);
+    const float4 b1 = *reinterpret_cast<const float4*>(B + (long long)n * ldb + k0 + 4);
+#pragma unroll
+    for (int m = 0; m < SK_M; ++m) {
+      if (m < M) {
+        const float4 a0 = *reinterpret_cast<const float4*>(A + m * lda + k0);
+        const float4 a1 = *reinterpret_cast<const float4*>(A + m * lda + k0 + 4);
+        float s = acc[m];
+        s = fmaf(a0.x, b0.x, s); s = fmaf(a0.y, b0.y, s); s = fmaf(a0.z, b0.z, s); s = fmaf(a0.w, b0.w, s);
+        s = fmaf(a1.x, b1.x, s); s = fmaf(a1.y, b1.y, s); s = fmaf(a1.z, b1.z, s); s = fmaf(a1.w, b1.w, s);
+        acc[m] = s;
+      }
+    }
+  }
+  // butterfly: after the stage with partner distance d (32, 16, 8, 4, 2) a lane keeps the half of its values selected by bit d
+#define SK_STAGE(D, CNT)                                                                       \
+  {                                                                                            \
+    const bool up = (lane & D) != 0;                                                           \
+    _Pragma("unroll") for (int j = 0; j < CNT; ++j) {                                          \
+      const float keep = up ? acc[j + CNT] : acc[j];                                           \
+      const float give = up ? acc[j] : acc[j + CNT];                                           \
+      acc[j] = keep + __shfl_xor(give, D);                                                     \
+    }                                                                                          \
+  }
+  SK_STAGE(32, 16) SK_STAGE(16, 8) SK_STAGE(8, 4) SK_STAGE(4, 2) SK_STAGE(2, 1)
+#undef SK_STAGE
+  float v = acc[0] + __shfl_xor(acc[0], 1);
+  // value index held by this lane: bit4 <- lane bit 5 (distance 32 chose the upper 16), bit3 <- lane bit 4, ... bit0 <- lane bit 1
+  const int m = ((lane >> 5) & 1) << 4 | ((lane >> 4) & 1) << 3 | ((lane >> 3) & 1) << 2 | ((lane >> 2) & 1) << 1 | ((lane >> 1) & 1);
+  if ((lane & 1) == 0 && m < M) {
+    if (bias) v += bias[n];
+    float* dst = C + m * ldc + n;
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
+bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch) {
+  static const bool off = getenv("PDAE_NO_SKINNY") != nullptr;        // tuning aid: force the MFMA tile kernel
+  if (off || transA || !transB || batch != 1 || alpha != 1.0f || M > SK_M || N < 64) return false;
+  return (K & 7) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+}
+
+int skinny_launch(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, const float* bias, int M, int N, int K,
+                  int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(skinny_nt_kernel, dim3((N + 3) / 4), dim3(256), 0, s, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate);
+  return pdae_launch_status("skinny_nt");
+}

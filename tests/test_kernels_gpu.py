@@ -476,3 +476,17 @@ def test_conv1x1_kernel(H, case, math_mode):
         dx1 = torch.full((N, Hh, W, C1), 1.0, device="cuda")
         H.run(H.op_conv_dgrad(c, dyd, wd, dx1, ci_off=C0, ci_cnt=C1, accumulate=1, wp_t=wp_t))
         assert rel_err(nchw(dx1), dxr[:, C0:] + 1.0) < tol
+
+
+@pytest.mark.parametrize("case", [(32, 256, 512, 0), (32, 1024, 512, 1), (7, 64, 128, 0), (32, 512, 4096, 0), (16, 768, 1032, 1), (1, 96, 72, 0)])
+def test_skinny_linear(H, case):
+    """skinny.hip (M <= 32 linear layers, one wave per output feature) through pdae_gemm, incl. strided operands and accumulate."""
+    M, N, K, acc = case
+    lda, ldb, ldc = K + 8, K + 4, N + 4
+    A, B = rn(1, M, lda), rn(2, N, ldb)
+    bias, C0 = rn(3, N), rn(4, M, ldc)
+    ref = A[:, :K].double() @ B[:, :K].double().t() + bias.double() + (C0[:, :N].double() if acc else 0)
+    Cd = C0.clone().cuda()
+    H.run(H.op_gemm(0, 1, M, N, K, A.cuda(), lda, B.cuda(), ldb, Cd, ldc, bias=bias.cuda(), accumulate=acc))
+    assert rel_err(Cd[:, :N], ref) < 1e-5
+    assert torch.equal(Cd[:, N:].cpu(), C0[:, N:])          # padding columns untouched

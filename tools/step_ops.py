@@ -41,7 +41,7 @@ for k, d in enumerate(durs):
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 tot = sum(durs)
 print(f"total {tot:.1f} ms")
-for (kind, shape, p), (cnt, ms, fl) in rows[:70]:
+for (kind, shape, p), (cnt, ms, fl) in rows[:int(os.environ.get("TOPN", "70"))]:
     print(f"{kind:7s} {p} {shape:44s} x{cnt:3d} {ms:7.2f} ms {100*ms/tot:5.1f}%  {fl/ms/1e9 if ms else 0:7.1f} TF")
 cat = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for (kind, shape, p), (cnt, ms, fl) in agg.items():
