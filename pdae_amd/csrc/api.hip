@@ -89,6 +89,8 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd: res_mode 2 needs even output");
+  if (tile == 0 && res_mode == 0 && convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
+    return convhead_fwd(x0, d->N, d->Hi, d->Wi, d->C0, w, d->Cout, bias, y, S(stream));
   const int kind = wp ? fast_kind(d, 0, false) : 0;
   PDAE_CHECK_ARG(!wp || (tile == 0 && kind != 0), "conv2d_fwd: wp given but the convolution is not eligible for a prepared-weight kernel");
   if (kind == 3)
@@ -152,6 +154,8 @@ static void wgrad_plan(const pdae_conv_desc* d, int& tile, int& splits, int& kch
 }
 
 extern "C" size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d) {
+  if (convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
+    return convhead_wgrad_workspace_bytes(d->N, d->Hi, d->Wi, d->C0, d->Cout);
   if (conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout))
     return conv3x3w_workspace_bytes(d->N, d->Ho, d->Wo, d->C0, d->Cout);
   int tile, splits, kchunk;
@@ -164,6 +168,8 @@ extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const
                                  size_t ws_bytes, pdae_stream_t stream) {
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "conv2d_wgrad: null pointer");
+  if (convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
+    return convhead_wgrad(x0, d->N, d->Hi, d->Wi, d->C0, dy, d->Cout, dw, accumulate, (float*)ws, ws_bytes, S(stream));
   if (conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout))
     return conv3x3w_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, dy, d->Cout, dw, accumulate, (float*)ws, ws_bytes, S(stream));
   int tile, splits, kchunk;

@@ -73,3 +73,10 @@ int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, l
 bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch);
 int skinny_launch(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, const float* bias, int M, int N, int K,
                   int accumulate, hipStream_t s);
+
+// convhead.hip: 3x3 convolutions with Cout <= 4 (image heads) as exact fp32 FMA kernels
+bool convhead_ok(int KH, int KW, int stride, int pad, int up, int C1, int C, int Cout);
+int convhead_fwd(const float* x, int N, int H, int W, int C, const float* w, int Cout, const float* bias, float* y, hipStream_t s);
+size_t convhead_wgrad_workspace_bytes(int N, int H, int W, int C, int Cout);
+int convhead_wgrad(const float* x, int N, int H, int W, int C, const float* dy, int Cout, float* dw, int accumulate, float* ws, size_t ws_bytes,
+                   hipStream_t s);

@@ -54,6 +54,9 @@ CONV_CASES = [
     (1, 16, 16, 32, 0, 3, 3, 1, 0, 0, 0),
     (1, 16, 16, 1, 0, 32, 3, 1, 0, 0, 0),
     (3, 32, 32, 128, 0, 128, 3, 1, 0, 0, 128),
+    (2, 24, 40, 128, 0, 3, 3, 1, 0, 0, 0),        # image head (convhead.hip): ragged tiles, 4 channel chunks
+    (2, 20, 12, 64, 0, 4, 3, 1, 0, 0, 0),
+    (1, 16, 16, 32, 0, 1, 3, 1, 0, 0, 0),
 ]
 
 
