@@ -50,6 +50,7 @@ typedef struct pdae_conv_desc {
  * implicit-GEMM kernel runs).  pdae_conv_wprep writes it from the fp32 weights w [Cout][KH][KW][Cin]; it must be re-run whenever w
  * changes (it is ~1% of the convolution's time). */
 #define PDAE_WPREP_TRANSPOSED 1   /* weights for the data gradient */
+#define PDAE_WPREP_GN 4           /* forward conv with fused GroupNorm input (pdae_conv2d_fwd_gn): two sources allowed, W % 16 == 0 */
 #define PDAE_WPREP_FORCE 2        /* _bytes: shape eligibility only, ignore the "enough tiles to fill 256 CUs" heuristic */
 size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags);
 int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream);
@@ -57,6 +58,12 @@ int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp
  * (the x_upd(x) skip of an up-ResBlock, module.py:279-284,297).  tile: 0 = auto, 64 or 128.  wp: NULL or pdae_conv_wprep(d, w, 0). */
 int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
                     const float* res, int res_mode, float* y, int tile, pdae_stream_t stream);
+/* Forward 3x3 convolution of act(a[n,c] * (x - mu[n,c]) + b[n,c]) -- GroupNorm / AdaGN (+ SiLU, act = 1) of module.py:241,257-263,
+ * 293-294,379-381 applied while the LDS patch is staged, so the normalised activation never exists in HBM (used where nothing is kept
+ * for a backward pass: the frozen trunk, sampling).  coef = [mu | a | b], each [N][C0+C1], from pdae_gn_coef; zero padding applies to the
+ * activated tensor; wp = pdae_conv_wprep(d, w, PDAE_WPREP_GN). */
+int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
+                       const float* res, int res_mode, float* y, pdae_stream_t stream);
 /* dx[N,Hl,Wl,ci_cnt] (+)= dL/d(conv input channels ci_off..ci_off+ci_cnt) on the LOGICAL input grid (Hl = 2*Hi when up).
  * wp_t: NULL or pdae_conv_wprep(d, w, PDAE_WPREP_TRANSPOSED): the data gradient then runs as a forward convolution of dy (3x3: the
  * whole channel range only; 1x1: any 32-aligned ci_off). */
@@ -135,7 +142,7 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN
 };
 typedef struct pdae_op {
   int32_t kind;

@@ -55,9 +55,17 @@ static int fast_kind(const pdae_conv_desc* d, int transposed, bool fill) {
   return 0;
 }
 
+// forward 3x3 convolution that applies GroupNorm/AdaGN(+SiLU) to its (possibly two-source) input inside the patch staging
+static bool gn_patch_ok(const pdae_conv_desc* d, bool fill) {
+  if ((d->C0 & 31) || (d->C1 & 31) || (d->Wo % 16)) return false;
+  return conv3x3p_ok(d->math, d->KH, d->KW, d->stride, d->pad, 0, d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, fill);
+}
+
 extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
   if (!d || check_desc(d)) return 0;
+  if (flags & PDAE_WPREP_GN)
+    return (!transposed && gn_patch_ok(d, !(flags & PDAE_WPREP_FORCE))) ? conv3x3p_wprep_bytes(d->math, d->Cout, d->C0 + d->C1, d->Ho, d->Wo, d->N) : 0;
   const int kind = fast_kind(d, transposed, !(flags & PDAE_WPREP_FORCE));
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
   if (kind == 3)
@@ -73,6 +81,10 @@ extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flag
   if (int e = check_desc(d)) return e;
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
   PDAE_CHECK_ARG(w && wp, "conv_wprep: null pointer");
+  if (flags & PDAE_WPREP_GN) {
+    PDAE_CHECK_ARG(!transposed && gn_patch_ok(d, false), "conv_wprep: convolution not eligible for the fused-GroupNorm patch kernel");
+    return conv3x3p_wprep(d->math, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, S(stream));
+  }
   const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
   PDAE_CHECK_ARG(kind != 0, "conv_wprep: convolution shape not eligible for a prepared-weight kernel");
   if (kind == 3) {
@@ -108,6 +120,17 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   P.C = y; P.ldc = d->Cout; P.bias = bias; P.res = res_mode ? res : nullptr; P.ldr = d->Cout; P.res_mode = res_mode;
   P.rHo = d->Ho; P.rWo = d->Wo; P.alpha = 1.0f; P.accumulate = 0;
   return igemm_conv_fwd(P, tile, d->math, S(stream));
+}
+
+extern "C" int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp,
+                                  const float* bias, const float* res, int res_mode, float* y, pdae_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  PDAE_CHECK_ARG(x0 && coef && wp && y && (d->C1 == 0 || x1), "conv2d_fwd_gn: null pointer");
+  PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd_gn: res_mode without res");
+  PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd_gn: res_mode 2 needs even output");
+  PDAE_CHECK_ARG(gn_patch_ok(d, false), "conv2d_fwd_gn: convolution not eligible (pdae_conv_wprep_bytes(d, PDAE_WPREP_GN) == 0)");
+  return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
+                         res_mode ? res : nullptr, res_mode, 0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act);
 }
 
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
@@ -357,6 +380,9 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_SOFTMAX: return pdae_softmax(FM(0), i[0], (int)i[1], st);
     case PDAE_OP_SOFTMAX_BWD: return pdae_softmax_bwd(F(0), FM(1), i[0], (int)i[1], st);
     case PDAE_OP_COLSUM: return pdae_colsum(F(0), i[0], (int)i[1], FM(1), (int)i[2], p[2], st);
+    case PDAE_OP_CONV_FWD_GN:
+      desc_from(i, d);
+      return pdae_conv2d_fwd_gn(&d, F(0), F(1), F(2), (int)i[15], p[3], F(4), F(5), (int)i[14], FM(6), st);
     case PDAE_OP_CONV_WPREP: desc_from(i, d); return pdae_conv_wprep(&d, F(0), (int)i[14], p[1], st);
     case PDAE_OP_MEMSET: {
       hipError_t e = hipMemsetAsync(p[0], 0, (size_t)i[0], S(st));

@@ -64,10 +64,16 @@ struct PatchParams {
   int tiles_x, tiles_y, tiles_n;
   int splits, cps;                      // split-K: `splits` ranges of `cps` chunks; splits > 1 => raw partials to slab[split][M][Nout]
   float* slab;
+  // fused GroupNorm / AdaGN + SiLU on the input (GN instantiation): the conv reads act(a[n,c] * (x - mu[n,c]) + b[n,c]) of the virtual
+  // concat [x | x1] (C0 channels in x), coefficients coef = [mu | a | b] each [N][C] from pdae_gn_coef; zero padding applies AFTER the map
+  const float* x1; int C0; const float* coef; int act;
 };
 
-template <int NS, int PTH, bool W8>
+__device__ __forceinline__ float p_silu(float v) { return v / (1.0f + expf(-v)); }
+
+template <int NS, int PTH, bool W8, bool GN = false>
 __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P) {
+  static_assert(!(GN && W8), "fused GroupNorm input is not built for the image-pair geometry");
   constexpr int PTHREADS = PTH * 32;                      // 512 | 256
   constexpr int PNPIX = (PTH + 2) * PPW;                  // 324 | 180
   constexpr int PA_LD = (PNPIX * 8 + PTHREADS - 1) / PTHREADS;
@@ -104,15 +110,29 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
       if constexpr (W8) { const int sub = px >= 10; im = img + sub; lx = px - 1 - 10 * sub; okx = im < P.N; }
       if (okx && (unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
         int sy = P.up ? ly >> 1 : ly, sx = P.up ? lx >> 1 : lx;
-        aoff[l] = ((long long)(im * P.Hs + sy) * P.Ws + sx) * C + qd * 4;
+        aoff[l] = GN ? (long long)(im * P.Hs + sy) * P.Ws + sx : ((long long)(im * P.Hs + sy) * P.Ws + sx) * C + qd * 4;
       }
     }
   }
   float4 apre[PA_LD];
+  float4 gmu, gsc, gsh;                          // GN: coefficients of this thread's 4 channels in the chunk being loaded
   auto a_gload = [&](int c0) {
+    if constexpr (GN) {
+      const int qd = t & 7, c = c0 + qd * 4;
+      const bool first = c0 < P.C0;
+      const float* src = first ? P.x : P.x1;
+      const int ld = first ? P.C0 : C - P.C0, cc = first ? c : c - P.C0;
+      const size_t NC = (size_t)P.N * C;
+      const float* cf = P.coef + (size_t)img * C + c;
+      gmu = *reinterpret_cast<const float4*>(cf); gsc = *reinterpret_cast<const float4*>(cf + NC); gsh = *reinterpret_cast<const float4*>(cf + 2 * NC);
 #pragma unroll
-    for (int l = 0; l < PA_LD; ++l)
-      apre[l] = aoff[l] >= 0 ? *reinterpret_cast<const float4*>(P.x + aoff[l] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int l = 0; l < PA_LD; ++l)
+        apre[l] = aoff[l] >= 0 ? *reinterpret_cast<const float4*>(src + aoff[l] * ld + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int l = 0; l < PA_LD; ++l)
+        apre[l] = aoff[l] >= 0 ? *reinterpret_cast<const float4*>(P.x + aoff[l] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
   auto a_lstore = [&]() {
 #pragma unroll
@@ -120,6 +140,15 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
       int idx = t + PTHREADS * l;
       int pix = idx >> 3, qd = idx & 7;
       if (pix < PNPIX) {
+        if constexpr (GN) {
+          if (aoff[l] >= 0) {
+            float4 v = apre[l];
+            v.x = gsc.x * (v.x - gmu.x) + gsh.x; v.y = gsc.y * (v.y - gmu.y) + gsh.y;
+            v.z = gsc.z * (v.z - gmu.z) + gsh.z; v.w = gsc.w * (v.w - gmu.w) + gsh.w;
+            if (P.act) { v.x = p_silu(v.x); v.y = p_silu(v.y); v.z = p_silu(v.z); v.w = p_silu(v.w); }
+            apre[l] = v;
+          }
+        }
         unsigned a[NS], b[NS];
         p_split2<NS>(apre[l].x, apre[l].y, a);
         p_split2<NS>(apre[l].z, apre[l].w, b);
@@ -283,20 +312,20 @@ __global__ void __launch_bounds__(256) conv3x3p_reduce_kernel(const PatchParams 
   }
 }
 
-template <int NS, int PTH, bool W8> static int launch_ns(const PatchParams& P, hipStream_t s) {
+template <int NS, int PTH, bool W8, bool GN = false> static int launch_ns(const PatchParams& P, hipStream_t s) {
   constexpr int NPIX = (PTH + 2) * PPW;
   size_t smem = (size_t)(NS * PPLANE(NPIX)) * sizeof(unsigned short);
   const size_t epi = (size_t)(PTH / 2) * 32 * EPW * sizeof(float);        // one 32 x 68 fp32 tile per wave
   if (smem < epi) smem = epi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS, PTH, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3p_kernel<NS, PTH, W8, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3p: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   const int nimg = W8 ? (P.N + 1) / 2 : P.N;
   dim3 grid(nimg * P.tiles_y * P.tiles_x * P.tiles_n * P.splits);
-  hipLaunchKernelGGL((conv3x3p_kernel<NS, PTH, W8>), grid, dim3(PTH * 32), smem, s, P);
+  hipLaunchKernelGGL((conv3x3p_kernel<NS, PTH, W8, GN>), grid, dim3(PTH * 32), smem, s, P);
   if (P.splits > 1) {
     const long long total = (long long)P.N * P.H * P.W * (P.Nout >> 2);
     long long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
@@ -362,14 +391,19 @@ static size_t prep_bytes(int math, int Nout, int C) {
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { return prep_bytes(math, Nout, C) + slab_bytes(C, H, W, N, Nout); }
 
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
-                    float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s) {
+                    float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1, int C0,
+                    const float* coef, int act) {
   PatchParams P;
+  P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.wp = wp; P.NT = (Nout + 31) / 32; P.Nout = Nout;
   P.y = y; P.bias = bias; P.res = res; P.res_mode = res_mode; P.accumulate = accumulate;
   const PatchPlan q = patch_plan(C, H, W, N, Nout);
+  if (coef && (q.w8 || (x1 && (C0 & 31)))) { pdae_set_error("conv3x3p: fused GroupNorm input needs W %% 16 == 0 and C0 %% 32 == 0"); return PDAE_EINVAL; }
   P.tiles_x = q.tiles_x; P.tiles_y = q.tiles_y; P.tiles_n = q.tiles_n; P.splits = q.splits; P.cps = q.cps;
   P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));
-#define PDAE_P3(NS_) (q.w8 ? launch_ns<NS_, 8, true>(P, s) : q.th == 16 ? launch_ns<NS_, 16, false>(P, s) : launch_ns<NS_, 8, false>(P, s))
+#define PDAE_P3(NS_)                                                                                                    \
+  (coef ? (q.th == 16 ? launch_ns<NS_, 16, false, true>(P, s) : launch_ns<NS_, 8, false, true>(P, s))                    \
+        : (q.w8 ? launch_ns<NS_, 8, true>(P, s) : q.th == 16 ? launch_ns<NS_, 16, false>(P, s) : launch_ns<NS_, 8, false>(P, s)))
   if (math == 1) return PDAE_P3(1);
   if (math == 2) return PDAE_P3(2);
   return PDAE_P3(3);

@@ -54,7 +54,8 @@ bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, i
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N);
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s);
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
-                    float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s);
+                    float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1 = nullptr,
+                    int C0 = 0, const float* coef = nullptr, int act = 0);
 
 // conv3x3w.hip: 3x3 stride-1 weight gradient with transposing LDS reads (math modes 1..3)
 bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Cout);

@@ -136,6 +136,7 @@ class Builder:
 
     def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False, math=None, frozen_of=None):
         self.p = plan
+        self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
         self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
         self._frozen_wp = {}
         self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
@@ -161,13 +162,14 @@ class Builder:
             self.p.free(wp)
         return y, NS(c=c, x0=x0, x1=x1, wname=wname, y=y)
 
-    def _wprep(self, c, w, transposed):
+    def _wprep(self, c, w, transposed, gn=False):
         """Fragment-ordered bf16 planes of w for the patch kernel (None when the conv is not eligible).  Refreshed right before
         every use -- the weights change each optimizer step and the copy costs ~10 bytes per parameter, noise next to the
         convolution itself -- so no cache has to be kept coherent with the optimizer."""
-        nbytes = c.wprep_bytes(transposed)
+        nbytes = c.wprep_bytes(transposed, gn=gn)
         if nbytes == 0:
             return None
+        transposed = int(transposed) | (4 if gn else 0)          # PDAE_WPREP_* flags from here on
         if self.frozen_of is not None and self.frozen_of.is_frozen_storage(w):
             # frozen weights (the pre-trained trunk of ShiftUNet: never touched by the optimizer / EMA kernels) are prepared once
             # per plan into a persistent buffer; Plan.run refreshes them when the module reports a parameter (re)load
@@ -237,6 +239,31 @@ class Builder:
         self.p.emit(H.op_silu(x, y, x.numel()))
         return y
 
+    def gn_conv(self, x0, x1, gname, wname, ss=None, zss=None, up=False, res=None, res_mode=0):
+        """GroupNorm [+AdaGN] + SiLU + 3x3 conv with the normalisation applied inside the conv's patch staging (pdae_conv2d_fwd_gn): the
+        activated tensor is never written.  Forward-only stages (nothing saved for a backward); returns None when the conv is not
+        eligible for the fused kernel."""
+        if self.save or not self.fuse_gn:
+            return None
+        N, Hh, W, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[3]
+        C = C0 + C1
+        w, b = self.P[wname + ".weight"], self.P[wname + ".bias"]
+        c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=3, up=up, math=self.math)
+        if c.wprep_bytes(0, gn=True) == 0:
+            return None
+        pl = self.p
+        gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]
+        pl.need_ws(H.gn_ws_bytes(N, C))
+        mean, rstd, coef = pl.buf(N * GROUPS), pl.buf(N * GROUPS), pl.buf(3, N, C)
+        pl.emit(H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, mean, rstd, None), ws_slot=4)
+        pl.emit(H.op_gn_coef(N, C, GROUPS, mean, rstd, gamma, beta, ss, zss, coef))
+        wp = self._wprep(c, w, 0, gn=True)
+        y = pl.buf(N, c.Ho, c.Wo, c.Cout)
+        pl.emit(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, b, y, res=res, res_mode=res_mode))
+        pl.free(mean, rstd, coef, wp)
+        return y
+
     def gn(self, x0, x1, gname, ss=None, zss=None, act=1, mode=0, want_xpool=False, dropout=False):
         """GroupNorm(32) [+AdaGN] [+SiLU] [+dropout] [+2x2 avg-pool].  Returns ctx with .y (.xpool)."""
         N, Hh, W, C0 = x0.shape
@@ -287,29 +314,40 @@ class Builder:
         pl = self.p
         has_skip = (pre + ".skip_connection.weight") in self.P
         assert not (has_skip and (up or down)), "channel-changing up/down ResBlocks do not occur on this path"
-        g1 = self.gn(x0, x1, pre + ".in_layers.0", act=1, mode=1 if down else 0, want_xpool=down)
-        h1, c1 = self.conv(g1.y, None, pre + ".in_layers.2", 3, up=up)
-        if not self.save:
-            pl.free(g1.y)
+        g1 = c1 = None
+        h1 = None if down else self.gn_conv(x0, x1, pre + ".in_layers.0", pre + ".in_layers.2", up=up)       # fused when forward-only
+        if h1 is None:
+            g1 = self.gn(x0, x1, pre + ".in_layers.0", act=1, mode=1 if down else 0, want_xpool=down)
+            h1, c1 = self.conv(g1.y, None, pre + ".in_layers.2", 3, up=up)
+            if not self.save:
+                pl.free(g1.y)
         ss, l_ss = self.linear(ea, pre + ".emb_layers.1")
         zss, l_zss = (None, None)
         if eza is not None:
             zss, l_zss = self.linear(eza, pre + ".emb_z_layers.1")
-        g2 = self.gn(h1, None, pre + ".out_layers.0", ss=ss, zss=zss, act=1, mode=0, dropout=dropout)
-        if not self.save:
-            pl.free(h1, ss, zss)
         cs = None
         if has_skip:
-            sk, cs = self.conv(x0, x1, pre + ".skip_connection", 1)
-            out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=sk, res_mode=1)
-            pl.free(sk)                      # never needed by backward
+            res, cs = self.conv(x0, x1, pre + ".skip_connection", 1)
+            res_mode = 1
         elif down:
-            out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=g1.xpool, res_mode=1)
-            pl.free(g1.xpool)
+            res, res_mode = g1.xpool, 1
         else:
-            out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=x0, res_mode=2 if up else 1)
+            res, res_mode = x0, (2 if up else 1)
+        g2 = c2 = None
+        out = None
+        if not (dropout and self.drop_p > 0):
+            out = self.gn_conv(h1, None, pre + ".out_layers.0", pre + ".out_layers.3", ss=ss, zss=zss, res=res, res_mode=res_mode)
+        if out is None:
+            g2 = self.gn(h1, None, pre + ".out_layers.0", ss=ss, zss=zss, act=1, mode=0, dropout=dropout)
+            out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=res, res_mode=res_mode)
+            if not self.save:
+                pl.free(g2.y)
         if not self.save:
-            pl.free(g2.y)
+            pl.free(h1, ss, zss)
+        if has_skip:
+            pl.free(res)                     # never needed by backward
+        elif down:
+            pl.free(g1.xpool)
         return out, NS(pre=pre, g1=g1, c1=c1, l_ss=l_ss, l_zss=l_zss, g2=g2, c2=c2, cs=cs, up=up, down=down, has_skip=has_skip, h1=h1)
 
     def resblock_bwd(self, r, dout, need_dx0=True, need_dx1=False, d_ea=None, d_eza=None):

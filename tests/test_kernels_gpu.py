@@ -493,3 +493,49 @@ def test_skinny_linear(H, case):
     H.run(H.op_gemm(0, 1, M, N, K, A.cuda(), lda, B.cuda(), ldb, Cd, ldc, bias=bias.cuda(), accumulate=acc))
     assert rel_err(Cd[:, :N], ref) < 1e-5
     assert torch.equal(Cd[:, N:].cpu(), C0[:, N:])          # padding columns untouched
+
+
+@pytest.mark.parametrize("math_mode", [1, 3])
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 32, 64, 0, 1), (2, 8, 8, 32, 0, 32, 1, 2), (1, 24, 16, 96, 0, 160, 0, 0), (2, 32, 32, 128, 128, 128, 0, 1)])
+def test_conv_with_fused_groupnorm_input(H, case, math_mode):
+    """pdae_conv2d_fwd_gn: GroupNorm + AdaGN + SiLU applied inside the conv's patch staging (two-source concat, upsample, residuals,
+    zero padding of the ACTIVATED tensor) against fp64 and against the unfused gn_apply -> conv pair."""
+    N, Hh, W, C0, C1, Cout, up, res_mode = case
+    C, G = C0 + C1, 32
+    tol = MATH_TOL[math_mode]
+    x = rn(1, N, C, Hh, W) * 1.5 + 0.7
+    gamma, beta = 1 + 0.2 * rn(2, C), 0.2 * rn(3, C) + 0.5          # beta offset: silu(b - a mu) != 0 would expose wrong padding
+    ss = 0.3 * rn(4, N, 2 * C)
+    w = rn(5, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9))
+    b = rn(6, Cout, scale=0.1)
+    c = H.Conv(N, Hh, W, C0, C1, Cout, k=3, up=bool(up), math=math_mode)
+    a_ref = _gn_ref(x.double(), gamma.double(), beta.double(), ss.double(), None, 1)
+    y_ref = ref_conv(a_ref, w, b, 1, 1, up)
+    res = None
+    if res_mode == 1:
+        res = rn(7, N, Cout, c.Ho, c.Wo); y_ref = y_ref + res.double()
+    elif res_mode == 2:
+        res = rn(7, N, Cout, c.Ho // 2, c.Wo // 2); y_ref = y_ref + F.interpolate(res, scale_factor=2, mode="nearest").double()
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous()
+    x1 = xh[..., C0:].contiguous() if C1 else None
+    mean = torch.empty(N * G, device="cuda"); rstd = torch.empty(N * G, device="cuda")
+    H.run(H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, G, 1e-5, mean, rstd, ws(H.gn_ws_bytes(N, C))))
+    coef = torch.empty(3, N, C, device="cuda")
+    H.run(H.op_gn_coef(N, C, G, mean, rstd, gamma.cuda(), beta.cuda(), ss.cuda(), None, coef))
+    nb = c.wprep_bytes(0, force=True, gn=True)
+    assert nb > 0
+    wd, bd = nhwc(w).cuda(), b.cuda()
+    wp = torch.empty(nb // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 4, wp))
+    y = torch.empty(N, c.Ho, c.Wo, Cout, device="cuda")
+    resd = nhwc(res).cuda() if res is not None else None
+    H.run(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, bd, y, res=resd, res_mode=res_mode))
+    assert rel_err(nchw(y), y_ref) < tol
+    # unfused pair on the same kernels
+    a = torch.empty(N, Hh, W, C, device="cuda")
+    H.run(H.op_gn_apply(x0, C0, x1, C1, N, Hh, W, coef, 1, 0, a))
+    c1 = H.Conv(N, Hh, W, C, 0, Cout, k=3, up=bool(up), math=math_mode)
+    y2 = torch.empty_like(y)
+    H.run(H.op_conv_fwd(c1, a, None, wd, bd, y2, res=resd, res_mode=res_mode))
+    assert rel_err(y, y2) < tol
