@@ -54,7 +54,7 @@ def op_flops(op):
     """Algorithmic FLOPs of one igemm-family op record (0 for everything else)."""
     from pdae_amd import hip as H
     i = op.i
-    if op.kind in (H.OP_CONV_FWD, H.OP_CONV_WGRAD):
+    if op.kind in (H.OP_CONV_FWD, H.OP_CONV_WGRAD, H.OP_CONV_FWD_GN):
         N, Ho, Wo, Cout, KH, KW, cin = i[0], i[5], i[6], i[7], i[8], i[9], i[3] + i[4]
         return 2.0 * N * Ho * Wo * Cout * KH * KW * cin
     if op.kind == H.OP_CONV_DGRAD:
@@ -238,16 +238,18 @@ def main():
         out["dtype"] = "f32" if math == "f32" else ("bf16" if math == "bf16" else f"f32 as {math} split-bf16 MFMA, fp32 accumulate")
         # dominant kernel: conv3x3p_kernel (3x3 forward + data gradient on the patch path = ops that carry prepared weights)
         def is_patch(op):
-            wl = op.i[6] if op.kind == H.OP_CONV_FWD else op.i[2] * (2 if op.i[12] else 1)
+            fwd = op.kind in (H.OP_CONV_FWD, H.OP_CONV_FWD_GN)
+            wl = op.i[6] if fwd else op.i[2] * (2 if op.i[12] else 1)
             if op.i[8] != 3 or wl == 8:               # 8-pixel-wide layers run the image-pair instantiation: a different kernel symbol
                 return False
-            return (op.kind == H.OP_CONV_FWD and bool(op.p[6])) or (op.kind == H.OP_CONV_DGRAD and bool(op.p[3]))
+            return op.kind == H.OP_CONV_FWD_GN or (op.kind == H.OP_CONV_FWD and bool(op.p[6])) or (op.kind == H.OP_CONV_DGRAD and bool(op.p[3]))
 
         def patch_bytes(op):                          # algorithmic HBM bytes of one launch: input + output (+ residual) once, fp32
             i = op.i
             N, Hi, Wi, Cin, Ho, Wo, Cout, up = i[0], i[1], i[2], i[3] + i[4], i[5], i[6], i[7], i[12]
-            if op.kind == H.OP_CONV_FWD:
-                return 4.0 * N * (Hi * Wi * Cin + Ho * Wo * Cout * (2 if op.p[4] else 1)) + 6.0 * Cout * 9 * Cin
+            if op.kind in (H.OP_CONV_FWD, H.OP_CONV_FWD_GN):
+                has_res = bool(op.p[4]) if op.kind == H.OP_CONV_FWD else bool(op.p[5])
+                return 4.0 * N * (Hi * Wi * Cin + Ho * Wo * Cout * (2 if has_res else 1)) + 6.0 * Cout * 9 * Cin
             s_ = 2 if up else 1
             return 4.0 * N * (Ho * Wo * Cout + Hi * s_ * Wi * s_ * Cin) + 6.0 * Cout * 9 * Cin
 
@@ -257,9 +259,10 @@ def main():
         traffic, traffic_src = None, None
         try:                                          # PMC counters cannot be read from inside the process: committed rocprofv3 --pmc passes
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
-            kk = pmc["kernels"].get("void conv3x3p_kernel<3, 8, false>(PatchParams)")
+            kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3p_kernel<3, 8, false")]     # plain + fused-GN instantiations
             if kk and math == "bf16x6":
-                traffic, traffic_src = kk["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, gfx950 x2 fetch correction)"
+                traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kk) / sum(v["dispatches"] for v in kk))
+                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, gfx950 x2 fetch correction)"
         except (OSError, ValueError, KeyError):
             pass
         out["roofline"] = {"bound": "mfma", "kernel": "conv3x3p_kernel (3x3 conv forward + data gradient, LDS-patch kernel)",
