@@ -64,6 +64,15 @@ int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, c
  * activated tensor; wp = pdae_conv_wprep(d, w, PDAE_WPREP_GN). */
 int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
                        const float* res, int res_mode, float* y, pdae_stream_t stream);
+/* ResBlock tail in one launch (module.py:265,276,297):  y = conv3x3_d(in) + bias + conv1x1_ds([s0 | s1]) + bias_s,  in = coef ?
+ * act(GN-affine([x0 | x1])) : x0.  The 1x1 skip_connection enters the 3x3 kernel's K loop as extra centre-tap chunks of the raw block
+ * input, so its output never exists in HBM.  ds: 1x1 descriptor on d's output grid (C0/C1 = channels of s0/s1);
+ * wps = pdae_conv_wprep(ds, w_skip, 0); wp as for pdae_conv2d_fwd (coef == NULL) or pdae_conv2d_fwd_gn.  pdae_conv2d_fwd_skip_ok tells
+ * whether the pair is eligible (otherwise run the two convolutions separately, the second with res_mode 1). */
+int pdae_conv2d_fwd_skip_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds);
+int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
+                         const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps, const float* bias_s, float* y,
+                         pdae_stream_t stream);
 /* dx[N,Hl,Wl,ci_cnt] (+)= dL/d(conv input channels ci_off..ci_off+ci_cnt) on the LOGICAL input grid (Hl = 2*Hi when up).
  * wp_t: NULL or pdae_conv_wprep(d, w, PDAE_WPREP_TRANSPOSED): the data gradient then runs as a forward convolution of dy (3x3: the
  * whole channel range only; 1x1: any 32-aligned ci_off). */
@@ -142,7 +151,7 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP
 };
 typedef struct pdae_op {
   int32_t kind;

@@ -133,6 +133,31 @@ extern "C" int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, cons
                          res_mode ? res : nullptr, res_mode, 0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act);
 }
 
+static bool skip_desc_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds) {
+  return ds && ds->KH == 1 && ds->KW == 1 && ds->stride == 1 && ds->pad == 0 && !ds->up && ds->N == d->N && ds->Hi == d->Ho && ds->Wi == d->Wo &&
+         ds->Ho == d->Ho && ds->Wo == d->Wo && ds->Cout == d->Cout && ds->math == d->math;
+}
+
+extern "C" int pdae_conv2d_fwd_skip_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds) {
+  if (!d || !ds || check_desc(d) || check_desc(ds) || !skip_desc_ok(d, ds)) return 0;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || (d->C0 & 31) || (d->C1 & 31)) return 0;
+  return conv3x3p_skip_ok(d->math, d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, d->up, ds->C0, ds->C1) ? 1 : 0;
+}
+
+extern "C" int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp,
+                                    const float* bias, const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps,
+                                    const float* bias_s, float* y, pdae_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  PDAE_CHECK_ARG(ds && !check_desc(ds) && skip_desc_ok(d, ds), "conv2d_fwd_skip: the 1x1 descriptor must map the conv's output grid (same N, H, W, Cout, math)");
+  PDAE_CHECK_ARG(x0 && wp && y && s0 && wps && (ds->C1 == 0 || s1), "conv2d_fwd_skip: null pointer");
+  PDAE_CHECK_ARG(coef || d->C1 == 0, "conv2d_fwd_skip: a two-source main input needs the fused GroupNorm form (coef)");
+  PDAE_CHECK_ARG(d->C1 == 0 || x1, "conv2d_fwd_skip: null second source");
+  PDAE_CHECK_ARG(pdae_conv2d_fwd_skip_ok(d, ds), "conv2d_fwd_skip: shape not eligible (pdae_conv2d_fwd_skip_ok == 0)");
+  PatchSkip sk{s0, ds->C1 ? s1 : nullptr, ds->C0, ds->C1, (const unsigned short*)wps, bias_s};
+  return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias, nullptr, 0,
+                         0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act, &sk);
+}
+
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
                                  int accumulate, int tile, pdae_stream_t stream) {
   if (int e = check_desc(d)) return e;
@@ -383,6 +408,12 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_CONV_FWD_GN:
       desc_from(i, d);
       return pdae_conv2d_fwd_gn(&d, F(0), F(1), F(2), (int)i[15], p[3], F(4), F(5), (int)i[14], FM(6), st);
+    case PDAE_OP_CONV_FWD_SKIP: {
+      desc_from(i, d);
+      pdae_conv_desc ds = d;
+      ds.Hi = d.Ho; ds.Wi = d.Wo; ds.C0 = (int)i[15]; ds.C1 = (int)i[16]; ds.KH = ds.KW = 1; ds.pad = 0; ds.up = 0; ds.stride = 1;
+      return pdae_conv2d_fwd_skip(&d, F(0), F(1), F(2), (int)i[14], p[3], F(4), &ds, F(5), F(6), p[7], F(8), FM(9), st);
+    }
     case PDAE_OP_CONV_WPREP: desc_from(i, d); return pdae_conv_wprep(&d, F(0), (int)i[14], p[1], st);
     case PDAE_OP_MEMSET: {
       hipError_t e = hipMemsetAsync(p[0], 0, (size_t)i[0], S(st));

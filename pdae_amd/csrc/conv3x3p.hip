@@ -67,6 +67,9 @@ struct PatchParams {
   // fused GroupNorm / AdaGN + SiLU on the input (GN instantiation): the conv reads act(a[n,c] * (x - mu[n,c]) + b[n,c]) of the virtual
   // concat [x | x1] (C0 channels in x), coefficients coef = [mu | a | b] each [N][C] from pdae_gn_coef; zero padding applies AFTER the map
   const float* x1; int C0; const float* coef; int act;
+  // fused 1x1 skip convolution (ResBlock skip_connection, module.py:276,297): nx extra 32-channel chunks of the raw two-source tensor
+  // [s0 | s1] enter the K loop with the centre tap only, weights wps = conv1x1_wprep layout, bias_x added in the epilogue
+  int nx; const float* s0; const float* s1; int Cs0, Cs1; const unsigned short* wps; const float* bias_x;
 };
 
 __device__ __forceinline__ float p_silu(float v) { return v / (1.0f + expf(-v)); }
@@ -110,29 +113,35 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
       if constexpr (W8) { const int sub = px >= 10; im = img + sub; lx = px - 1 - 10 * sub; okx = im < P.N; }
       if (okx && (unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
         int sy = P.up ? ly >> 1 : ly, sx = P.up ? lx >> 1 : lx;
-        aoff[l] = GN ? (long long)(im * P.Hs + sy) * P.Ws + sx : ((long long)(im * P.Hs + sy) * P.Ws + sx) * C + qd * 4;
+        aoff[l] = (long long)(im * P.Hs + sy) * P.Ws + sx;          // pixel index in the stored tensor(s)
       }
     }
   }
   float4 apre[PA_LD];
   float4 gmu, gsc, gsh;                          // GN: coefficients of this thread's 4 channels in the chunk being loaded
-  auto a_gload = [&](int c0) {
-    if constexpr (GN) {
-      const int qd = t & 7, c = c0 + qd * 4;
-      const bool first = c0 < P.C0;
-      const float* src = first ? P.x : P.x1;
-      const int ld = first ? P.C0 : C - P.C0, cc = first ? c : c - P.C0;
-      const size_t NC = (size_t)P.N * C;
-      const float* cf = P.coef + (size_t)img * C + c;
-      gmu = *reinterpret_cast<const float4*>(cf); gsc = *reinterpret_cast<const float4*>(cf + NC); gsh = *reinterpret_cast<const float4*>(cf + 2 * NC);
-#pragma unroll
-      for (int l = 0; l < PA_LD; ++l)
-        apre[l] = aoff[l] >= 0 ? *reinterpret_cast<const float4*>(src + aoff[l] * ld + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+  bool pre_raw = false;                          // the registers hold a skip chunk (raw input: no GroupNorm map)
+  const int nmain = C >> 5, nchunk = nmain + P.nx;            // virtual chunk list: main chunks (9 taps), then skip chunks (centre tap)
+  auto a_gload = [&](int chunk) {
+    const int qd = t & 7;
+    const float* src; int ld, cc;
+    pre_raw = chunk >= nmain;
+    if (pre_raw) {                               // skip chunk: raw [s0 | s1] at the output resolution
+      const int c = ((chunk - nmain) << 5) + qd * 4;
+      const bool first = c < P.Cs0;
+      src = first ? P.s0 : P.s1; ld = first ? P.Cs0 : P.Cs1; cc = first ? c : c - P.Cs0;
     } else {
-#pragma unroll
-      for (int l = 0; l < PA_LD; ++l)
-        apre[l] = aoff[l] >= 0 ? *reinterpret_cast<const float4*>(P.x + aoff[l] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = (chunk << 5) + qd * 4;
+      const bool first = c < P.C0;               // C0 == C for a single source
+      src = first ? P.x : P.x1; ld = first ? P.C0 : C - P.C0; cc = first ? c : c - P.C0;
+      if constexpr (GN) {
+        const size_t NC = (size_t)P.N * C;
+        const float* cf = P.coef + (size_t)img * C + c;
+        gmu = *reinterpret_cast<const float4*>(cf); gsc = *reinterpret_cast<const float4*>(cf + NC); gsh = *reinterpret_cast<const float4*>(cf + 2 * NC);
+      }
     }
+#pragma unroll
+    for (int l = 0; l < PA_LD; ++l)
+      apre[l] = aoff[l] >= 0 ? *reinterpret_cast<const float4*>(src + aoff[l] * ld + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto a_lstore = [&]() {
 #pragma unroll
@@ -141,7 +150,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
       int pix = idx >> 3, qd = idx & 7;
       if (pix < PNPIX) {
         if constexpr (GN) {
-          if (aoff[l] >= 0) {
+          if (aoff[l] >= 0 && !pre_raw) {
             float4 v = apre[l];
             v.x = gsc.x * (v.x - gmu.x) + gsh.x; v.y = gsc.y * (v.y - gmu.y) + gsh.y;
             v.z = gsc.z * (v.z - gmu.z) + gsh.z; v.w = gsc.w * (v.w - gmu.w) + gsh.w;
@@ -158,7 +167,6 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
     }
   };
 
-  // ---- B panel of one (chunk, tap): 32 k x 128 n
   // MFMA row i of 32-row group g = wm*2+a <-> pixel (by*8 + i/4, bx*4 + i%4), (bx, by) = (g & 3, g >> 2): with the 20-pixel
   // pitch and 80-byte rows the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots for all 9 tap shifts
   int apix[2];
@@ -176,25 +184,24 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nchunk = C >> 5;
   const int c_begin = sp * P.cps, c_end = min(nchunk, c_begin + P.cps);
-  const int s_begin = 18 * c_begin, total = 18 * c_end;     // (chunk, tap, k-half) steps of 16 k each
-  // B fragments of step s: wp[p][chunk][tap][kc][nt][lane] -> one uint4 (8 bf16) per lane, tile and plane
+  // B fragments of one k-step (16 channels of one tap): one uint4 (8 bf16) per lane, 32-channel tile and plane;
+  //   main chunks: wp [p][chunk][tap][kc][nt][lane],  skip chunks: wps [p][chunk - nmain][kc][nt][lane]
   const int nt0 = (n0 >> 5) + wn * 2;
-  const size_t plane_stride = (size_t)nchunk * 18 * P.NT * 512;      // bf16 elements per plane
-  auto ldb = [&](uint4 (&bq)[2][NS], int s) {
-    const unsigned short* base = P.wp + ((size_t)s * P.NT + nt0) * 512 + lane * 8;
+  const size_t plane_main = (size_t)nmain * 18 * P.NT * 512, plane_skip = (size_t)P.nx * 2 * P.NT * 512;      // bf16 elements per plane
+  auto ldb = [&](uint4 (&bq)[2][NS], int chunk, int tap, int kc) {
+    const bool raw = chunk >= nmain;
+    const unsigned short* base = raw ? P.wps + ((size_t)(((chunk - nmain) << 1) + kc) * P.NT + nt0) * 512 + lane * 8
+                                     : P.wp + ((size_t)(((chunk * 9 + tap) << 1) + kc) * P.NT + nt0) * 512 + lane * 8;
+    const size_t ps = raw ? plane_skip : plane_main;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int p = 0; p < NS; ++p) {
-        bq[b][p] = (nt0 + b < P.NT) ? *reinterpret_cast<const uint4*>(base + p * plane_stride + b * 512) : make_uint4(0u, 0u, 0u, 0u);
-      }
+      for (int p = 0; p < NS; ++p)
+        bq[b][p] = (nt0 + b < P.NT) ? *reinterpret_cast<const uint4*>(base + p * ps + b * 512) : make_uint4(0u, 0u, 0u, 0u);
   };
-  auto step = [&](int s, const uint4 (&bq)[2][NS], uint4 (&bn)[2][NS]) {
-    if (s + 1 < total) ldb(bn, s + 1);            // next step's weights in flight under this step's MFMAs
-    const int ct = s >> 1, kc = s & 1;
-    const int chunk = ct / 9, tap = ct - chunk * 9;
+  // one k-step: 16 channels (half kc of the staged chunk) of one tap
+  auto mma = [&](int tap, int kc, const uint4 (&bq)[2][NS]) {
     const int dy = tap / 3, dx = tap - dy * 3;
     const int ashift = dy * PPW + dx;
     bf16x8 af[2][NS];
@@ -220,23 +227,32 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(0), acc[a][b], 0, 0, 0);
 #undef PDAE_B
       }
-    // patch hand-over at the end of a chunk: the only barriers of the kernel
-    if ((s + 1) % 18 == 0 && s + 1 < total) {
-      __syncthreads();                            // every wave is done with the current patch
-      a_lstore();
-      __syncthreads();
-      if (chunk + 2 < c_end) a_gload((chunk + 2) << 5);
-    }
   };
   uint4 q0[2][NS], q1[2][NS];
-  a_gload(c_begin << 5);
-  ldb(q0, s_begin);
-  a_lstore();
-  __syncthreads();
-  if (c_begin + 1 < c_end) a_gload((c_begin + 1) << 5);
-  for (int s = s_begin; s < total; s += 2) {      // an even number of steps
-    step(s, q0, q1);
-    step(s + 1, q1, q0);
+  if (c_begin < c_end) {
+    a_gload(c_begin);
+    ldb(q0, c_begin, c_begin >= nmain ? 4 : 0, 0);
+    a_lstore();
+    __syncthreads();
+    if (c_begin + 1 < c_end) a_gload(c_begin + 1);
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+      const bool raw = chunk >= nmain;
+      const int t_lo = raw ? 4 : 0, t_hi = raw ? 5 : 9;                   // skip chunks: centre tap only
+      for (int tap = t_lo; tap < t_hi; ++tap) {
+        ldb(q1, chunk, tap, 1);                   // next k-step's weights in flight under this step's MFMAs
+        mma(tap, 0, q0);
+        if (tap + 1 < t_hi) ldb(q0, chunk, tap + 1, 0);
+        else if (chunk + 1 < c_end) ldb(q0, chunk + 1, chunk + 1 >= nmain ? 4 : 0, 0);
+        mma(tap, 1, q1);
+      }
+      // patch hand-over at the end of a chunk: the only barriers of the kernel
+      if (chunk + 1 < c_end) {
+        __syncthreads();                          // every wave is done with the current patch
+        a_lstore();
+        __syncthreads();
+        if (chunk + 2 < c_end) a_gload(chunk + 2);
+      }
+    }
   }
 
   // ---- epilogue: every wave transposes its 32-pixel x 64-channel accumulator groups through a private LDS region (the patch is
@@ -248,10 +264,9 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   const int er = lane >> 4, ec = (lane & 15) * 4;         // read side: row within a group of 4, first of 4 channels
   const int colb = n0 + wn * 64 + ec;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (P.bias && P.splits == 1) {
-    if (colb + 3 < P.Nout) bias4 = *reinterpret_cast<const float4*>(P.bias + colb);
-    else { float t4[4] = {0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (colb + j < P.Nout) t4[j] = P.bias[colb + j];
-           bias4 = make_float4(t4[0], t4[1], t4[2], t4[3]); }
+  if (P.splits == 1 && colb < P.Nout) {          // Nout % 4 == 0: the four columns are valid together
+    if (P.bias) bias4 = *reinterpret_cast<const float4*>(P.bias + colb);
+    if (P.bias_x) { const float4 u = *reinterpret_cast<const float4*>(P.bias_x + colb); bias4.x += u.x; bias4.y += u.y; bias4.z += u.z; bias4.w += u.w; }
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
@@ -298,6 +313,7 @@ __global__ void __launch_bounds__(256) conv3x3p_reduce_kernel(const PatchParams 
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
     if (P.bias) { const float4 u = *reinterpret_cast<const float4*>(P.bias + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    if (P.bias_x) { const float4 u = *reinterpret_cast<const float4*>(P.bias_x + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
     if (P.res_mode) {
       long long rrow = row;
       if (P.res_mode == 2) {
@@ -367,6 +383,14 @@ static PatchPlan patch_plan(int C, int H, int W, int N, int Nout) {
   return q;
 }
 
+// fused 1x1 skip convolution: the main conv must be eligible without the image-pair geometry / upsample and the combined K loop must not
+// need split-K (its slabs are sized for the main convolution alone)
+bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, int Cs0, int Cs1) {
+  if (math < 1 || up || (C & 31) || (Cs0 & 31) || (Cs1 & 31) || (H % 8) || (W % PTW) || (Nout & 3) || Nout < 32) return false;
+  const PatchPlan q = patch_plan(C + Cs0 + Cs1, H, W, N, Nout);
+  return q.blocks / q.splits >= 256;              // enough tiles without split-K (the fused launch never splits)
+}
+
 // eligibility: 3x3, stride 1, pad 1, one source, channels % 32, spatial tile-aligned (W % 16, or W == 8 for image pairs);
 // fill: also enough blocks to occupy the chip (fill = false: shape eligibility only)
 bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout, bool fill) {
@@ -392,12 +416,16 @@ size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { re
 
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1, int C0,
-                    const float* coef, int act) {
+                    const float* coef, int act, const PatchSkip* sk) {
   PatchParams P;
   P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
+  P.nx = 0; P.s0 = P.s1 = nullptr; P.Cs0 = P.Cs1 = 0; P.wps = nullptr; P.bias_x = nullptr;
+  if (sk) { P.nx = (sk->C0 + sk->C1) >> 5; P.s0 = sk->s0; P.s1 = sk->s1; P.Cs0 = sk->C0; P.Cs1 = sk->C1; P.wps = sk->wps; P.bias_x = sk->bias; }
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.wp = wp; P.NT = (Nout + 31) / 32; P.Nout = Nout;
   P.y = y; P.bias = bias; P.res = res; P.res_mode = res_mode; P.accumulate = accumulate;
-  const PatchPlan q = patch_plan(C, H, W, N, Nout);
+  PatchPlan q = patch_plan(C + 32 * P.nx, H, W, N, Nout);
+  if (sk) { q.splits = 1; q.cps = (C >> 5) + P.nx; }          // the slabs behind wp are sized for the main convolution alone
+  if (sk && (q.w8 || up || (sk->C0 & 31) || (sk->C1 & 31))) { pdae_set_error("conv3x3p: fused skip convolution not eligible for this shape"); return PDAE_EINVAL; }
   if (coef && (q.w8 || (x1 && (C0 & 31)))) { pdae_set_error("conv3x3p: fused GroupNorm input needs W %% 16 == 0 and C0 %% 32 == 0"); return PDAE_EINVAL; }
   P.tiles_x = q.tiles_x; P.tiles_y = q.tiles_y; P.tiles_n = q.tiles_n; P.splits = q.splits; P.cps = q.cps;
   P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));

@@ -50,12 +50,14 @@ int igemm_splitk_reduce(const float* ws, float* out, long long n, int splits, in
 int igemm_dense(int transA, int transB, const GemmParams& P, int zdim, hipStream_t s);
 
 // conv3x3p.hip: 3x3 stride-1 "patch" kernel on the bf16 MFMA pipe (math modes 1..3)
+struct PatchSkip { const float* s0; const float* s1; int C0, C1; const unsigned short* wps; const float* bias; };   // fused 1x1 skip conv
 bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout, bool fill);
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N);
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s);
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1 = nullptr,
-                    int C0 = 0, const float* coef = nullptr, int act = 0);
+                    int C0 = 0, const float* coef = nullptr, int act = 0, const PatchSkip* sk = nullptr);
+bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, int Cs0, int Cs1);
 
 // conv3x3w.hip: 3x3 stride-1 weight gradient with transposing LDS reads (math modes 1..3)
 bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Cout);

@@ -136,6 +136,7 @@ class Builder:
 
     def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False, math=None, frozen_of=None):
         self.p = plan
+        self.fuse_skip = os.environ.get("PDAE_FUSE_SKIP", "1") != "0"  # ResBlock skip_connection rides in conv2's K loop (conv_skip)
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
         self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
         self._frozen_wp = {}
@@ -239,7 +240,38 @@ class Builder:
         self.p.emit(H.op_silu(x, y, x.numel()))
         return y
 
-    def gn_conv(self, x0, x1, gname, wname, ss=None, zss=None, up=False, res=None, res_mode=0):
+    def _skip_parts(self, c, skip):
+        """(cs, s0, s1, wps, bias_s, ctx) of a fusable 1x1 skip convolution riding on the 3x3 conv c, or None."""
+        if skip is None or not self.fuse_skip:
+            return None
+        s0, s1, sname = skip
+        ws, bs = self.P[sname + ".weight"], self.P[sname + ".bias"]
+        cs = H.Conv(c.N, c.Ho, c.Wo, s0.shape[3], 0 if s1 is None else s1.shape[3], c.Cout, k=1, math=self.math)
+        if not H.conv_fwd_skip_ok(c, cs):
+            return None
+        wps = self._wprep(cs, ws, 0)
+        if wps is None:
+            return None
+        return cs, s0, s1, wps, bs, NS(c=cs, x0=s0, x1=s1, wname=sname, y=None)
+
+    def conv_skip(self, x, wname, skip):
+        """3x3 conv of x plus the fused 1x1 skip convolution of skip = (s0, s1, name) (pdae_conv2d_fwd_skip); None if not eligible."""
+        N, Hh, W, C0 = x.shape
+        w, b = self.P[wname + ".weight"], self.P[wname + ".bias"]
+        c = H.Conv(N, Hh, W, C0, 0, w.shape[0], k=3, math=self.math)
+        if c.wprep_bytes(0) == 0:
+            return None
+        sp = self._skip_parts(c, skip)
+        if sp is None:
+            return None
+        cs, s0, s1, wps, bs, cs_ctx = sp
+        wp = self._wprep(c, w, 0)
+        y = self.p.buf(N, c.Ho, c.Wo, c.Cout)
+        self.p.emit(H.op_conv_fwd_skip(c, x, None, None, 0, wp, b, cs, s0, s1, wps, bs, y))
+        self.p.free(wp, wps)
+        return y, NS(c=c, x0=x, x1=None, wname=wname, y=y), cs_ctx
+
+    def gn_conv(self, x0, x1, gname, wname, ss=None, zss=None, up=False, res=None, res_mode=0, skip=None):
         """GroupNorm [+AdaGN] + SiLU + 3x3 conv with the normalisation applied inside the conv's patch staging (pdae_conv2d_fwd_gn): the
         activated tensor is never written.  Forward-only stages (nothing saved for a backward); returns None when the conv is not
         eligible for the fused kernel."""
@@ -252,6 +284,9 @@ class Builder:
         c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=3, up=up, math=self.math)
         if c.wprep_bytes(0, gn=True) == 0:
             return None
+        sp = self._skip_parts(c, skip)
+        if skip is not None and sp is None:
+            return None
         pl = self.p
         gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]
         pl.need_ws(H.gn_ws_bytes(N, C))
@@ -260,7 +295,12 @@ class Builder:
         pl.emit(H.op_gn_coef(N, C, GROUPS, mean, rstd, gamma, beta, ss, zss, coef))
         wp = self._wprep(c, w, 0, gn=True)
         y = pl.buf(N, c.Ho, c.Wo, c.Cout)
-        pl.emit(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, b, y, res=res, res_mode=res_mode))
+        if sp is not None:
+            cs, s0, s1, wps, bs, _ = sp
+            pl.emit(H.op_conv_fwd_skip(c, x0, x1, coef, 1, wp, b, cs, s0, s1, wps, bs, y))
+            pl.free(wps)
+        else:
+            pl.emit(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, b, y, res=res, res_mode=res_mode))
         pl.free(mean, rstd, coef, wp)
         return y
 
@@ -325,27 +365,38 @@ class Builder:
         zss, l_zss = (None, None)
         if eza is not None:
             zss, l_zss = self.linear(eza, pre + ".emb_z_layers.1")
-        cs = None
-        if has_skip:
-            res, cs = self.conv(x0, x1, pre + ".skip_connection", 1)
-            res_mode = 1
-        elif down:
+        cs = g2 = c2 = out = None
+        skip = (x0, x1, pre + ".skip_connection") if has_skip else None
+        res, res_mode = None, 0
+        if down:
             res, res_mode = g1.xpool, 1
-        else:
+        elif not has_skip:
             res, res_mode = x0, (2 if up else 1)
-        g2 = c2 = None
-        out = None
-        if not (dropout and self.drop_p > 0):
-            out = self.gn_conv(h1, None, pre + ".out_layers.0", pre + ".out_layers.3", ss=ss, zss=zss, res=res, res_mode=res_mode)
+        plain_drop = dropout and self.drop_p > 0
+        # 1) forward-only: GN + SiLU + conv2 (+ skip conv) in one launch
+        if not plain_drop:
+            out = self.gn_conv(h1, None, pre + ".out_layers.0", pre + ".out_layers.3", ss=ss, zss=zss, res=res, res_mode=res_mode, skip=skip)
+            if out is None and has_skip and not self.save:
+                # skip not fusable: fused GN with the separately computed skip as residual
+                res, cs = self.conv(x0, x1, pre + ".skip_connection", 1)
+                res_mode, skip = 1, None
+                out = self.gn_conv(h1, None, pre + ".out_layers.0", pre + ".out_layers.3", ss=ss, zss=zss, res=res, res_mode=1)
         if out is None:
             g2 = self.gn(h1, None, pre + ".out_layers.0", ss=ss, zss=zss, act=1, mode=0, dropout=dropout)
-            out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=res, res_mode=res_mode)
+            r = self.conv_skip(g2.y, pre + ".out_layers.3", skip) if skip is not None else None
+            if r is not None:                         # 2) materialised GN output, skip conv fused into conv2
+                out, c2, cs = r
+            else:                                     # 3) separate kernels
+                if skip is not None:
+                    res, cs = self.conv(x0, x1, pre + ".skip_connection", 1)
+                    res_mode = 1
+                out, c2 = self.conv(g2.y, None, pre + ".out_layers.3", 3, res=res, res_mode=res_mode)
             if not self.save:
                 pl.free(g2.y)
         if not self.save:
             pl.free(h1, ss, zss)
-        if has_skip:
-            pl.free(res)                     # never needed by backward
+        if has_skip and res is not None:
+            pl.free(res)                     # the separately computed skip tensor is never needed by backward
         elif down:
             pl.free(g1.xpool)
         return out, NS(pre=pre, g1=g1, c1=c1, l_ss=l_ss, l_zss=l_zss, g2=g2, c2=c2, cs=cs, up=up, down=down, has_skip=has_skip, h1=h1)

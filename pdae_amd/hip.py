@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
- OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN) = range(1, 31)
+ OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP) = range(1, 32)
 
 
 class PdaeOp(ctypes.Structure):
@@ -67,7 +67,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_adam_ema", "pdae_run_ops"]
@@ -164,6 +164,16 @@ def op_conv_fwd(c, x0, x1, w, bias, y, res=None, res_mode=0, tile=0, wp=None):
 def op_conv_fwd_gn(c, x0, x1, coef, act, wp, bias, y, res=None, res_mode=0):
     """conv of act(GN-affine(x)): GroupNorm/AdaGN(+SiLU) applied in the patch staging (pdae_conv2d_fwd_gn)."""
     return make_op(OP_CONV_FWD_GN, [x0, x1, coef, wp, bias, res, y], c.fields() + [res_mode, act])
+
+
+def op_conv_fwd_skip(c, x0, x1, coef, act, wp, bias, cs, s0, s1, wps, bias_s, y):
+    """y = conv3x3_c(in) + bias + conv1x1_cs([s0 | s1]) + bias_s in one launch (pdae_conv2d_fwd_skip)."""
+    return make_op(OP_CONV_FWD_SKIP, [x0, x1, coef, wp, bias, s0, s1, wps, bias_s, y], c.fields() + [act, cs.C0, cs.C1])
+
+
+def conv_fwd_skip_ok(c, cs):
+    d, ds = c.cdesc(), cs.cdesc()
+    return bool(lib().pdae_conv2d_fwd_skip_ok(ctypes.byref(d), ctypes.byref(ds)))
 
 
 def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0, wp_t=None):

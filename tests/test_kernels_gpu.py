@@ -539,3 +539,41 @@ def test_conv_with_fused_groupnorm_input(H, case, math_mode):
     y2 = torch.empty_like(y)
     H.run(H.op_conv_fwd(c1, a, None, wd, bd, y2, res=resd, res_mode=res_mode))
     assert rel_err(y, y2) < tol
+
+
+@pytest.mark.parametrize("math_mode", [1, 3])
+@pytest.mark.parametrize("case", [(16, 64, 32, 64, 64, 32, 64, True), (16, 64, 32, 64, 96, 0, 128, False), (32, 32, 32, 32, 32, 32, 32, True)])
+def test_conv_with_fused_skip_connection(H, case, math_mode):
+    """pdae_conv2d_fwd_skip: conv3x3(in) + conv1x1([s0 | s1]) + both biases in one launch, with plain and fused-GroupNorm main input."""
+    N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
+    Cs, G = Cs0 + Cs1, 32
+    tol = MATH_TOL[math_mode]
+    x = rn(1, N, C, Hh, W) * 1.2 + 0.3
+    sx = rn(2, N, Cs, Hh, W)
+    w = rn(3, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(4, Cout, scale=0.1)
+    wsk = rn(5, Cout, Cs, 1, 1, scale=1.0 / math.sqrt(Cs)); bsk = rn(6, Cout, scale=0.1)
+    gamma, beta = 1 + 0.2 * rn(7, C), 0.2 * rn(8, C) + 0.4
+    c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=math_mode)
+    cs = H.Conv(N, Hh, W, Cs0, Cs1, Cout, k=1, math=math_mode)
+    assert H.conv_fwd_skip_ok(c, cs)
+    a_ref = _gn_ref(x.double(), gamma.double(), beta.double(), None, None, 1) if use_gn else x.double()
+    y_ref = ref_conv(a_ref, w, b, 1, 1, 0) + F.conv2d(sx.double(), wsk.double(), bsk.double())
+    xd = nhwc(x).cuda()
+    sh = nhwc(sx).cuda()
+    s0 = sh[..., :Cs0].contiguous()
+    s1 = sh[..., Cs0:].contiguous() if Cs1 else None
+    wd, wsd = nhwc(w).cuda(), nhwc(wsk).cuda()
+    coef = None
+    if use_gn:
+        mean = torch.empty(N * G, device="cuda"); rstd = torch.empty(N * G, device="cuda")
+        H.run(H.op_gn_stats(xd, C, None, 0, N, Hh * W, G, 1e-5, mean, rstd, ws(H.gn_ws_bytes(N, C))))
+        coef = torch.empty(3, N, C, device="cuda")
+        H.run(H.op_gn_coef(N, C, G, mean, rstd, gamma.cuda(), beta.cuda(), None, None, coef))
+    nb = c.wprep_bytes(0, force=True, gn=use_gn)
+    wp = torch.empty(nb // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 4 if use_gn else 0, wp))
+    wps = torch.empty(cs.wprep_bytes(0) // 4, device="cuda")
+    H.run(H.op_conv_wprep(cs, wsd, 0, wps))
+    y = torch.empty(N, Hh, W, Cout, device="cuda")
+    H.run(H.op_conv_fwd_skip(c, xd, None, coef, 1, wp, b.cuda(), cs, s0, s1, wps, bsk.cuda(), y))
+    assert rel_err(nchw(y), y_ref) < tol
