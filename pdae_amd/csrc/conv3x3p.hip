@@ -270,33 +270,43 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
+    const int g = wm * 2 + a, bx = g & 3;
+    // destination rows of the 8 float4 this lane stores, and the residual / accumulate operands: all loads are issued up front
+    // so that their latency runs under the LDS transposition instead of serialising the 8 stores
+    long long rowv[8];
+    float4 rv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = it * 4 + er;
+      const int oy = y0 + (g >> 2) * 8 + (i >> 2);
+      const int ox = W8 ? (bx & 1) * 4 + (i & 3) : x0 + bx * 4 + (i & 3);
+      const int im = W8 ? img + (bx >> 1) : img;
+      rowv[it] = (oy >= P.H || ox >= P.W || im >= P.N || colb >= P.Nout) ? -1 : ((long long)im * P.H + oy) * P.W + ox;
+      rv[it] = bias4;
+      if (rowv[it] >= 0 && P.splits == 1) {
+        if (P.res_mode) {
+          long long rrow = rowv[it];
+          if (P.res_mode == 2) rrow = ((long long)im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
+          const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + colb);
+          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+        }
+        if (P.accumulate) {
+          const float4 u = *reinterpret_cast<const float4*>(P.y + rowv[it] * P.Nout + colb);
+          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+        }
+      }
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + b * 32 + li] = acc[a][b][r];
-    const int g = wm * 2 + a, bx = g & 3;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int i = it * 4 + er;
-      float4 v = *reinterpret_cast<const float4*>(&tw[i * EPW + ec]);
-      const int oy = y0 + (g >> 2) * 8 + (i >> 2);
-      const int ox = W8 ? (bx & 1) * 4 + (i & 3) : x0 + bx * 4 + (i & 3);
-      const int im = W8 ? img + (bx >> 1) : img;
-      if (oy >= P.H || ox >= P.W || im >= P.N || colb >= P.Nout) continue;
-      const long long row = ((long long)im * P.H + oy) * P.W + ox;
-      const bool full = colb + 3 < P.Nout;                // Nout % 4 == 0 => always true when colb < Nout
-      (void)full;
-      if (P.splits > 1) { *reinterpret_cast<float4*>(P.slab + ((long long)sp * Mtot + row) * P.Nout + colb) = v; continue; }
-      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      if (P.res_mode) {
-        long long rrow = row;
-        if (P.res_mode == 2) rrow = ((long long)im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
-        const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + colb);
-        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-      }
-      float4* dst = reinterpret_cast<float4*>(P.y + row * P.Nout + colb);
-      if (P.accumulate) { const float4 u = *dst; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-      *dst = v;
+      float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * EPW + ec]);
+      if (rowv[it] < 0) continue;
+      if (P.splits > 1) { *reinterpret_cast<float4*>(P.slab + ((long long)sp * Mtot + rowv[it]) * P.Nout + colb) = v; continue; }
+      v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
+      *reinterpret_cast<float4*>(P.y + rowv[it] * P.Nout + colb) = v;
     }
   }
 }
