@@ -57,6 +57,8 @@ def op_flops(op):
     if op.kind in (H.OP_CONV_FWD, H.OP_CONV_WGRAD, H.OP_CONV_FWD_GN):
         N, Ho, Wo, Cout, KH, KW, cin = i[0], i[5], i[6], i[7], i[8], i[9], i[3] + i[4]
         return 2.0 * N * Ho * Wo * Cout * KH * KW * cin
+    if op.kind == H.OP_CONV_FWD_SKIP:                 # 3x3 conv + the 1x1 skip convolution riding in its K loop
+        return 2.0 * i[0] * i[5] * i[6] * i[7] * (9 * (i[3] + i[4]) + i[15] + i[16])
     if op.kind == H.OP_CONV_DGRAD:
         N, Hi, Wi, Cout, KH, KW, up = i[0], i[1], i[2], i[7], i[8], i[9], i[12]
         s = 2 if up else 1
@@ -238,15 +240,17 @@ def main():
         out["dtype"] = "f32" if math == "f32" else ("bf16" if math == "bf16" else f"f32 as {math} split-bf16 MFMA, fp32 accumulate")
         # dominant kernel: conv3x3p_kernel (3x3 forward + data gradient on the patch path = ops that carry prepared weights)
         def is_patch(op):
-            fwd = op.kind in (H.OP_CONV_FWD, H.OP_CONV_FWD_GN)
+            fwd = op.kind in (H.OP_CONV_FWD, H.OP_CONV_FWD_GN, H.OP_CONV_FWD_SKIP)
             wl = op.i[6] if fwd else op.i[2] * (2 if op.i[12] else 1)
             if op.i[8] != 3 or wl == 8:               # 8-pixel-wide layers run the image-pair instantiation: a different kernel symbol
                 return False
-            return op.kind == H.OP_CONV_FWD_GN or (op.kind == H.OP_CONV_FWD and bool(op.p[6])) or (op.kind == H.OP_CONV_DGRAD and bool(op.p[3]))
+            return op.kind in (H.OP_CONV_FWD_GN, H.OP_CONV_FWD_SKIP) or (op.kind == H.OP_CONV_FWD and bool(op.p[6])) or (op.kind == H.OP_CONV_DGRAD and bool(op.p[3]))
 
         def patch_bytes(op):                          # algorithmic HBM bytes of one launch: input + output (+ residual) once, fp32
             i = op.i
             N, Hi, Wi, Cin, Ho, Wo, Cout, up = i[0], i[1], i[2], i[3] + i[4], i[5], i[6], i[7], i[12]
+            if op.kind == H.OP_CONV_FWD_SKIP:
+                return 4.0 * N * (Hi * Wi * Cin + Ho * Wo * (Cout + i[15] + i[16])) + 6.0 * Cout * (9 * Cin + i[15] + i[16])
             if op.kind in (H.OP_CONV_FWD, H.OP_CONV_FWD_GN):
                 has_res = bool(op.p[4]) if op.kind == H.OP_CONV_FWD else bool(op.p[5])
                 return 4.0 * N * (Hi * Wi * Cin + Ho * Wo * Cout * (2 if has_res else 1)) + 6.0 * Cout * 9 * Cin

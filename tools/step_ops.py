@@ -18,10 +18,10 @@ st.step(x0); st.load_batch(x0)
 durs = bench.profile_plan(st.plan, 0, st.n_bwd)
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 gb = 0.0
-names = {1: "fwd", 2: "dgrad", 3: "wgrad", 4: "gemm", 30: "fwd"}
+names = {1: "fwd", 2: "dgrad", 3: "wgrad", 4: "gemm", 30: "fwd", 31: "fwd+sk"}
 for k, d in enumerate(durs):
     op = st.plan.arr[k]; i = op.i
-    if op.kind in (1, 2, 3, 30):
+    if op.kind in (1, 2, 3, 30, 31):
         patch = (i[8] == 3 and i[10] == 1 and i[4] == 0 and i[3] % 32 == 0 and i[5] % 8 == 0 and i[6] % 16 == 0)
         key = (names[op.kind], f"N{i[0]} {i[1]}x{i[2]} {i[3]}+{i[4]}->{i[7]} k{i[8]} s{i[10]} up{i[12]}", "P" if patch else "-")
     elif op.kind == 4:
@@ -37,7 +37,7 @@ for k, d in enumerate(durs):
         key = ("colsum", f"M{i[0]} C{i[1]}", "-"); gb = 4.0 * i[0] * i[1]
     else:
         key = (f"kind{op.kind}", "", "-")
-    a = agg[key]; a[0] += 1; a[1] += d; a[2] += bench.op_flops(op) if (op.kind < 5 or op.kind == 30) else gb * 1e3; gb = 0.0
+    a = agg[key]; a[0] += 1; a[1] += d; a[2] += bench.op_flops(op) if (op.kind < 5 or op.kind in (30, 31)) else gb * 1e3; gb = 0.0
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 tot = sum(durs)
 print(f"total {tot:.1f} ms")
