@@ -95,6 +95,9 @@ size_t pdae_gn_workspace_bytes(int N, int C);
 int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, void* ws,
                   pdae_stream_t stream);
 /* coef[3][N][C] = (mu, a, b) such that v = a*(x-mu)+b equals (1+zs)*((GN(x))*(1+s)+sh)+zsh; ss/zss = [N][2C] (scale|shift) or NULL */
+/* pdae_gn_stats followed by pdae_gn_coef with the finalize and the coefficient fold in ONE launch (two launches instead of three) */
+int pdae_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma, const float* beta,
+                       const float* ss, const float* zss, float* mean, float* rstd, float* coef, void* ws, pdae_stream_t stream);
 int pdae_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss,
                  const float* zss, float* coef, pdae_stream_t stream);
 /* y = act(v) * dropmask; act: 0 identity, 1 SiLU.  mode 0: same size; mode 1: y (and xpool = raw x) are 2x2 average pooled. */
@@ -151,7 +154,7 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF
 };
 typedef struct pdae_op {
   int32_t kind;

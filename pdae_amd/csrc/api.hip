@@ -262,6 +262,12 @@ extern "C" int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, i
   PDAE_CHECK_ARG(x0 && mean && rstd && ws && (C1 == 0 || x1), "gn_stats: null pointer");
   return k_gn_stats(x0, C0, x1, C1, N, HW, G, eps, mean, rstd, (float*)ws, S(stream));
 }
+extern "C" int pdae_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma,
+                                  const float* beta, const float* ss, const float* zss, float* mean, float* rstd, float* coef, void* ws,
+                                  pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x0 && gamma && beta && mean && rstd && coef && ws && (C1 == 0 || x1) && (C0 + C1) % G == 0, "gn_stats_coef: bad arguments");
+  return k_gn_stats_coef(x0, C0, x1, C1, N, HW, G, eps, gamma, beta, ss, zss, mean, rstd, coef, (float*)ws, S(stream));
+}
 extern "C" int pdae_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss,
                             const float* zss, float* coef, pdae_stream_t stream) {
   PDAE_CHECK_ARG(mean && rstd && gamma && beta && coef && C % G == 0, "gn_coef: bad arguments");
@@ -372,6 +378,9 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
       return pdae_gemm((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), i[5], i[6], i[7], F(1), i[8], i[9], i[10], FM(2),
                        i[11], i[12], i[13], (int)i[14], (int)i[15], F(3), (int)i[16], st);
     case PDAE_OP_GN_STATS: return pdae_gn_stats(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], FM(2), FM(3), p[4], st);
+    case PDAE_OP_GN_STATS_COEF:
+      return pdae_gn_stats_coef(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(2), F(3), F(4), F(5), FM(6), FM(7),
+                                FM(8), p[9], st);
     case PDAE_OP_GN_COEF: return pdae_gn_coef((int)i[0], (int)i[1], (int)i[2], F(0), F(1), F(2), F(3), F(4), F(5), FM(6), st);
     case PDAE_OP_GN_APPLY:
       return pdae_gn_apply(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], F(2), (int)i[5], (int)i[6], FM(3), FM(4), (float)f[0],

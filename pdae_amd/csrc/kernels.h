@@ -5,6 +5,8 @@
 
 size_t k_gn_workspace_floats(int N, int C);
 int k_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, float* ws, hipStream_t st);
+int k_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma, const float* beta,
+                    const float* ss, const float* zss, float* mean, float* rstd, float* coef, float* ws, hipStream_t st);
 int k_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss, const float* zss,
               float* coef, hipStream_t st);
 int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, const float* coef, int act, int mode, float* y, float* xpool,

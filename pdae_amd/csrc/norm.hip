@@ -128,6 +128,40 @@ __global__ void gn_coef_kernel(int N, int C, int G, const float* __restrict__ me
   coef[(size_t)2 * N * C + i] = b;
 }
 
+// statistics finalize + coefficient fold in one launch: block = sample n; waves reduce the per-chunk partials of their groups
+// (double butterfly), then all threads write the per-(n,c) coefficients
+__global__ void __launch_bounds__(256) gn_finalize_coef_kernel(Src2 s, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ ss, const float* __restrict__ zss,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ coef) {
+  __shared__ float smean[64], srstd[64];
+  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, cg = C / G;
+  for (int g = t >> 6; g < G; g += 4) {
+    double a = 0.0, b = 0.0;
+    for (int k = lane; k < S; k += 64) { const float* o = part + (((size_t)n * S + k) * G + g) * 2; a += o[0]; b += o[1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if (lane == 0) {
+      const double cnt = (double)cg * HW, K = ld1(s, (size_t)n * HW, g * cg), m = a / cnt;
+      double var = b / cnt - m * m;
+      if (var < 0.0) var = 0.0;
+      smean[g] = (float)(K + m); srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+      mean[n * G + g] = smean[g]; rstd[n * G + g] = srstd[g];
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int g = c / cg;
+    float k = gamma[c] * srstd[g], b = beta[c];
+    if (ss) { float sc = 1.0f + ss[(size_t)n * 2 * C + c]; k *= sc; b = b * sc + ss[(size_t)n * 2 * C + C + c]; }
+    if (zss) { float sc = 1.0f + zss[(size_t)n * 2 * C + c]; k *= sc; b = b * sc + zss[(size_t)n * 2 * C + C + c]; }
+    const size_t i = (size_t)n * C + c;
+    coef[i] = smean[g];
+    coef[(size_t)N * C + i] = k;
+    coef[(size_t)2 * N * C + i] = b;
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // apply: y = act(a*(x-mu)+b) [* dropmask]; mode 0 = same resolution, 1 = 2x2 average pool of y
 // (and of raw x into xpool when given).  One thread per output float4.
@@ -411,6 +445,18 @@ int k_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, 
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, N), dim3(256), 0, st, s, HW, C, G, chunk, ws);
   hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, st, s, N, HW, C, G, S, eps, ws, mean, rstd);
   return pdae_launch_status("gn_stats");
+}
+
+int k_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma, const float* beta,
+                    const float* ss, const float* zss, float* mean, float* rstd, float* coef, float* ws, hipStream_t st) {
+  if (int e = check_c(C0, C1, G)) return e;
+  const int C = C0 + C1;
+  Src2 s{x0, x1, C0, C1};
+  int S = stats_chunks(HW, C), chunk = cdiv(HW, S);
+  S = cdiv(HW, chunk);
+  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, N), dim3(256), 0, st, s, HW, C, G, chunk, ws);
+  hipLaunchKernelGGL(gn_finalize_coef_kernel, dim3(N), dim3(256), 0, st, s, N, HW, C, G, S, eps, ws, gamma, beta, ss, zss, mean, rstd, coef);
+  return pdae_launch_status("gn_stats_coef");
 }
 
 int k_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss,

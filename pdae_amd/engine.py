@@ -291,8 +291,7 @@ class Builder:
         gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]
         pl.need_ws(H.gn_ws_bytes(N, C))
         mean, rstd, coef = pl.buf(N * GROUPS), pl.buf(N * GROUPS), pl.buf(3, N, C)
-        pl.emit(H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, mean, rstd, None), ws_slot=4)
-        pl.emit(H.op_gn_coef(N, C, GROUPS, mean, rstd, gamma, beta, ss, zss, coef))
+        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None), ws_slot=9)
         wp = self._wprep(c, w, 0, gn=True)
         y = pl.buf(N, c.Ho, c.Wo, c.Cout)
         if sp is not None:
@@ -316,8 +315,7 @@ class Builder:
         Ho, Wo = (Hh // 2, W // 2) if mode == 1 else (Hh, W)
         y = pl.buf(N, Ho, Wo, C)
         xpool = pl.buf(N, Ho, Wo, C) if (mode == 1 and want_xpool) else None
-        pl.emit(H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, mean, rstd, None), ws_slot=4)
-        pl.emit(H.op_gn_coef(N, C, GROUPS, mean, rstd, gamma, beta, ss, zss, coef))
+        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None), ws_slot=9)
         dp = self.drop_p if dropout else 0.0
         layer = 0
         if dp > 0:

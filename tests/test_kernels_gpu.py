@@ -202,6 +202,10 @@ def test_groupnorm_family(H, case):
     assert rel_err(rstd, 1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5).flatten()) < 1e-5
     coef = torch.empty(3, N, C, device="cuda")
     H.run(H.op_gn_coef(N, C, G, mean, rstd, f32(gamma), f32(beta), f32(ss), f32(zss), coef))
+    # the two-launch form (statistics partials + fused finalize / coefficient fold) must give the same numbers
+    mean2, rstd2, coef2 = torch.empty_like(mean), torch.empty_like(rstd), torch.empty_like(coef)
+    H.run(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, G, 1e-5, f32(gamma), f32(beta), f32(ss), f32(zss), mean2, rstd2, coef2, wsp))
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2) and torch.equal(coef, coef2)
     Ho, Wo = (Hh // 2, W // 2) if mode == 1 else (Hh, W)
     y = torch.empty(N, Ho, Wo, C, device="cuda")
     xp = torch.empty(N, Ho, Wo, C, device="cuda") if mode == 1 else None
