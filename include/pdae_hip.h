@@ -78,9 +78,10 @@ int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* 
  * whole channel range only; 1x1: any 32-aligned ci_off). */
 int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
                       int accumulate, int tile, pdae_stream_t stream);
-/* dw[Cout][KH][KW][Cin] (+)= sum over pixels; split-K over pixels through the workspace, reduced in fixed order. */
+/* dw[Cout][KH][KW][Cin] (+)= sum over pixels; split-K over pixels through the workspace, reduced in fixed order.
+ * db (optional) [Cout] (+)= column sums of dy = the bias gradient; the 3x3 kernel takes them from its own dY staging (no second read of dy). */
 size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d);
-int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, int accumulate, void* ws,
+int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, float* db, int accumulate, void* ws,
                       size_t ws_bytes, pdae_stream_t stream);
 
 /* ---- strided-batched GEMM (F.linear, torch.einsum of module.py:450-457 / 479-488, and their backward)

@@ -201,25 +201,46 @@ static void wgrad_plan(const pdae_conv_desc* d, int& tile, int& splits, int& kch
   splits = cdiv(K, kchunk);
 }
 
-extern "C" size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d) {
+// workspace of the weight gradient proper (slabs / partials), 256-byte aligned; the bias-gradient column-sum scratch follows it
+static size_t wgrad_path_bytes(const pdae_conv_desc* d) {
+  size_t b;
   if (convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
-    return convhead_wgrad_workspace_bytes(d->N, d->Hi, d->Wi, d->C0, d->Cout);
-  if (conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout))
-    return conv3x3w_workspace_bytes(d->N, d->Ho, d->Wo, d->C0, d->Cout);
-  int tile, splits, kchunk;
-  wgrad_plan(d, tile, splits, kchunk);
-  if (splits <= 1) return 16;
-  return (size_t)splits * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
+    b = convhead_wgrad_workspace_bytes(d->N, d->Hi, d->Wi, d->C0, d->Cout);
+  else if (conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout))
+    b = conv3x3w_workspace_bytes(d->N, d->Ho, d->Wo, d->C0, d->Cout);
+  else {
+    int tile, splits, kchunk;
+    wgrad_plan(d, tile, splits, kchunk);
+    b = splits <= 1 ? 16 : (size_t)splits * d->Cout * d->KH * d->KW * (d->C0 + d->C1) * sizeof(float);
+  }
+  return (b + 255) & ~(size_t)255;
 }
 
-extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, int accumulate, void* ws,
-                                 size_t ws_bytes, pdae_stream_t stream) {
+extern "C" size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d) {
+  return wgrad_path_bytes(d) + k_colsum_workspace_floats((long long)d->N * d->Ho * d->Wo, d->Cout) * sizeof(float);
+}
+
+extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, float* db, int accumulate,
+                                 void* ws, size_t ws_bytes, pdae_stream_t stream) {
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "conv2d_wgrad: null pointer");
-  if (convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
-    return convhead_wgrad(x0, d->N, d->Hi, d->Wi, d->C0, dy, d->Cout, dw, accumulate, (float*)ws, ws_bytes, S(stream));
-  if (conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout))
-    return conv3x3w_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, dy, d->Cout, dw, accumulate, (float*)ws, ws_bytes, S(stream));
+  const size_t pb = wgrad_path_bytes(d);
+  const long long Mpix = (long long)d->N * d->Ho * d->Wo;
+  PDAE_CHECK_ARG(!db || (ws && ws_bytes >= pb + k_colsum_workspace_floats(Mpix, d->Cout) * sizeof(float)),
+                 "conv2d_wgrad: workspace too small for the bias gradient (%zu < pdae_conv2d_wgrad_workspace_bytes)", ws_bytes);
+  float* cws = ws ? (float*)((char*)ws + pb) : nullptr;                 // column-sum scratch
+  const size_t wsb = ws_bytes < pb ? ws_bytes : pb;                     // what the weight-gradient path may use
+  if (convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout)) {
+    if (int e = convhead_wgrad(x0, d->N, d->Hi, d->Wi, d->C0, dy, d->Cout, dw, accumulate, (float*)ws, wsb, S(stream))) return e;
+    return db ? k_colsum(dy, Mpix, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;
+  }
+  if (conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout)) {
+    float* part = nullptr; int rows = 0;                                  // bias gradient: column sums of dY fall out of the dY staging
+    if (int e = conv3x3w_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, dy, d->Cout, dw, accumulate, (float*)ws, wsb, S(stream),
+                                db ? &part : nullptr, db ? &rows : nullptr))
+      return e;
+    return db ? k_colsum(part, rows, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;
+  }
   int tile, splits, kchunk;
   wgrad_plan(d, tile, splits, kchunk);
   GemmParams P;
@@ -231,13 +252,15 @@ extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const
   const long long MN = (long long)P.M * P.N;
   if (splits <= 1) {
     P.splitk = 1; P.kchunk = P.K; P.C = dw; P.ldc = P.N; P.accumulate = accumulate;
-    return igemm_conv_wgrad(P, tile, 1, d->math, S(stream));
+    if (int e = igemm_conv_wgrad(P, tile, 1, d->math, S(stream))) return e;
+  } else {
+    PDAE_CHECK_ARG(ws && wsb >= (size_t)splits * MN * sizeof(float), "conv2d_wgrad: workspace too small (%zu < %zu)", wsb,
+                   (size_t)splits * MN * sizeof(float));
+    P.splitk = splits; P.kchunk = kchunk; P.split_stride = MN; P.C = (float*)ws; P.ldc = P.N; P.accumulate = 0;
+    if (int e = igemm_conv_wgrad(P, tile, splits, d->math, S(stream))) return e;
+    if (int e = igemm_splitk_reduce((const float*)ws, dw, MN, splits, accumulate, S(stream))) return e;
   }
-  PDAE_CHECK_ARG(ws && ws_bytes >= (size_t)splits * MN * sizeof(float), "conv2d_wgrad: workspace too small (%zu < %zu)", ws_bytes,
-                 (size_t)splits * MN * sizeof(float));
-  P.splitk = splits; P.kchunk = kchunk; P.split_stride = MN; P.C = (float*)ws; P.ldc = P.N; P.accumulate = 0;
-  if (int e = igemm_conv_wgrad(P, tile, splits, d->math, S(stream))) return e;
-  return igemm_splitk_reduce((const float*)ws, dw, MN, splits, accumulate, S(stream));
+  return db ? k_colsum(dy, Mpix, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;
 }
 
 extern "C" int pdae_gemm(int transA, int transB, int M, int N, int K, float alpha, const float* A, int64_t lda, int64_t sAo, int64_t sAi,
@@ -373,7 +396,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
   switch (o.kind) {
     case PDAE_OP_CONV_FWD: desc_from(i, d); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), p[6], F(3), F(4), (int)i[14], FM(5), (int)i[15], st);
     case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), p[3], FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], st);
-    case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), (int)i[14], p[4], (size_t)i[15], st);
+    case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), FM(5), (int)i[14], p[4], (size_t)i[15], st);
     case PDAE_OP_GEMM:
       return pdae_gemm((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), i[5], i[6], i[7], F(1), i[8], i[9], i[10], FM(2),
                        i[11], i[12], i[13], (int)i[14], (int)i[15], F(3), (int)i[16], st);

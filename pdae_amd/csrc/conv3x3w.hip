@@ -69,6 +69,7 @@ struct WgradParams {
   int tiles_x, tiles_y, ntiles;          // pixel tiles per image / total
   int tiles_per_split, splits;
   int co_tiles, ci_chunks;
+  float* db_part;                        // optional bias-gradient partials [splits][Cout] (column sums of dY, written by the ci_chunk 0 blocks)
 };
 
 template <int NS>
@@ -100,6 +101,11 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
   const unsigned sX_base = 0u, sY_base = (unsigned)(SX * 2);   // LDS byte offsets: the dynamic segment is the only LDS of this kernel
 
   float4 xpre[WX_LD], ypre[WY_LD];
+  const bool want_db = P.db_part != nullptr && ci_chunk == 0;       // this block also owns the column sums of its dY tiles
+  // per-thread running column sums live in LDS behind the operand planes (thread-private slots: deterministic, no registers held
+  // across the MFMA phase -- the kernel sits at the 256-VGPR limit); thread: output channels (t & 31) * 4 .. +3, pixels idx >> 5
+  float4* bred = reinterpret_cast<float4*>(smem + SX + NS * WTPIX * WSY);
+  if (want_db) bred[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int tile) {
     int img = tile / (P.tiles_y * P.tiles_x); int rem = tile - img * P.tiles_y * P.tiles_x;
     int ty = rem / P.tiles_x, tx = rem - ty * P.tiles_x;
@@ -135,6 +141,12 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
 #pragma unroll
         for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sX[(p * WNPIX + pix) * WSX + qd * 4]) = make_uint2(u[p], v[p]);
       }
+    }
+    if (want_db) {
+      float4 b4 = bred[t];
+#pragma unroll
+      for (int l = 0; l < WY_LD; ++l) { b4.x += ypre[l].x; b4.y += ypre[l].y; b4.z += ypre[l].z; b4.w += ypre[l].w; }
+      bred[t] = b4;
     }
 #pragma unroll
     for (int l = 0; l < WY_LD; ++l) {
@@ -186,6 +198,15 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
     }
   }
 
+  if (P.db_part != nullptr) {                 // bias gradient: 16 threads share each channel quad -> LDS -> fixed-order sum
+    __syncthreads();
+    if (want_db && t < 32) {
+      float4 s4 = bred[t];
+      for (int k = 1; k < 16; ++k) { const float4 u = bred[t + 32 * k]; s4.x += u.x; s4.y += u.y; s4.z += u.z; s4.w += u.w; }
+      const int co = co0 + t * 4;
+      if (co < Cout) *reinterpret_cast<float4*>(P.db_part + (size_t)split * Cout + co) = s4;      // Cout % 4 == 0
+    }
+  }
   // epilogue: slab (split*2 + kh) of the workspace, layout [Cout][9][C]
   float* slab = P.ws + (size_t)(split * 2 + kh) * Cout * 9 * C;
 #pragma unroll
@@ -222,14 +243,15 @@ bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, i
   return (long long)N * (H / WTH) * (W / WTW) >= 64;
 }
 
+// slabs [2*splits][Cout][9][C] + bias-gradient partials [splits][Cout]
 size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout) {
   int splits, tps;
   wgradp_plan(N, H, W, C, Cout, splits, tps);
-  return (size_t)splits * 2 * Cout * 9 * C * sizeof(float);
+  return ((size_t)splits * 2 * Cout * 9 * C + (size_t)splits * Cout) * sizeof(float);
 }
 
 template <int NS> static int launch_w(const WgradParams& P, hipStream_t s) {
-  const size_t smem = (size_t)(NS * WNPIX * WSX + NS * WTPIX * WSY) * sizeof(unsigned short);
+  const size_t smem = (size_t)(NS * WNPIX * WSX + NS * WTPIX * WSY) * sizeof(unsigned short) + WTHREADS * sizeof(float4);   // + bias-sum slots
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3w_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -241,13 +263,15 @@ template <int NS> static int launch_w(const WgradParams& P, hipStream_t s) {
 }
 
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
-                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s) {
+                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows) {
   WgradParams P;
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.dy = dy; P.Cout = Cout; P.ws = ws;
   P.tiles_x = W / WTW; P.tiles_y = H / WTH; P.ntiles = N * P.tiles_x * P.tiles_y;
   wgradp_plan(N, H, W, C, Cout, P.splits, P.tiles_per_split);
   P.co_tiles = (Cout + 127) / 128; P.ci_chunks = C / 32;
-  const size_t need = (size_t)P.splits * 2 * Cout * 9 * C * sizeof(float);
+  const size_t need = ((size_t)P.splits * 2 * Cout * 9 * C + (size_t)P.splits * Cout) * sizeof(float);
+  P.db_part = db_part ? ws + (size_t)P.splits * 2 * Cout * 9 * C : nullptr;
+  if (db_part) { *db_part = P.db_part; *db_rows = P.splits; }
   if (!ws || ws_bytes < need) { pdae_set_error("conv3x3w: workspace too small (%zu < %zu)", ws_bytes, need); return PDAE_EINVAL; }
   int e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : launch_w<3>(P, s));
   if (e) return e;

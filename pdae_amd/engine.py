@@ -136,6 +136,7 @@ class Builder:
 
     def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False, math=None, frozen_of=None):
         self.p = plan
+        self.fuse_db = os.environ.get("PDAE_FUSE_DB", "1") != "0"      # bias gradients ride in the weight-gradient launch
         self.fuse_skip = os.environ.get("PDAE_FUSE_SKIP", "1") != "0"  # ResBlock skip_connection rides in conv2's K loop (conv_skip)
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
         self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
@@ -191,11 +192,16 @@ class Builder:
         """dW, db of a conv stage (only if the parameter is trained by this plan)."""
         c = cx.c
         gw = self.Gr.get(cx.wname + ".weight")
+        gb = self.Gr.get(cx.wname + ".bias")
         if gw is not None:
             wsb = c.wgrad_ws_bytes()
             self.p.need_ws(wsb)
-            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc), ws_slot=4, wsb_slot=len(c.fields()) + 1)
-        gb = self.Gr.get(cx.wname + ".bias")
+            # the bias gradient rides along: the 3x3 kernel sums dY while staging it, the other paths run the column sum themselves
+            ride = self.fuse_db
+            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None), ws_slot=4,
+                        wsb_slot=len(c.fields()) + 1)
+            if ride:
+                gb = None
         if gb is not None:
             M = c.N * c.Ho * c.Wo
             self.p.need_ws(H.colsum_ws_bytes(M, c.Cout))

@@ -185,8 +185,9 @@ def op_conv_wprep(c, w, transposed, wp):
     return make_op(OP_CONV_WPREP, [w, wp], c.fields() + [transposed])
 
 
-def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0):
-    return make_op(OP_CONV_WGRAD, [x0, x1, dy, dw, ws], c.fields() + [accumulate, ws_bytes])
+def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0, db=None):
+    """dw (+)= weight gradient; db (optional): bias gradient = column sums of dy, same accumulate flag."""
+    return make_op(OP_CONV_WGRAD, [x0, x1, dy, dw, ws, db], c.fields() + [accumulate, ws_bytes])
 
 
 def op_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=None, accumulate=0,

@@ -107,10 +107,12 @@ def test_conv_fwd_dgrad_wgrad(H, case):
     wsb = c.wgrad_ws_bytes()
     wsp = ws(wsb)
     dw = torch.empty_like(wd)
-    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, wsp, wsb))
-    assert rel_err(dw.permute(0, 3, 1, 2), dw_ref) < 2e-5
-    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, wsp, wsb, accumulate=1))
-    assert rel_err(dw.permute(0, 3, 1, 2), 2 * dw_ref) < 2e-5
+    db = torch.empty(Cout, device="cuda")            # bias gradient rides along (column sums of dy)
+    db_ref = dy.double().sum((0, 2, 3))
+    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, wsp, wsb, db=db))
+    assert rel_err(dw.permute(0, 3, 1, 2), dw_ref) < 2e-5 and rel_err(db, db_ref) < 1e-5
+    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, wsp, wsb, accumulate=1, db=db))
+    assert rel_err(dw.permute(0, 3, 1, 2), 2 * dw_ref) < 2e-5 and rel_err(db, 2 * db_ref) < 1e-5
 
 
 def test_conv_wgrad_splitk_large(H):
@@ -432,8 +434,10 @@ def test_conv_bf16_split_modes(H, case, math_mode):
         assert rel_err(nchw(dx2), xl.grad) < tol
     wsb = c.wgrad_ws_bytes()
     dw = torch.empty_like(wd)
-    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb))
+    db = torch.empty(Cout, device="cuda")
+    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb, db=db))
     assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2 * tol
+    assert rel_err(db, dy.double().sum((0, 2, 3))) < 1e-5          # exact fp32 sums in every math mode
 
 
 @pytest.mark.parametrize("math_mode", [1, 3])
