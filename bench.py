@@ -258,6 +258,10 @@ def main():
             return 4.0 * N * (Ho * Wo * Cout + Hi * s_ * Wi * s_ * Cin) + 6.0 * Cout * 9 * Cin
 
         pk = [k for k in range(st.n_bwd) if is_patch(st.plan.arr[k])]
+        kname = "conv3x3p_kernel (3x3 conv forward + data gradient, LDS-patch kernel)"
+        if not pk:                                    # f32 mode: every convolution runs on the generic f32-MFMA implicit GEMM
+            pk = [k for k in range(st.n_bwd) if fl[k] > 0 and st.plan.arr[k].kind != H.OP_GEMM]
+            kname = "igemm_kernel (generic implicit-GEMM convolution, f32 MFMA)"
         p_ms, p_fl = sum(durs[k] for k in pk), sum(fl[k] for k in pk)
         p_by = sum(patch_bytes(st.plan.arr[k]) for k in pk)
         traffic, traffic_src = None, None
@@ -269,7 +273,7 @@ def main():
                 traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, gfx950 x2 fetch correction)"
         except (OSError, ValueError, KeyError):
             pass
-        out["roofline"] = {"bound": "mfma", "kernel": "conv3x3p_kernel (3x3 conv forward + data gradient, LDS-patch kernel)",
+        out["roofline"] = {"bound": "mfma", "kernel": kname,
                            "math": math, "achieved": round(p_fl / p_ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                            "frac": round(p_fl / p_ms / 1e9 / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(p_by / max(len(pk), 1)),
