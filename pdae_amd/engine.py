@@ -10,6 +10,7 @@ and torch autograd) with a plan built once per (network, batch shape, mode):
 Only what the path needs is differentiated: the frozen trunk / eps-branch of ShiftUNet emit no backward.
 """
 import math
+import copy
 import os
 from types import SimpleNamespace as NS
 
@@ -136,6 +137,10 @@ class Builder:
 
     def __init__(self, plan, params, grads=None, save=False, drop_p=0.0, acc_grads=False, math=None, frozen_of=None):
         self.p = plan
+        # optional cheaper arithmetic for the gradient convolutions only (default: same as forward = fp32-grade bf16x6).  bf16x3 keeps
+        # ~2^-17 per product -- tighter than the TF32 convolutions of the reference's own cuDNN default -- and is NOT used for any reported number
+        bm = os.environ.get("PDAE_BWD_MATH")
+        self.bwd_math = H.MATH_NAMES[bm] if bm else None
         self.fuse_db = os.environ.get("PDAE_FUSE_DB", "1") != "0"      # bias gradients ride in the weight-gradient launch
         self.fuse_skip = os.environ.get("PDAE_FUSE_SKIP", "1") != "0"  # ResBlock skip_connection rides in conv2's K loop (conv_skip)
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
@@ -188,9 +193,17 @@ class Builder:
         self.p.emit(H.op_conv_wprep(c, w, transposed, wp))
         return wp
 
+    def _bwd_desc(self, c):
+        """Descriptor of the backward launches of conv c: same geometry, arithmetic mode `bwd_math` when it is set (PDAE_BWD_MATH)."""
+        if self.bwd_math is None or self.bwd_math == c.math:
+            return c
+        b = copy.copy(c)
+        b.math = self.bwd_math
+        return b
+
     def conv_bwd_params(self, cx, dy):
         """dW, db of a conv stage (only if the parameter is trained by this plan)."""
-        c = cx.c
+        c = self._bwd_desc(cx.c)
         gw = self.Gr.get(cx.wname + ".weight")
         gb = self.Gr.get(cx.wname + ".bias")
         if gw is not None:
@@ -208,7 +221,7 @@ class Builder:
             self.p.emit(H.op_colsum(dy, M, c.Cout, gb, None, acc=self.acc), ws_slot=2)
 
     def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0):
-        c = cx.c
+        c = self._bwd_desc(cx.c)
         ci_cnt = c.Cin if ci_cnt is None else ci_cnt
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
