@@ -57,7 +57,8 @@ __device__ __forceinline__ long long half_row(long long row, int H, int W) {
 #define QLDH 72                                          // bf16 per LDS row: 64 channels + 8 pad = 144 bytes
 template <int NS>
 __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
-  __shared__ __attribute__((aligned(16))) unsigned short sA[NS * 128 * QLDH];
+  constexpr int SA_PLANES = NS * 128 * QLDH, SA_EPI = 4 * 32 * 68 * 2;        // operand planes | epilogue transpose tiles (4 waves x 32 x 68 fp32)
+  __shared__ __attribute__((aligned(16))) unsigned short sA[SA_PLANES > SA_EPI ? SA_PLANES : SA_EPI];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
   const int wm = wv >> 1, wn = wv & 1;
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -166,29 +167,45 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   }
   const long long mw = m0 + wm * 64;
 
-  // ---- epilogue
-  float bcol[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) { const int col = n0 + b * 32 + li; bcol[b] = (P.bias && col < P.Nout) ? P.bias[col] : 0.f; }
+  // ---- epilogue: each wave transposes its 32-pixel x 64-channel accumulator groups through a private LDS tile (the activation tile is
+  // dead by now) so that global traffic is float4 per lane in 256-byte runs; residual / accumulate operands are loaded up front
+  __syncthreads();
+  float* tw = reinterpret_cast<float*>(sA) + wv * (32 * 68);
+  const int er = lane >> 4, ec = (lane & 15) * 4;
+  const int colb = n0 + ec;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (P.bias && P.splits == 1 && colb < P.Nout) bias4 = *reinterpret_cast<const float4*>(P.bias + colb);      // Nout % 4 == 0
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
+    long long rowv[8];
+    float4 rv[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const long long row = mw + a * 32 + i;
-      if (row >= P.M) continue;
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int col = n0 + b * 32 + li;
-        if (col >= P.Nout) continue;
-        float val = acc[a][b][r];
-        if (P.splits > 1) { P.slab[((long long)sp * P.M + row) * P.Nout + col] = val; continue; }
-        val += bcol[b];
-        if (P.res) val += P.res[(P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + col];
-        float* dst = P.y + row * P.Nout + col;
-        if (P.accumulate) val += *dst;
-        *dst = val;
+    for (int it = 0; it < 8; ++it) {
+      const long long row = mw + a * 32 + it * 4 + er;
+      rowv[it] = (row >= P.M || colb >= P.Nout) ? -1 : row;
+      rv[it] = bias4;
+      if (rowv[it] >= 0 && P.splits == 1) {
+        if (P.res) {
+          const float4 u = *reinterpret_cast<const float4*>(P.res + (P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + colb);
+          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+        }
+        if (P.accumulate) {
+          const float4 u = *reinterpret_cast<const float4*>(P.y + row * P.Nout + colb);
+          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+        }
       }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + li] = acc[a][b][r];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * 68 + ec]);
+      if (rowv[it] < 0) continue;
+      if (P.splits > 1) { *reinterpret_cast<float4*>(P.slab + ((long long)sp * P.M + rowv[it]) * P.Nout + colb) = v; continue; }
+      v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
+      *reinterpret_cast<float4*>(P.y + rowv[it] * P.Nout + colb) = v;
     }
   }
 }
