@@ -44,7 +44,7 @@ typedef struct pdae_conv_desc {
 } pdae_conv_desc;
 
 /* Fast paths in the bf16 modes (math >= 1): 3x3 / stride-1 / pad-1 convolutions run on the LDS-patch kernel (conv3x3p.hip) and 1x1
- * convolutions on the register-direct kernel (conv1x1.hip).  Both read their weights pre-split into bf16 planes in MFMA-fragment
+ * convolutions on the 1x1 kernel (conv1x1.hip).  Both read their weights pre-split into bf16 planes in MFMA-fragment
  * order.  pdae_conv_wprep_bytes returns the size of that copy (+ split-K scratch) for the forward (flags = 0) or data-gradient
  * (PDAE_WPREP_TRANSPOSED) convolution of d, or 0 when the convolution is not eligible (then pass wp = NULL and the generic
  * implicit-GEMM kernel runs).  pdae_conv_wprep writes it from the fp32 weights w [Cout][KH][KW][Cin]; it must be re-run whenever w

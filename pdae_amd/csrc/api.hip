@@ -42,7 +42,7 @@ static void fwd_geom(ConvGeom& g, const pdae_conv_desc* d, const float* x0, cons
 }
 
 // fast-path kind of the forward (transposed = 0) / data-gradient (transposed = 1) convolution of d:
-//   3 = LDS-patch 3x3 kernel (conv3x3p.hip), 1 = register-direct 1x1 kernel (conv1x1.hip), 0 = generic implicit GEMM only
+//   3 = LDS-patch 3x3 kernel (conv3x3p.hip), 1 = 1x1 kernel (conv1x1.hip), 0 = generic implicit GEMM only
 static int fast_kind(const pdae_conv_desc* d, int transposed, bool fill) {
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
   if (!transposed) {

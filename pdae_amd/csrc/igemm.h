@@ -65,7 +65,7 @@ size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout);
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
                     int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part = nullptr, int* db_rows = nullptr);
 
-// conv1x1.hip: register-direct 1x1 convolution (forward / data gradient) on prepared weights
+// conv1x1.hip: 1x1 convolution (forward / data gradient) on prepared weights, activations staged through LDS
 bool conv1x1_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, int C1, int Nout);
 size_t conv1x1_wprep_bytes(int math, int Nrows, int C, long long M);
 int conv1x1_wprep(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, hipStream_t s);
