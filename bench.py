@@ -34,7 +34,7 @@ FFHQ128 = dict(input_channel=3, base_channel=128, channel_multiplier=[1, 1, 2, 3
                attention_resolutions=[8], num_heads=1, head_channel=-1, use_new_attention_order=False, dropout=0.1)
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
-MFMA_PER_PRODUCT = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6}
+MFMA_PER_PRODUCT = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
 TRAIN_GFLOP_PER_IMG = 481.4         # fwd 258.4 + 2 x 110.7 (shift-branch bwd) + 3 x 0.549 (encoder)
 FWD_GFLOP_PER_IMG = 258.4
 
@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--math", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--math", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16", "f16x3"],
                     help="conv arithmetic on fp32 tensors (default bf16x6 = exact 3-plane split, fp32 grade; f32 = f32 MFMA)")
     args = ap.parse_args()
 
@@ -234,10 +234,18 @@ def main():
         from pdae_amd import hip as H
         math = os.environ.get("PDAE_CONV_MATH", H.DEFAULT_MATH)
         npm = MFMA_PER_PRODUCT[math]
+
+        def op_npm(op):                               # MFMAs issued per algorithmic product by the kernel that runs this op
+            if math == "f16x3":                       # two fp16 planes in the forward 3x3 patch kernel only; everything else bf16x6
+                fwd3 = op.kind in (H.OP_CONV_FWD_GN, H.OP_CONV_FWD_SKIP) or (op.kind == H.OP_CONV_FWD and bool(op.p[6]) and op.i[8] == 3)
+                return 3 if fwd3 else 6
+            return npm
         # peak for the arithmetic actually executed: f32 MFMA 157.3 TF, or the dense bf16 MFMA peak divided by the number of
         # bf16 MFMAs issued per algorithmic product (6 for the exact 3-plane split)
         peak = PEAK_F32_MFMA_TFLOPS if math == "f32" else PEAK_BF16_MFMA_TFLOPS / npm
-        out["dtype"] = "f32" if math == "f32" else ("bf16" if math == "bf16" else f"f32 as {math} split-bf16 MFMA, fp32 accumulate")
+        out["dtype"] = {"f32": "f32", "bf16": "bf16",
+                        "f16x3": "f32 as split-operand MFMA (forward 3x3: 2 fp16 planes x3 products; gradients / 1x1: 3 bf16 planes x6), fp32 accumulate",
+                        }.get(math, f"f32 as {math} split-operand MFMA, fp32 accumulate")
         # dominant kernel: conv3x3p_kernel (3x3 forward + data gradient on the patch path = ops that carry prepared weights)
         def is_patch(op):
             fwd = op.kind in (H.OP_CONV_FWD, H.OP_CONV_FWD_GN, H.OP_CONV_FWD_SKIP)
@@ -263,12 +271,16 @@ def main():
             pk = [k for k in range(st.n_bwd) if fl[k] > 0 and st.plan.arr[k].kind != H.OP_GEMM]
             kname = "igemm_kernel (generic implicit-GEMM convolution, f32 MFMA)"
         p_ms, p_fl = sum(durs[k] for k in pk), sum(fl[k] for k in pk)
+        if math != "f32":                             # peak of the executed mix: dense low-precision MFMA peak / average MFMAs per product
+            peak = PEAK_BF16_MFMA_TFLOPS * p_fl / max(sum(fl[k] * op_npm(st.plan.arr[k]) for k in pk), 1.0)
+        fam_peak = peak if math == "f32" else PEAK_BF16_MFMA_TFLOPS * ig_fl / max(sum(f * (op_npm(st.plan.arr[k]) if st.plan.arr[k].kind != H.OP_GEMM else 16)
+                                                                                      for k, f in enumerate(fl) if f > 0), 1.0)
         p_by = sum(patch_bytes(st.plan.arr[k]) for k in pk)
         traffic, traffic_src = None, None
         try:                                          # PMC counters cannot be read from inside the process: committed rocprofv3 --pmc passes
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
-            kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3p_kernel<3, 8, false")]     # plain + fused-GN instantiations
-            if kk and math == "bf16x6":
+            kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3p_kernel<") and ", 8, false" in k_]   # every non-pair instantiation
+            if kk and pmc.get("math", "bf16x6") == math:
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kk) / sum(v["dispatches"] for v in kk))
                 traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, gfx950 x2 fetch correction)"
         except (OSError, ValueError, KeyError):
@@ -277,14 +289,14 @@ def main():
                            "math": math, "achieved": round(p_fl / p_ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                            "frac": round(p_fl / p_ms / 1e9 / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(p_by / max(len(pk), 1)),
-                           "peak_note": "algorithmic TFLOP/s; peak = dense MFMA peak of the executed dtype / MFMAs per product",
+                           "peak_note": "algorithmic TFLOP/s; peak = dense 16-bit MFMA peak (2500) / average MFMAs issued per algorithmic product of these launches",
                            "launches_per_step": len(pk), "avg_launch_ms": round(p_ms / max(len(pk), 1), 4),
                            "algorithmic_gflop_per_launch": round(p_fl / 1e9 / max(len(pk), 1), 2), "kernel_ms_per_step": round(p_ms, 3),
                            "frac_of_f32_mfma_peak": round(p_fl / p_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                            "heaviest_launch": {"gflop": round(fl[kbig] / 1e9, 2), "ms": round(durs[kbig], 4),
                                                "tflops": round(fl[kbig] / durs[kbig] / 1e9, 2)},
                            "family": {"kernels": "conv3x3p + conv3x3w + conv1x1 + igemm(_bf) (every conv fwd/dgrad/wgrad and dense GEMM)",
-                                      "achieved": round(ig_fl / ig_ms / 1e9, 2), "frac": round(ig_fl / ig_ms / 1e9 / peak, 4),
+                                      "achieved": round(ig_fl / ig_ms / 1e9, 2), "frac": round(ig_fl / ig_ms / 1e9 / fam_peak, 4), "peak": round(fam_peak, 1),
                                       "launches_per_step": n_ig, "algorithmic_gflop_per_step": round(ig_fl / 1e9, 1),
                                       "ms_per_step": round(ig_ms, 3), "all_ops_ms_per_step": round(sum(durs), 3)}}
         st.micro = 0

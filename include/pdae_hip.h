@@ -40,7 +40,10 @@ typedef struct pdae_conv_desc {
   int32_t up;             /* 1: the conv reads the nearest-x2 upsample of the stored input (F.interpolate, module.py:169) */
   int32_t math;           /* MFMA arithmetic for fp32 tensors: 0 = f32 MFMA (exact fp32 fmaf chain);
                            * 1 = bf16 operands (rn); 2 = 2 bf16 planes, 3 products (~2^-17 per product);
-                           * 3 = 3 exact bf16 planes, 6 products (~2^-23 per product, fp32 grade).  fp32 accumulate in all modes. */
+                           * 3 = 3 exact bf16 planes, 6 products (~2^-23 per product, fp32 grade);
+                           * 4 = 2 fp16 planes (11+11 mantissa bits), 3 products (~2^-21 per product) in the FORWARD 3x3 patch kernel -- operands must
+                           *     lie inside the fp16 range (post-GroupNorm activations, weights); every other kernel and all gradient kernels
+                           *     run mode 3.  fp32 accumulate in all modes. */
 } pdae_conv_desc;
 
 /* Fast paths in the bf16 modes (math >= 1): 3x3 / stride-1 / pad-1 convolutions run on the LDS-patch kernel (conv3x3p.hip) and 1x1
@@ -67,9 +70,12 @@ int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, const float* x1
 /* ResBlock tail in one launch (module.py:265,276,297):  y = conv3x3_d(in) + bias + conv1x1_ds([s0 | s1]) + bias_s,  in = coef ?
  * act(GN-affine([x0 | x1])) : x0.  The 1x1 skip_connection enters the 3x3 kernel's K loop as extra centre-tap chunks of the raw block
  * input, so its output never exists in HBM.  ds: 1x1 descriptor on d's output grid (C0/C1 = channels of s0/s1);
- * wps = pdae_conv_wprep(ds, w_skip, 0); wp as for pdae_conv2d_fwd (coef == NULL) or pdae_conv2d_fwd_gn.  pdae_conv2d_fwd_skip_ok tells
- * whether the pair is eligible (otherwise run the two convolutions separately, the second with res_mode 1). */
+ * wps = pdae_conv_skip_wprep(d, ds, w_skip) (the skip weights in the plane format / scale of d's main loop); wp as for pdae_conv2d_fwd
+ * (coef == NULL) or pdae_conv2d_fwd_gn.  pdae_conv2d_fwd_skip_ok tells whether the pair is eligible (otherwise run the two convolutions
+ * separately, the second with res_mode 1). */
 int pdae_conv2d_fwd_skip_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds);
+size_t pdae_conv_skip_wprep_bytes(const pdae_conv_desc* d, const pdae_conv_desc* ds);
+int pdae_conv_skip_wprep(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_stream_t stream);
 int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
                          const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps, const float* bias_s, float* y,
                          pdae_stream_t stream);
@@ -155,7 +161,7 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP
 };
 typedef struct pdae_op {
   int32_t kind;

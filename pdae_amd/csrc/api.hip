@@ -27,7 +27,7 @@ static int check_desc(const pdae_conv_desc* d) {
   PDAE_CHECK_ARG(d && d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad dims");
   PDAE_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2");
   PDAE_CHECK_ARG(!(d->up && d->stride != 1), "conv: up with stride!=1");
-  PDAE_CHECK_ARG(d->math >= 0 && d->math <= 3, "conv: math mode must be 0..3");
+  PDAE_CHECK_ARG(d->math >= 0 && d->math <= 4, "conv: math mode must be 0..4");
   int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
   PDAE_CHECK_ARG(d->Ho == (Hl + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (Wl + 2 * d->pad - d->KW) / d->stride + 1,
                  "conv: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d->Ho, d->Wo, Hl, Wl, d->KH, d->stride, d->pad);
@@ -40,6 +40,10 @@ static void fwd_geom(ConvGeom& g, const pdae_conv_desc* d, const float* x0, cons
   g.Hs = d->Hi; g.Ws = d->Wi; g.Hl = d->up ? 2 * d->Hi : d->Hi; g.Wl = d->up ? 2 * d->Wi : d->Wi;
   g.Ho = d->Ho; g.Wo = d->Wo; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.up = d->up; g.dil = 0;
 }
+
+// mode 4 (two fp16 planes, 3 products) is a FORWARD format: activations and weights live inside the fp16 range, gradients do not
+// (dY of a converged network underflows); every gradient kernel runs the exact three-plane bf16 split instead
+static int bwd_math(const pdae_conv_desc* d) { return d->math == 4 ? 3 : d->math; }
 
 // fast-path kind of the forward (transposed = 0) / data-gradient (transposed = 1) convolution of d:
 //   3 = LDS-patch 3x3 kernel (conv3x3p.hip), 1 = 1x1 kernel (conv1x1.hip), 0 = generic implicit GEMM only
@@ -69,7 +73,7 @@ extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
   const int kind = fast_kind(d, transposed, !(flags & PDAE_WPREP_FORCE));
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
   if (kind == 3)
-    return transposed ? conv3x3p_wprep_bytes(d->math, Cin, d->Cout, Hl, Wl, d->N) : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
+    return transposed ? conv3x3p_wprep_bytes(bwd_math(d), Cin, d->Cout, Hl, Wl, d->N) : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
   if (kind == 1) {
     const long long M = (long long)d->N * d->Ho * d->Wo;
     return transposed ? conv1x1_wprep_bytes(d->math, Cin, d->Cout, M) : conv1x1_wprep_bytes(d->math, d->Cout, Cin, M);
@@ -88,7 +92,7 @@ extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flag
   const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
   PDAE_CHECK_ARG(kind != 0, "conv_wprep: convolution shape not eligible for a prepared-weight kernel");
   if (kind == 3) {
-    if (transposed) return conv3x3p_wprep(d->math, w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
+    if (transposed) return conv3x3p_wprep(bwd_math(d), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
     return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream));
   }
   if (transposed) return conv1x1_wprep(d->math, w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
@@ -144,6 +148,16 @@ extern "C" int pdae_conv2d_fwd_skip_ok(const pdae_conv_desc* d, const pdae_conv_
   return conv3x3p_skip_ok(d->math, d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, d->up, ds->C0, ds->C1) ? 1 : 0;
 }
 
+extern "C" size_t pdae_conv_skip_wprep_bytes(const pdae_conv_desc* d, const pdae_conv_desc* ds) {
+  if (!pdae_conv2d_fwd_skip_ok(d, ds)) return 0;
+  return conv3x3p_skip_wprep_bytes(d->math, ds->Cout, ds->C0 + ds->C1);
+}
+
+extern "C" int pdae_conv_skip_wprep(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(w_skip && wps && pdae_conv2d_fwd_skip_ok(d, ds), "conv_skip_wprep: not an eligible (conv3x3, skip 1x1) pair");
+  return conv3x3p_skip_wprep(d->math, w_skip, ds->Cout, ds->C0 + ds->C1, d->C0 + d->C1, (unsigned short*)wps, S(stream));
+}
+
 extern "C" int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp,
                                     const float* bias, const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps,
                                     const float* bias_s, float* y, pdae_stream_t stream) {
@@ -169,7 +183,7 @@ extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const
   PDAE_CHECK_ARG(!wp_t || (tile == 0 && ((kind == 3 && ci_off == 0 && ci_cnt == Cin) || (kind == 1 && (ci_off & 31) == 0 && (ci_cnt & 3) == 0))),
                  "conv2d_dgrad: wp_t given but the convolution / channel range is not eligible for a prepared-weight kernel");
   if (kind == 3)
-    return conv3x3p_launch(d->math, dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, (const unsigned short*)wp_t, Cin, dx, nullptr, nullptr, 0,
+    return conv3x3p_launch(bwd_math(d), dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, (const unsigned short*)wp_t, Cin, dx, nullptr, nullptr, 0,
                            accumulate, S(stream));
   if (kind == 1)
     return conv1x1_launch(d->math, dy, d->Cout, nullptr, 0, (long long)d->N * d->Ho * d->Wo, (const unsigned short*)wp_t, Cin, ci_off, ci_cnt, dx,
@@ -445,6 +459,12 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
       pdae_conv_desc ds = d;
       ds.Hi = d.Ho; ds.Wi = d.Wo; ds.C0 = (int)i[15]; ds.C1 = (int)i[16]; ds.KH = ds.KW = 1; ds.pad = 0; ds.up = 0; ds.stride = 1;
       return pdae_conv2d_fwd_skip(&d, F(0), F(1), F(2), (int)i[14], p[3], F(4), &ds, F(5), F(6), p[7], F(8), FM(9), st);
+    }
+    case PDAE_OP_CONV_SKIP_WPREP: {
+      desc_from(i, d);
+      pdae_conv_desc ds = d;
+      ds.Hi = d.Ho; ds.Wi = d.Wo; ds.C0 = (int)i[14]; ds.C1 = (int)i[15]; ds.KH = ds.KW = 1; ds.pad = 0; ds.up = 0; ds.stride = 1;
+      return pdae_conv_skip_wprep(&d, &ds, F(0), p[1], st);
     }
     case PDAE_OP_CONV_WPREP: desc_from(i, d); return pdae_conv_wprep(&d, F(0), (int)i[14], p[1], st);
     case PDAE_OP_MEMSET: {

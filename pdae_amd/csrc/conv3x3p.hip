@@ -17,6 +17,11 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// NS encodes the operand format: 1..3 = that many bf16 planes; 4 = TWO fp16 planes (11 + 11 mantissa bits, 3 products ~2^-21:
+// fp32-grade at half the MFMAs of bf16x6, for operands inside the fp16 range -- forward activations / weights)
+#define NPL(NS_) ((NS_) == 4 ? 2 : (NS_))
+#define PASCALE 16.0f            // fp16 format: activations are multiplied by 2^4 before the split (undone exactly in the epilogue)
 
 // Geometries (template PTH, W8):
 //   PTH = 16      : 16x16-pixel tile, 512 threads (4x2 waves), 86 KB LDS at NS=3 (one block per CU)
@@ -39,8 +44,15 @@ __device__ __forceinline__ unsigned p_rn(float a, float b) {
   unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
   return (unsigned)x | ((unsigned)y << 16);
 }
-template <int NS> __device__ __forceinline__ void p_split2(float e0, float e1, unsigned (&w)[NS]) {
-  if constexpr (NS == 1) { w[0] = p_rn(e0, e1); }
+__device__ __forceinline__ unsigned p_pack_h(_Float16 a, _Float16 b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+template <int NS> __device__ __forceinline__ void p_split2(float e0, float e1, unsigned (&w)[NPL(NS)]) {
+  if constexpr (NS == 4) {                       // fp16 hi (rn) + fp16 of the exact fp32 residual
+    const _Float16 h0 = (_Float16)e0, h1 = (_Float16)e1;
+    w[0] = p_pack_h(h0, h1);
+    w[1] = p_pack_h((_Float16)(e0 - (float)h0), (_Float16)(e1 - (float)h1));
+  } else if constexpr (NS == 1) { w[0] = p_rn(e0, e1); }
   else {
     float h0 = p_trunc(e0), h1 = p_trunc(e1);
     float r0 = e0 - h0, r1 = e1 - h1;
@@ -70,6 +82,7 @@ struct PatchParams {
   // fused 1x1 skip convolution (ResBlock skip_connection, module.py:276,297): nx extra 32-channel chunks of the raw two-source tensor
   // [s0 | s1] enter the K loop with the centre tap only, weights wps = conv1x1_wprep layout, bias_x added in the epilogue
   int nx; const float* s0; const float* s1; int Cs0, Cs1; const unsigned short* wps; const float* bias_x;
+  float oscale;                         // fp16 format: the prepared weights carry a power-of-two scale (conv3x3p_wscale); accumulators * oscale
 };
 
 __device__ __forceinline__ float p_silu(float v) { return v / (1.0f + expf(-v)); }
@@ -81,7 +94,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   constexpr int PNPIX = (PTH + 2) * PPW;                  // 324 | 180
   constexpr int PA_LD = (PNPIX * 8 + PTHREADS - 1) / PTHREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  constexpr int SA = NS * PPLANE(PNPIX);        // A patch planes
+  constexpr int SA = NPL(NS) * PPLANE(PNPIX);   // A patch planes
   unsigned short* sA = smem;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
@@ -158,11 +171,16 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
             apre[l] = v;
           }
         }
-        unsigned a[NS], b[NS];
+        if constexpr (NS == 4) {                // fp16 format: exact power-of-two pre-scale, window [2^-7, 4094] keeps both planes normal
+          // saturate instead of overflowing to inf (|x| > 3750 cannot occur behind GroupNorm; a stray value must not poison the tile)
+          apre[l].x = fminf(fmaxf(apre[l].x * PASCALE, -60000.f), 60000.f); apre[l].y = fminf(fmaxf(apre[l].y * PASCALE, -60000.f), 60000.f);
+          apre[l].z = fminf(fmaxf(apre[l].z * PASCALE, -60000.f), 60000.f); apre[l].w = fminf(fmaxf(apre[l].w * PASCALE, -60000.f), 60000.f);
+        }
+        unsigned a[NPL(NS)], b[NPL(NS)];
         p_split2<NS>(apre[l].x, apre[l].y, a);
         p_split2<NS>(apre[l].z, apre[l].w, b);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sA[p * PPLANE(PNPIX) + PSLOT(pix, qd >> 1) + (qd & 1) * 4]) = make_uint2(a[p], b[p]);
+        for (int p = 0; p < NPL(NS); ++p) *reinterpret_cast<uint2*>(&sA[p * PPLANE(PNPIX) + PSLOT(pix, qd >> 1) + (qd & 1) * 4]) = make_uint2(a[p], b[p]);
       }
     }
   };
@@ -189,7 +207,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   //   main chunks: wp [p][chunk][tap][kc][nt][lane],  skip chunks: wps [p][chunk - nmain][kc][nt][lane]
   const int nt0 = (n0 >> 5) + wn * 2;
   const size_t plane_main = (size_t)nmain * 18 * P.NT * 512, plane_skip = (size_t)P.nx * 2 * P.NT * 512;      // bf16 elements per plane
-  auto ldb = [&](uint4 (&bq)[2][NS], int chunk, int tap, int kc) {
+  auto ldb = [&](uint4 (&bq)[2][NPL(NS)], int chunk, int tap, int kc) {
     const bool raw = chunk >= nmain;
     const unsigned short* base = raw ? P.wps + ((size_t)(((chunk - nmain) << 1) + kc) * P.NT + nt0) * 512 + lane * 8
                                      : P.wp + ((size_t)(((chunk * 9 + tap) << 1) + kc) * P.NT + nt0) * 512 + lane * 8;
@@ -197,38 +215,50 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int p = 0; p < NS; ++p)
+      for (int p = 0; p < NPL(NS); ++p)
         bq[b][p] = (nt0 + b < P.NT) ? *reinterpret_cast<const uint4*>(base + p * ps + b * 512) : make_uint4(0u, 0u, 0u, 0u);
   };
   // one k-step: 16 channels (half kc of the staged chunk) of one tap
-  auto mma = [&](int tap, int kc, const uint4 (&bq)[2][NS]) {
+  auto mma = [&](int tap, int kc, const uint4 (&bq)[2][NPL(NS)]) {
     const int dy = tap / 3, dx = tap - dy * 3;
     const int ashift = dy * PPW + dx;
-    bf16x8 af[2][NS];
+    uint4 af[2][NPL(NS)];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int p = 0; p < NS; ++p)
-        af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
+      for (int p = 0; p < NPL(NS); ++p)
+        af[a][p] = *reinterpret_cast<const uint4*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
+#define PDAE_A(P_) __builtin_bit_cast(bf16x8, af[a][P_])
 #define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[b][P_])
-        if constexpr (NS == 3) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], PDAE_B(1), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(2), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], PDAE_B(0), acc[a][b], 0, 0, 0);
+#define PDAE_AH(P_) __builtin_bit_cast(f16x8, af[a][P_])
+#define PDAE_BH(P_) __builtin_bit_cast(f16x8, bq[b][P_])
+        if constexpr (NS == 4) {                  // fp16 planes: cross terms first, leading term last
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(1), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(1), PDAE_BH(0), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(0), acc[a][b], 0, 0, 0);
+        } else {
+          if constexpr (NS == 3) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(1), acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(2), acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(2), PDAE_B(0), acc[a][b], 0, 0, 0);
+          }
+          if constexpr (NS >= 2) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(1), acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(0), acc[a][b], 0, 0, 0);
+          }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(0), acc[a][b], 0, 0, 0);
         }
-        if constexpr (NS >= 2) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(1), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], PDAE_B(0), acc[a][b], 0, 0, 0);
-        }
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(0), acc[a][b], 0, 0, 0);
+#undef PDAE_A
+#undef PDAE_AH
+#undef PDAE_BH
 #undef PDAE_B
       }
   };
-  uint4 q0[2][NS], q1[2][NS];
+  uint4 q0[2][NPL(NS)], q1[2][NPL(NS)];
   if (c_begin < c_end) {
     a_gload(c_begin);
     ldb(q0, c_begin, c_begin >= nmain ? 4 : 0, 0);
@@ -299,7 +329,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + b * 32 + li] = acc[a][b][r];
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + b * 32 + li] = NS == 4 ? acc[a][b][r] * P.oscale : acc[a][b][r];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * EPW + ec]);
@@ -340,7 +370,7 @@ __global__ void __launch_bounds__(256) conv3x3p_reduce_kernel(const PatchParams 
 
 template <int NS, int PTH, bool W8, bool GN = false> static int launch_ns(const PatchParams& P, hipStream_t s) {
   constexpr int NPIX = (PTH + 2) * PPW;
-  size_t smem = (size_t)(NS * PPLANE(NPIX)) * sizeof(unsigned short);
+  size_t smem = (size_t)(NPL(NS) * PPLANE(NPIX)) * sizeof(unsigned short);
   const size_t epi = (size_t)(PTH / 2) * 32 * EPW * sizeof(float);        // one 32 x 68 fp32 tile per wave
   if (smem < epi) smem = epi;
   static bool attr_set = false;
@@ -416,10 +446,14 @@ static size_t slab_bytes(int C, int H, int W, int N, int Nout) {
 }
 
 static size_t prep_bytes(int math, int Nout, int C) {
-  const int NS = math < 1 ? 1 : (math > 3 ? 3 : math);
+  const int NS = math < 1 ? 1 : (math == 4 ? 2 : (math > 3 ? 3 : math));       // planes: math 4 = two fp16 planes
   const size_t b = (size_t)NS * (C >> 5) * 18 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short);
   return (b + 255) & ~(size_t)255;
 }
+
+// power-of-two scale of the fp16-format prepared weights: trained conv weights are ~ 1/sqrt(fan_in), which would put their low plane
+// into the fp16 subnormals; scaled to O(1) both planes keep full precision, the kernel multiplies the accumulators by the inverse (exact)
+float conv3x3p_wscale(int C) { int k = 0; while ((1 << (2 * k)) < 9 * C) ++k; return (float)(1 << k); }
 
 // prepared weights + split-K slabs of the convolution (one buffer: [planes | slabs])
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { return prep_bytes(math, Nout, C) + slab_bytes(C, H, W, N, Nout); }
@@ -429,6 +463,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
                     const float* coef, int act, const PatchSkip* sk) {
   PatchParams P;
   P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
+  P.oscale = 1.0f / (conv3x3p_wscale(C) * PASCALE);
   P.nx = 0; P.s0 = P.s1 = nullptr; P.Cs0 = P.Cs1 = 0; P.wps = nullptr; P.bias_x = nullptr;
   if (sk) { P.nx = (sk->C0 + sk->C1) >> 5; P.s0 = sk->s0; P.s1 = sk->s1; P.Cs0 = sk->C0; P.Cs1 = sk->C1; P.wps = sk->wps; P.bias_x = sk->bias; }
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.wp = wp; P.NT = (Nout + 31) / 32; P.Nout = Nout;
@@ -444,6 +479,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
         : (q.w8 ? launch_ns<NS_, 8, true>(P, s) : q.th == 16 ? launch_ns<NS_, 16, false>(P, s) : launch_ns<NS_, 8, false>(P, s)))
   if (math == 1) return PDAE_P3(1);
   if (math == 2) return PDAE_P3(2);
+  if (math == 4) return PDAE_P3(4);
   return PDAE_P3(3);
 #undef PDAE_P3
 }
@@ -454,40 +490,60 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
 // (lane l of a wave holds k = (l>>5)*8 + j, j = 0..7, of output channel nt*32 + (l&31)).  One thread per fragment slot.
 // ---------------------------------------------------------------------------------------------
 template <int NS>
-__global__ void __launch_bounds__(256) conv3x3p_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed, unsigned short* __restrict__ wp) {
-  const size_t nslot = (size_t)(C >> 5) * 18 * NT * 64;
+__global__ void __launch_bounds__(256) conv3x3p_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed, float wscale,
+                                                             int T, unsigned short* __restrict__ wp) {
+  const size_t nslot = (size_t)(C >> 5) * 2 * T * NT * 64;          // T taps: 9 (3x3) or 1 (fused 1x1 skip chunks)
   const size_t plane_stride = nslot * 8;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) {
     const int lane = (int)(i & 63); size_t r = i >> 6;
     const int nt = (int)(r % NT); r /= NT;
     const int kc = (int)(r & 1); r >>= 1;
-    const int tap = (int)(r % 9); const int chunk = (int)(r / 9);
+    const int tap = (int)(r % T); const int chunk = (int)(r / T);
     const int n = nt * 32 + (lane & 31), c = (chunk << 5) + kc * 16 + (lane >> 5) * 8;
     float e[8];
     if (n < Nout && transposed) {               // GEMM weight w'[n][tap][c] = w[c][8 - tap][n]   (w stored [C][9][Nout])
 #pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = w[((size_t)(c + j) * 9 + (8 - tap)) * Nout + n];
+      for (int j = 0; j < 8; ++j) e[j] = w[((size_t)(c + j) * T + (T - 1 - tap)) * Nout + n];
     } else if (n < Nout) {
-      const float4 v0 = *reinterpret_cast<const float4*>(w + ((size_t)n * 9 + tap) * C + c);
-      const float4 v1 = *reinterpret_cast<const float4*>(w + ((size_t)n * 9 + tap) * C + c + 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(w + ((size_t)n * T + tap) * C + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(w + ((size_t)n * T + tap) * C + c + 4);
       e[0] = v0.x; e[1] = v0.y; e[2] = v0.z; e[3] = v0.w; e[4] = v1.x; e[5] = v1.y; e[6] = v1.z; e[7] = v1.w;
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) e[j] = 0.f;
     }
-    unsigned a[NS], b[NS], cc[NS], d[NS];
+    if constexpr (NS == 4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] *= wscale;
+    }
+    unsigned a[NPL(NS)], b[NPL(NS)], cc[NPL(NS)], d[NPL(NS)];
     p_split2<NS>(e[0], e[1], a); p_split2<NS>(e[2], e[3], b); p_split2<NS>(e[4], e[5], cc); p_split2<NS>(e[6], e[7], d);
 #pragma unroll
-    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
+    for (int p = 0; p < NPL(NS); ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
   }
 }
 
-int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s) {
+static int wprep_launch(int math, const float* w, int Nout, int C, int transposed, float wscale, int T, unsigned short* wp, hipStream_t s) {
   const int NT = (Nout + 31) / 32;
-  const size_t nslot = (size_t)(C >> 5) * 18 * NT * 64;
+  const size_t nslot = (size_t)(C >> 5) * 2 * T * NT * 64;
   int grid = (int)((nslot + 255) / 256); if (grid > 4096) grid = 4096;
-  if (math == 1) hipLaunchKernelGGL(conv3x3p_wprep_kernel<1>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wp);
-  else if (math == 2) hipLaunchKernelGGL(conv3x3p_wprep_kernel<2>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wp);
-  else hipLaunchKernelGGL(conv3x3p_wprep_kernel<3>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wp);
+  if (math == 1) hipLaunchKernelGGL(conv3x3p_wprep_kernel<1>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wscale, T, wp);
+  else if (math == 2) hipLaunchKernelGGL(conv3x3p_wprep_kernel<2>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wscale, T, wp);
+  else if (math == 4) hipLaunchKernelGGL(conv3x3p_wprep_kernel<4>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wscale, T, wp);
+  else hipLaunchKernelGGL(conv3x3p_wprep_kernel<3>, dim3(grid), dim3(256), 0, s, w, Nout, C, NT, transposed, wscale, T, wp);
   return pdae_launch_status("conv3x3p_wprep");
+}
+
+int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s) {
+  return wprep_launch(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, s);
+}
+
+// weights of a 1x1 skip convolution [Nout][Cs] for the skip chunks of a 3x3 launch whose main input has Cmain channels: same plane
+// format and (fp16 format) the same power-of-two scale as the main weights
+size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs) {
+  const int NS = math < 1 ? 1 : (math == 4 ? 2 : (math > 3 ? 3 : math));
+  return (((size_t)NS * (Cs >> 5) * 2 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short)) + 255) & ~(size_t)255;
+}
+int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s) {
+  return wprep_launch(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain), 1, wp, s);
 }

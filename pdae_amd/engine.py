@@ -266,11 +266,22 @@ class Builder:
         s0, s1, sname = skip
         ws, bs = self.P[sname + ".weight"], self.P[sname + ".bias"]
         cs = H.Conv(c.N, c.Ho, c.Wo, s0.shape[3], 0 if s1 is None else s1.shape[3], c.Cout, k=1, math=self.math)
-        if not H.conv_fwd_skip_ok(c, cs):
+        nbytes = H.conv_skip_wprep_bytes(c, cs)
+        if nbytes == 0:
             return None
-        wps = self._wprep(cs, ws, 0)
-        if wps is None:
-            return None
+        if self.frozen_of is not None and self.frozen_of.is_frozen_storage(ws):
+            key = (ws.data_ptr(), tuple(c.fields()), "skip")
+            wps = self._frozen_wp.get(key)
+            if wps is None:
+                wps = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)
+                self.p.live.append(wps)
+                self.p.bytes_alloc += wps.numel() * 4
+                self.p.emit_init(H.op_conv_skip_wprep(c, cs, ws, wps), self.frozen_of)
+                self._frozen_wp[key] = wps
+            wps = NoFree(wps)
+        else:
+            wps = self.p.buf((nbytes + 3) // 4)
+            self.p.emit(H.op_conv_skip_wprep(c, cs, ws, wps))
         return cs, s0, s1, wps, bs, NS(c=cs, x0=s0, x1=s1, wname=sname, y=None)
 
     def conv_skip(self, x, wname, skip):

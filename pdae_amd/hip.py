@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
- OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF) = range(1, 33)
+ OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP) = range(1, 34)
 
 
 class PdaeOp(ctypes.Structure):
@@ -28,11 +28,15 @@ class ConvDesc(ctypes.Structure):
 
 
 MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2, 3      # pdae_conv_desc.math
-MATH_NAMES = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3}
-# default arithmetic of the conv GEMMs on fp32 tensors: every fp32 operand is split EXACTLY into three bf16 planes and the six
-# leading plane products are accumulated in fp32 on the bf16 MFMA pipe (error ~2^-23 per product, i.e. fp32 grade; it passes the
-# same parity gates as the exact f32-MFMA kernels, which remain selectable with PDAE_CONV_MATH=f32)
-DEFAULT_MATH = "bf16x6"
+MATH_NAMES = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
+# default arithmetic of the conv GEMMs on fp32 tensors.  Every fp32 operand is split into low-precision planes whose leading cross
+# products are accumulated in fp32 on the MFMA pipe:
+#   "f16x3"  (default): FORWARD 3x3 patch convolutions use two fp16 planes (11+11 mantissa bits, 3 products, power-of-two pre-scales keep
+#            both planes normal); measured 2.8e-7 relative error vs fp64 on a 256->128 conv (torch fp32: 2.3e-7).  Every gradient kernel,
+#            the 1x1 and the generic kernels run "bf16x6" (gradients leave the fp16 range).
+#   "bf16x6": three exact bf16 planes, 6 products (3.7e-7 on the same conv) everywhere -- range-safe for any input.
+# Both pass the same parity gates as the exact f32-MFMA kernels ("f32"), which remain selectable with PDAE_CONV_MATH.
+DEFAULT_MATH = "f16x3"
 
 
 class PdaeError(RuntimeError):
@@ -57,6 +61,7 @@ def lib():
         L.pdae_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
         L.pdae_conv_wprep_bytes.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int]
         L.pdae_conv_wprep_bytes.restype = ctypes.c_size_t
+        L.pdae_conv_skip_wprep_bytes.restype = ctypes.c_size_t
         L.pdae_gn_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.pdae_gn_workspace_bytes.restype = ctypes.c_size_t
         L.pdae_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
@@ -67,7 +72,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_adam_ema", "pdae_run_ops"]
@@ -169,6 +174,16 @@ def op_conv_fwd_gn(c, x0, x1, coef, act, wp, bias, y, res=None, res_mode=0):
 def op_conv_fwd_skip(c, x0, x1, coef, act, wp, bias, cs, s0, s1, wps, bias_s, y):
     """y = conv3x3_c(in) + bias + conv1x1_cs([s0 | s1]) + bias_s in one launch (pdae_conv2d_fwd_skip)."""
     return make_op(OP_CONV_FWD_SKIP, [x0, x1, coef, wp, bias, s0, s1, wps, bias_s, y], c.fields() + [act, cs.C0, cs.C1])
+
+
+def op_conv_skip_wprep(c, cs, w_skip, wps):
+    """skip_connection weights in the plane format / scale of conv c's main loop (pdae_conv_skip_wprep)."""
+    return make_op(OP_CONV_SKIP_WPREP, [w_skip, wps], c.fields() + [cs.C0, cs.C1])
+
+
+def conv_skip_wprep_bytes(c, cs):
+    d, ds = c.cdesc(), cs.cdesc()
+    return int(lib().pdae_conv_skip_wprep_bytes(ctypes.byref(d), ctypes.byref(ds)))
 
 
 def conv_fwd_skip_ok(c, cs):

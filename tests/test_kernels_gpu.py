@@ -381,10 +381,10 @@ def test_softmax_colsum_layout_misc(H):
     assert dst.sum().item() == 64 and buf.sum().item() == 0
 
 
-MATH_TOL = {1: 2e-2, 2: 1e-4, 3: 1e-5}     # bf16 | 2 planes (3 products) | 3 exact planes (6 products): fp32 grade
+MATH_TOL = {1: 2e-2, 2: 1e-4, 3: 1e-5, 4: 1e-5}     # bf16 | 2 bf16 planes (3 products) | 3 exact bf16 planes (6 products): fp32 grade | 2 fp16 planes (3 products, forward patch kernel): fp32 grade
 
 
-@pytest.mark.parametrize("math_mode", [1, 2, 3])
+@pytest.mark.parametrize("math_mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("case", [(2, 12, 12, 64, 0, 96, 3, 1, 0, 0), (1, 10, 14, 32, 64, 64, 3, 1, 0, 64), (2, 8, 8, 32, 0, 32, 3, 1, 1, 0),
                                   (2, 16, 16, 64, 0, 128, 3, 2, 0, 0), (2, 9, 9, 64, 32, 32, 1, 1, 0, 0), (3, 32, 32, 128, 0, 128, 3, 1, 0, 128),
                                   (4, 64, 48, 64, 0, 160, 3, 1, 0, 0), (3, 32, 32, 96, 0, 64, 3, 1, 1, 0), (6, 32, 32, 32, 0, 256, 3, 1, 0, 0), (2, 24, 32, 64, 0, 64, 3, 1, 0, 0),
@@ -503,7 +503,7 @@ def test_skinny_linear(H, case):
     assert torch.equal(Cd[:, N:].cpu(), C0[:, N:])          # padding columns untouched
 
 
-@pytest.mark.parametrize("math_mode", [1, 3])
+@pytest.mark.parametrize("math_mode", [1, 3, 4])
 @pytest.mark.parametrize("case", [(2, 16, 32, 64, 32, 64, 0, 1), (2, 8, 8, 32, 0, 32, 1, 2), (1, 24, 16, 96, 0, 160, 0, 0), (2, 32, 32, 128, 128, 128, 0, 1)])
 def test_conv_with_fused_groupnorm_input(H, case, math_mode):
     """pdae_conv2d_fwd_gn: GroupNorm + AdaGN + SiLU applied inside the conv's patch staging (two-source concat, upsample, residuals,
@@ -549,7 +549,7 @@ def test_conv_with_fused_groupnorm_input(H, case, math_mode):
     assert rel_err(y, y2) < tol
 
 
-@pytest.mark.parametrize("math_mode", [1, 3])
+@pytest.mark.parametrize("math_mode", [1, 3, 4])
 @pytest.mark.parametrize("case", [(16, 64, 32, 64, 64, 32, 64, True), (16, 64, 32, 64, 96, 0, 128, False), (32, 32, 32, 32, 32, 32, 32, True)])
 def test_conv_with_fused_skip_connection(H, case, math_mode):
     """pdae_conv2d_fwd_skip: conv3x3(in) + conv1x1([s0 | s1]) + both biases in one launch, with plain and fused-GroupNorm main input."""
@@ -580,8 +580,8 @@ def test_conv_with_fused_skip_connection(H, case, math_mode):
     nb = c.wprep_bytes(0, force=True, gn=use_gn)
     wp = torch.empty(nb // 4, device="cuda")
     H.run(H.op_conv_wprep(c, wd, 4 if use_gn else 0, wp))
-    wps = torch.empty(cs.wprep_bytes(0) // 4, device="cuda")
-    H.run(H.op_conv_wprep(cs, wsd, 0, wps))
+    wps = torch.empty(H.conv_skip_wprep_bytes(c, cs) // 4, device="cuda")
+    H.run(H.op_conv_skip_wprep(c, cs, wsd, wps))
     y = torch.empty(N, Hh, W, Cout, device="cuda")
     H.run(H.op_conv_fwd_skip(c, xd, None, coef, 1, wp, b.cuda(), cs, s0, s1, wps, bsk.cuda(), y))
     assert rel_err(nchw(y), y_ref) < tol

@@ -2,14 +2,15 @@
 import csv, collections, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 stats_dir, pmc_prefix = sys.argv[1], sys.argv[2]
+math_name = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
 rows = list(csv.DictReader(open(glob.glob(os.path.join(ROOT, "gpurun_out", stats_dir, "*", "*_kernel_stats.csv"))[0])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ddim   (MI355X, bf16x6 default, B=32 FFHQ-128 RL step)",
+out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ddim   (MI355X, default arithmetic " + math_name + ", B=32 FFHQ-128 RL step)",
        "# 7 training steps are in the trace (2 warm-up + 4 timed + 1 per-op profile pass); durations in ns; Percentage of total GPU kernel time",
        f"# total kernel time {tot / 1e6:.1f} ms", f"{'Name':90s} {'Calls':>7s} {'TotalNs':>14s} {'AvgNs':>12s} {'Pct':>6s}"]
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
     out.append(f"{r['Name'][:90]:90s} {r['Calls']:>7s} {r['TotalDurationNs']:>14s} {float(r['AverageNs']):12.0f} {float(r['Percentage']):6.2f}")
-open(os.path.join(ROOT, "profiles", "r01_kernel_stats_bf16x6.txt"), "w").write("\n".join(out) + "\n")
+open(os.path.join(ROOT, "profiles", "r01_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
 print("\n".join(out[2:12]))
 
 
@@ -22,7 +23,7 @@ def agg(path):
 
 af = agg(glob.glob(os.path.join(ROOT, "gpurun_out", pmc_prefix + "FETCH_SIZE", "*", "*_counter_collection.csv"))[0])
 aw = agg(glob.glob(os.path.join(ROOT, "gpurun_out", pmc_prefix + "WRITE_SIZE", "*", "*_counter_collection.csv"))[0])
-o = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ddim",
+o = {"math": math_name, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ddim",
      "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE counts wide coalesced reads at half their size (MI355X_MICROARCH.md, HBM "
               "section): fetch_bytes = 2 x FETCH_SIZE x 1024. Calibration inside this very trace: gn_apply_stream_kernel reads and writes tensors of equal size "
               "and reports WRITE_SIZE ~ 2 x FETCH_SIZE.", "kernels": {}}
