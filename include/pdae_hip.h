@@ -54,6 +54,7 @@ typedef struct pdae_conv_desc {
  * changes (it is ~1% of the convolution's time). */
 #define PDAE_WPREP_TRANSPOSED 1   /* weights for the data gradient */
 #define PDAE_WPREP_GN 4           /* forward conv with fused GroupNorm input (pdae_conv2d_fwd_gn): two sources allowed, W % 16 == 0 */
+#define PDAE_WPREP_F16_GRAD 16     /* with TRANSPOSED and math 4: data-gradient weights in the fp16 format (the launch then needs dy_amax) */
 #define PDAE_WPREP_FORCE 2        /* _bytes: shape eligibility only, ignore the "enough tiles to fill 256 CUs" heuristic */
 size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags);
 int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream);
@@ -83,12 +84,16 @@ int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* 
  * wp_t: NULL or pdae_conv_wprep(d, w, PDAE_WPREP_TRANSPOSED): the data gradient then runs as a forward convolution of dy (3x3: the
  * whole channel range only; 1x1: any 32-aligned ci_off). */
 int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
-                      int accumulate, int tile, pdae_stream_t stream);
+                      int accumulate, int tile, const float* dy_amax, pdae_stream_t stream);
+/* dy_amax (dgrad / wgrad, optional, math 4 only): device scalar max|dy| from pdae_amax.  When given, the 3x3 gradient kernels run the
+ * two-fp16-plane format too, with dy scaled by the power of two that puts its abs-max into [1024, 2048) (undone exactly in the epilogue);
+ * NULL: the exact three-plane bf16 split (range-free). */
+int pdae_amax(const float* x, size_t n, float* out, pdae_stream_t stream);
 /* dw[Cout][KH][KW][Cin] (+)= sum over pixels; split-K over pixels through the workspace, reduced in fixed order.
  * db (optional) [Cout] (+)= column sums of dy = the bias gradient; the 3x3 kernel takes them from its own dY staging (no second read of dy). */
 size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d);
 int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, float* db, int accumulate, void* ws,
-                      size_t ws_bytes, pdae_stream_t stream);
+                      size_t ws_bytes, const float* dy_amax, pdae_stream_t stream);
 
 /* ---- strided-batched GEMM (F.linear, torch.einsum of module.py:450-457 / 479-488, and their backward)
  * C[b][m][n] (+)= alpha * sum_k opA[b][m][k] * opB[b][k][n] + bias[n];  opA = A[m*lda+k] (transA=0) | A[k*lda+m] (1);
@@ -161,7 +166,7 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX
 };
 typedef struct pdae_op {
   int32_t kind;

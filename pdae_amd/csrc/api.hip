@@ -43,7 +43,7 @@ static void fwd_geom(ConvGeom& g, const pdae_conv_desc* d, const float* x0, cons
 
 // mode 4 (two fp16 planes, 3 products) is a FORWARD format: activations and weights live inside the fp16 range, gradients do not
 // (dY of a converged network underflows); every gradient kernel runs the exact three-plane bf16 split instead
-static int bwd_math(const pdae_conv_desc* d) { return d->math == 4 ? 3 : d->math; }
+static int bwd_math(const pdae_conv_desc* d, bool f16_grad = false) { return d->math == 4 ? (f16_grad ? 4 : 3) : d->math; }
 
 // fast-path kind of the forward (transposed = 0) / data-gradient (transposed = 1) convolution of d:
 //   3 = LDS-patch 3x3 kernel (conv3x3p.hip), 1 = 1x1 kernel (conv1x1.hip), 0 = generic implicit GEMM only
@@ -73,7 +73,7 @@ extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
   const int kind = fast_kind(d, transposed, !(flags & PDAE_WPREP_FORCE));
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
   if (kind == 3)
-    return transposed ? conv3x3p_wprep_bytes(bwd_math(d), Cin, d->Cout, Hl, Wl, d->N) : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
+    return transposed ? conv3x3p_wprep_bytes(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), Cin, d->Cout, Hl, Wl, d->N) : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
   if (kind == 1) {
     const long long M = (long long)d->N * d->Ho * d->Wo;
     return transposed ? conv1x1_wprep_bytes(d->math, Cin, d->Cout, M) : conv1x1_wprep_bytes(d->math, d->Cout, Cin, M);
@@ -92,7 +92,7 @@ extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flag
   const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
   PDAE_CHECK_ARG(kind != 0, "conv_wprep: convolution shape not eligible for a prepared-weight kernel");
   if (kind == 3) {
-    if (transposed) return conv3x3p_wprep(bwd_math(d), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
+    if (transposed) return conv3x3p_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
     return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream));
   }
   if (transposed) return conv1x1_wprep(d->math, w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
@@ -173,7 +173,7 @@ extern "C" int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, co
 }
 
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
-                                 int accumulate, int tile, pdae_stream_t stream) {
+                                 int accumulate, int tile, const float* dy_amax, pdae_stream_t stream) {
   if (int e = check_desc(d)) return e;
   const int Cin = d->C0 + d->C1;
   PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
@@ -183,8 +183,8 @@ extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const
   PDAE_CHECK_ARG(!wp_t || (tile == 0 && ((kind == 3 && ci_off == 0 && ci_cnt == Cin) || (kind == 1 && (ci_off & 31) == 0 && (ci_cnt & 3) == 0))),
                  "conv2d_dgrad: wp_t given but the convolution / channel range is not eligible for a prepared-weight kernel");
   if (kind == 3)
-    return conv3x3p_launch(bwd_math(d), dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, (const unsigned short*)wp_t, Cin, dx, nullptr, nullptr, 0,
-                           accumulate, S(stream));
+    return conv3x3p_launch(bwd_math(d, dy_amax != nullptr), dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, (const unsigned short*)wp_t, Cin, dx, nullptr,
+                           nullptr, 0, accumulate, S(stream), nullptr, 0, nullptr, 0, nullptr, dy_amax);
   if (kind == 1)
     return conv1x1_launch(d->math, dy, d->Cout, nullptr, 0, (long long)d->N * d->Ho * d->Wo, (const unsigned short*)wp_t, Cin, ci_off, ci_cnt, dx,
                           nullptr, nullptr, 0, d->Ho, d->Wo, accumulate, S(stream));
@@ -235,7 +235,7 @@ extern "C" size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d) {
 }
 
 extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, float* db, int accumulate,
-                                 void* ws, size_t ws_bytes, pdae_stream_t stream) {
+                                 void* ws, size_t ws_bytes, const float* dy_amax, pdae_stream_t stream) {
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "conv2d_wgrad: null pointer");
   const size_t pb = wgrad_path_bytes(d);
@@ -251,7 +251,7 @@ extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const
   if (conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout)) {
     float* part = nullptr; int rows = 0;                                  // bias gradient: column sums of dY fall out of the dY staging
     if (int e = conv3x3w_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, dy, d->Cout, dw, accumulate, (float*)ws, wsb, S(stream),
-                                db ? &part : nullptr, db ? &rows : nullptr))
+                                db ? &part : nullptr, db ? &rows : nullptr, dy_amax))
       return e;
     return db ? k_colsum(part, rows, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;
   }
@@ -340,6 +340,10 @@ extern "C" int pdae_mlp_modln_bwd(const float* u, const float* e, const float* g
                                   pdae_stream_t stream) {
   return k_mlp_modln_bwd(u, e, gamma, beta, mean, rstd, dy, R, C, norm, act, du, de, tg, tb, S(stream));
 }
+extern "C" int pdae_amax(const float* x, size_t n, float* out, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x && out && n > 0 && (((uintptr_t)x) & 15) == 0, "amax: bad arguments (x must be 16-byte aligned)");
+  return k_amax(x, n, out, S(stream));
+}
 extern "C" int pdae_silu(const float* x, float* y, size_t n, pdae_stream_t stream) { return k_silu(x, y, n, S(stream)); }
 extern "C" int pdae_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int acc, pdae_stream_t stream) {
   return k_silu_bwd(x, dy, dx, n, acc, S(stream));
@@ -409,8 +413,8 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
   pdae_conv_desc d;
   switch (o.kind) {
     case PDAE_OP_CONV_FWD: desc_from(i, d); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), p[6], F(3), F(4), (int)i[14], FM(5), (int)i[15], st);
-    case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), p[3], FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], st);
-    case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), FM(5), (int)i[14], p[4], (size_t)i[15], st);
+    case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), p[3], FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], F(4), st);
+    case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), FM(5), (int)i[14], p[4], (size_t)i[15], F(6), st);
     case PDAE_OP_GEMM:
       return pdae_gemm((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), i[5], i[6], i[7], F(1), i[8], i[9], i[10], FM(2),
                        i[11], i[12], i[13], (int)i[14], (int)i[15], F(3), (int)i[16], st);
@@ -431,6 +435,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
       return pdae_mlp_modln_fwd(F(0), F(1), F(2), F(3), (int)i[0], (int)i[1], (int)i[2], (int)i[3], (float)f[0], FM(4), FM(5), FM(6), st);
     case PDAE_OP_MLP_MODLN_BWD:
       return pdae_mlp_modln_bwd(F(0), F(1), F(2), F(3), F(4), F(5), F(6), (int)i[0], (int)i[1], (int)i[2], (int)i[3], FM(7), FM(8), FM(9), FM(10), st);
+    case PDAE_OP_AMAX: return pdae_amax(F(0), (size_t)i[0], FM(1), st);
     case PDAE_OP_SILU: return pdae_silu(F(0), FM(1), (size_t)i[0], st);
     case PDAE_OP_SILU_BWD: return pdae_silu_bwd(F(0), F(1), FM(2), (size_t)i[0], (int)i[1], st);
     case PDAE_OP_AXPBY: return pdae_axpby(F(0), FM(1), (size_t)i[0], (float)f[0], (float)f[1], st);

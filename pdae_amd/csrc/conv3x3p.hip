@@ -82,9 +82,19 @@ struct PatchParams {
   // fused 1x1 skip convolution (ResBlock skip_connection, module.py:276,297): nx extra 32-channel chunks of the raw two-source tensor
   // [s0 | s1] enter the K loop with the centre tap only, weights wps = conv1x1_wprep layout, bias_x added in the epilogue
   int nx; const float* s0; const float* s1; int Cs0, Cs1; const unsigned short* wps; const float* bias_x;
-  float oscale;                         // fp16 format: the prepared weights carry a power-of-two scale (conv3x3p_wscale); accumulators * oscale
+  float woscale;                        // fp16 format: 1 / (power-of-two scale of the prepared weights, conv3x3p_wscale)
+  const float* amax;                    // fp16 format: NULL = activations (static 2^4 pre-scale); else device scalar max|input| (pdae_amax)
+                                        // -> power-of-two scale putting the input's abs-max into [1024, 2048): gradients (dY) as input
 };
 
+// 2^(10 - floor(log2(amax))): amax * scale in [1024, 2048)  (amax == 0 or non-finite: 1)
+__device__ __forceinline__ float p_pow2_scale(float amax) {
+  const int ex = (__float_as_int(amax) >> 23) & 0xff;
+  if (ex == 0 || ex == 255) return 1.0f;
+  int sb = 127 + 10 - (ex - 127);
+  sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+  return __int_as_float(sb << 23);
+}
 __device__ __forceinline__ float p_silu(float v) { return v / (1.0f + expf(-v)); }
 
 template <int NS, int PTH, bool W8, bool GN = false>
@@ -130,6 +140,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
       }
     }
   }
+  const float ascale = NS == 4 ? (P.amax ? p_pow2_scale(*P.amax) : PASCALE) : 1.0f;
   float4 apre[PA_LD];
   float4 gmu, gsc, gsh;                          // GN: coefficients of this thread's 4 channels in the chunk being loaded
   bool pre_raw = false;                          // the registers hold a skip chunk (raw input: no GroupNorm map)
@@ -173,8 +184,8 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
         }
         if constexpr (NS == 4) {                // fp16 format: exact power-of-two pre-scale, window [2^-7, 4094] keeps both planes normal
           // saturate instead of overflowing to inf (|x| > 3750 cannot occur behind GroupNorm; a stray value must not poison the tile)
-          apre[l].x = fminf(fmaxf(apre[l].x * PASCALE, -60000.f), 60000.f); apre[l].y = fminf(fmaxf(apre[l].y * PASCALE, -60000.f), 60000.f);
-          apre[l].z = fminf(fmaxf(apre[l].z * PASCALE, -60000.f), 60000.f); apre[l].w = fminf(fmaxf(apre[l].w * PASCALE, -60000.f), 60000.f);
+          apre[l].x = fminf(fmaxf(apre[l].x * ascale, -60000.f), 60000.f); apre[l].y = fminf(fmaxf(apre[l].y * ascale, -60000.f), 60000.f);
+          apre[l].z = fminf(fmaxf(apre[l].z * ascale, -60000.f), 60000.f); apre[l].w = fminf(fmaxf(apre[l].w * ascale, -60000.f), 60000.f);
         }
         unsigned a[NPL(NS)], b[NPL(NS)];
         p_split2<NS>(apre[l].x, apre[l].y, a);
@@ -289,6 +300,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   // dead by now) so that global traffic is float4 per lane, 16 lanes per pixel row: 256-byte contiguous runs, 4x fewer store
   // instructions than storing the MFMA layout directly (the dword-per-lane form is store-issue bound)
   const long long Mtot = (long long)P.N * P.H * P.W;
+  const float oscale = NS == 4 ? P.woscale / ascale : 1.0f;      // exact: powers of two
   __syncthreads();                                        // all waves are done reading the patch
   float* tw = reinterpret_cast<float*>(smem) + wv * (32 * EPW);
   const int er = lane >> 4, ec = (lane & 15) * 4;         // read side: row within a group of 4, first of 4 channels
@@ -329,7 +341,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + b * 32 + li] = NS == 4 ? acc[a][b][r] * P.oscale : acc[a][b][r];
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + b * 32 + li] = NS == 4 ? acc[a][b][r] * oscale : acc[a][b][r];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * EPW + ec]);
@@ -460,10 +472,10 @@ size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { re
 
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1, int C0,
-                    const float* coef, int act, const PatchSkip* sk) {
+                    const float* coef, int act, const PatchSkip* sk, const float* amax) {
   PatchParams P;
   P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
-  P.oscale = 1.0f / (conv3x3p_wscale(C) * PASCALE);
+  P.woscale = 1.0f / conv3x3p_wscale(C); P.amax = amax;
   P.nx = 0; P.s0 = P.s1 = nullptr; P.Cs0 = P.Cs1 = 0; P.wps = nullptr; P.bias_x = nullptr;
   if (sk) { P.nx = (sk->C0 + sk->C1) >> 5; P.s0 = sk->s0; P.s1 = sk->s1; P.Cs0 = sk->C0; P.Cs1 = sk->C1; P.wps = sk->wps; P.bias_x = sk->bias; }
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.wp = wp; P.NT = (Nout + 31) / 32; P.Nout = Nout;

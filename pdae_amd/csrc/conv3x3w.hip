@@ -19,6 +19,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// NS = 4: two fp16 planes, 3 products (see conv3x3p.hip); dY is scaled by a per-launch power of two derived from its abs-max
+#define WNPL(NS_) ((NS_) == 4 ? 2 : (NS_))
+#define WXSCALE 16.0f
 
 #define WTH 8
 #define WTW 16
@@ -37,8 +41,23 @@ __device__ __forceinline__ unsigned w_rn(float a, float b) {
   unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
   return (unsigned)x | ((unsigned)y << 16);
 }
-template <int NS> __device__ __forceinline__ void w_split2(float e0, float e1, unsigned (&w)[NS]) {
-  if constexpr (NS == 1) { w[0] = w_rn(e0, e1); }
+__device__ __forceinline__ unsigned w_pack_h(_Float16 a, _Float16 b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+// 2^(10 - floor(log2(amax))): amax * scale in [1024, 2048)  (amax == 0 or non-finite: 1)
+__device__ __forceinline__ float w_pow2_scale(float amax) {
+  const int ex = (__float_as_int(amax) >> 23) & 0xff;
+  if (ex == 0 || ex == 255) return 1.0f;
+  int sb = 127 + 10 - (ex - 127);
+  sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+  return __int_as_float(sb << 23);
+}
+template <int NS> __device__ __forceinline__ void w_split2(float e0, float e1, unsigned (&w)[WNPL(NS)]) {
+  if constexpr (NS == 4) {
+    const _Float16 h0 = (_Float16)e0, h1 = (_Float16)e1;
+    w[0] = w_pack_h(h0, h1);
+    w[1] = w_pack_h((_Float16)(e0 - (float)h0), (_Float16)(e1 - (float)h1));
+  } else if constexpr (NS == 1) { w[0] = w_rn(e0, e1); }
   else {
     float h0 = w_trunc(e0), h1 = w_trunc(e1);
     float r0 = e0 - h0, r1 = e1 - h1;
@@ -53,12 +72,12 @@ template <int NS> __device__ __forceinline__ void w_split2(float e0, float e1, u
 }
 
 // two transposing reads -> 8 consecutive k (pixel rows r0..r0+7 as seen by this lane's half) of this lane's column
-__device__ __forceinline__ bf16x8 tr_frag(unsigned addr_lo, unsigned addr_hi) {
+__device__ __forceinline__ uint4 tr_frag(unsigned addr_lo, unsigned addr_hi) {
   unsigned long long v0, v1;
   asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                : "=&v"(v0), "=&v"(v1) : "v"(addr_lo), "v"(addr_hi) : "memory");
   uint4 u = make_uint4((unsigned)v0, (unsigned)(v0 >> 32), (unsigned)v1, (unsigned)(v1 >> 32));
-  return __builtin_bit_cast(bf16x8, u);
+  return u;
 }
 
 struct WgradParams {
@@ -69,13 +88,14 @@ struct WgradParams {
   int tiles_x, tiles_y, ntiles;          // pixel tiles per image / total
   int tiles_per_split, splits;
   int co_tiles, ci_chunks;
+  const float* dy_amax;                  // fp16 format: device scalar max|dY| (pdae_amax) -> power-of-two dY scale
   float* db_part;                        // optional bias-gradient partials [splits][Cout] (column sums of dY, written by the ci_chunk 0 blocks)
 };
 
 template <int NS>
 __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  constexpr int SX = NS * WNPIX * WSX;
+  constexpr int SX = WNPL(NS) * WNPIX * WSX;
   unsigned short* sX = smem;                 // [NS][180][WSX]
   unsigned short* sY = smem + SX;            // [NS][128][WSY]
 
@@ -104,7 +124,8 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
   const bool want_db = P.db_part != nullptr && ci_chunk == 0;       // this block also owns the column sums of its dY tiles
   // per-thread running column sums live in LDS behind the operand planes (thread-private slots: deterministic, no registers held
   // across the MFMA phase -- the kernel sits at the 256-VGPR limit); thread: output channels (t & 31) * 4 .. +3, pixels idx >> 5
-  float4* bred = reinterpret_cast<float4*>(smem + SX + NS * WTPIX * WSY);
+  float4* bred = reinterpret_cast<float4*>(smem + SX + WNPL(NS) * WTPIX * WSY);
+  const float yscale = NS == 4 ? w_pow2_scale(*P.dy_amax) : 1.0f;
   if (want_db) bred[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int tile) {
     int img = tile / (P.tiles_y * P.tiles_x); int rem = tile - img * P.tiles_y * P.tiles_x;
@@ -136,10 +157,14 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
     for (int l = 0; l < WX_LD; ++l) {
       int idx = t + WTHREADS * l; int pix = idx >> 3, qd = idx & 7;
       if (pix < WNPIX) {
-        unsigned u[NS], v[NS];
+        if constexpr (NS == 4) {
+          xpre[l].x = fminf(fmaxf(xpre[l].x * WXSCALE, -60000.f), 60000.f); xpre[l].y = fminf(fmaxf(xpre[l].y * WXSCALE, -60000.f), 60000.f);
+          xpre[l].z = fminf(fmaxf(xpre[l].z * WXSCALE, -60000.f), 60000.f); xpre[l].w = fminf(fmaxf(xpre[l].w * WXSCALE, -60000.f), 60000.f);
+        }
+        unsigned u[WNPL(NS)], v[WNPL(NS)];
         w_split2<NS>(xpre[l].x, xpre[l].y, u); w_split2<NS>(xpre[l].z, xpre[l].w, v);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sX[(p * WNPIX + pix) * WSX + qd * 4]) = make_uint2(u[p], v[p]);
+        for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sX[(p * WNPIX + pix) * WSX + qd * 4]) = make_uint2(u[p], v[p]);
       }
     }
     if (want_db) {
@@ -151,10 +176,11 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
 #pragma unroll
     for (int l = 0; l < WY_LD; ++l) {
       int idx = t + WTHREADS * l; int pix = idx >> 5, c4 = idx & 31;
-      unsigned u[NS], v[NS];
+      if constexpr (NS == 4) { ypre[l].x *= yscale; ypre[l].y *= yscale; ypre[l].z *= yscale; ypre[l].w *= yscale; }
+      unsigned u[WNPL(NS)], v[WNPL(NS)];
       w_split2<NS>(ypre[l].x, ypre[l].y, u); w_split2<NS>(ypre[l].z, ypre[l].w, v);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + c4 * 4]) = make_uint2(u[p], v[p]);
+      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + c4 * 4]) = make_uint2(u[p], v[p]);
     }
   };
 
@@ -169,31 +195,45 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
 #pragma unroll 1
     for (int kq = 0; kq < 4; ++kq) {
       const int kc = kq * 2 + kh;             // tile row handled by this wave (16 pixels = one k-chunk)
-      bf16x8 af[NS];
+      uint4 af[WNPL(NS)];
 #pragma unroll
-      for (int p = 0; p < NS; ++p) {
+      for (int p = 0; p < WNPL(NS); ++p) {
         unsigned ad = sY_base + y_lane + (unsigned)((p * WTPIX + kc * 16) * WSY * 2);
         af[p] = tr_frag(ad, ad + 4 * WSY * 2);
       }
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
         const int dy = tp / 3, dx = tp - dy * 3;
-        bf16x8 bfr[NS];
+        uint4 bfr[WNPL(NS)];
 #pragma unroll
-        for (int p = 0; p < NS; ++p) {
+        for (int p = 0; p < WNPL(NS); ++p) {
           unsigned ad = sX_base + x_lane + (unsigned)((p * WNPIX + (kc + dy) * WPW + dx) * WSX * 2);
           bfr[p] = tr_frag(ad, ad + 4 * WSX * 2);
         }
-        if constexpr (NS == 3) {
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[1], acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[2], acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bfr[0], acc[tp], 0, 0, 0);
+#define WA(P_) __builtin_bit_cast(bf16x8, af[P_])
+#define WB(P_) __builtin_bit_cast(bf16x8, bfr[P_])
+#define WAH(P_) __builtin_bit_cast(f16x8, af[P_])
+#define WBH(P_) __builtin_bit_cast(f16x8, bfr[P_])
+        if constexpr (NS == 4) {
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(0), WBH(1), acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(1), WBH(0), acc[tp], 0, 0, 0);
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(0), WBH(0), acc[tp], 0, 0, 0);
+        } else {
+          if constexpr (NS == 3) {
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(1), WB(1), acc[tp], 0, 0, 0);
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(2), acc[tp], 0, 0, 0);
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(2), WB(0), acc[tp], 0, 0, 0);
+          }
+          if constexpr (NS >= 2) {
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(1), acc[tp], 0, 0, 0);
+            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(1), WB(0), acc[tp], 0, 0, 0);
+          }
+          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(0), acc[tp], 0, 0, 0);
         }
-        if constexpr (NS >= 2) {
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], acc[tp], 0, 0, 0);
-        }
-        acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], acc[tp], 0, 0, 0);
+#undef WA
+#undef WB
+#undef WAH
+#undef WBH
       }
     }
   }
@@ -207,6 +247,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
       if (co < Cout) *reinterpret_cast<float4*>(P.db_part + (size_t)split * Cout + co) = s4;      // Cout % 4 == 0
     }
   }
+  const float oscale = NS == 4 ? 1.0f / (yscale * WXSCALE) : 1.0f;      // exact: both scales are powers of two
   // epilogue: slab (split*2 + kh) of the workspace, layout [Cout][9][C]
   float* slab = P.ws + (size_t)(split * 2 + kh) * Cout * 9 * C;
 #pragma unroll
@@ -214,7 +255,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (co < Cout) slab[((size_t)co * 9 + tp) * C + ci0 + li] = acc[tp][r];
+      if (co < Cout) slab[((size_t)co * 9 + tp) * C + ci0 + li] = NS == 4 ? acc[tp][r] * oscale : acc[tp][r];
     }
 }
 
@@ -251,7 +292,7 @@ size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout) {
 }
 
 template <int NS> static int launch_w(const WgradParams& P, hipStream_t s) {
-  const size_t smem = (size_t)(NS * WNPIX * WSX + NS * WTPIX * WSY) * sizeof(unsigned short) + WTHREADS * sizeof(float4);   // + bias-sum slots
+  const size_t smem = (size_t)(WNPL(NS) * WNPIX * WSX + WNPL(NS) * WTPIX * WSY) * sizeof(unsigned short) + WTHREADS * sizeof(float4);   // + bias-sum slots
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3w_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -263,8 +304,10 @@ template <int NS> static int launch_w(const WgradParams& P, hipStream_t s) {
 }
 
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
-                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows) {
+                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax) {
   WgradParams P;
+  P.dy_amax = dy_amax;
+  if (math == 4 && !dy_amax) math = 3;          // fp16 format needs the dY scale: without it the exact bf16 split runs
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.dy = dy; P.Cout = Cout; P.ws = ws;
   P.tiles_x = W / WTW; P.tiles_y = H / WTH; P.ntiles = N * P.tiles_x * P.tiles_y;
   wgradp_plan(N, H, W, C, Cout, P.splits, P.tiles_per_split);
@@ -273,7 +316,7 @@ int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   P.db_part = db_part ? ws + (size_t)P.splits * 2 * Cout * 9 * C : nullptr;
   if (db_part) { *db_part = P.db_part; *db_rows = P.splits; }
   if (!ws || ws_bytes < need) { pdae_set_error("conv3x3w: workspace too small (%zu < %zu)", ws_bytes, need); return PDAE_EINVAL; }
-  int e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : launch_w<3>(P, s));
+  int e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : (math == 4 ? launch_w<4>(P, s) : launch_w<3>(P, s)));
   if (e) return e;
   return igemm_splitk_reduce(ws, dw, (long long)Cout * 9 * C, P.splits * 2, accumulate, s);
 }

@@ -349,3 +349,29 @@ int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws,
   return pdae_launch_status("colsum");
 }
 
+// ---------------------------------------------------------------------------------------------
+// out[0] = max |x|  (non-negative floats order like their bit patterns: atomicMax on the bits; out must be zeroed by the caller --
+// k_amax does it).  Feeds the power-of-two operand scale of the fp16-format gradient kernels.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) amax_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+int k_amax(const float* x, size_t n, float* out, hipStream_t st) {
+  hipMemsetAsync(out, 0, sizeof(float), st);
+  size_t nb = (n / 4 + 255) / 256; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(amax_kernel, dim3((int)nb), dim3(256), 0, st, x, n, reinterpret_cast<unsigned*>(out));
+  return pdae_launch_status("amax");
+}
+

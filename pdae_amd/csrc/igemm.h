@@ -56,7 +56,7 @@ size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N);
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s);
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1 = nullptr,
-                    int C0 = 0, const float* coef = nullptr, int act = 0, const PatchSkip* sk = nullptr);
+                    int C0 = 0, const float* coef = nullptr, int act = 0, const PatchSkip* sk = nullptr, const float* amax = nullptr);
 size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs);
 int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s);
 bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, int Cs0, int Cs1);
@@ -65,7 +65,8 @@ bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, in
 bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Cout);
 size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout);
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
-                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part = nullptr, int* db_rows = nullptr);
+                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part = nullptr, int* db_rows = nullptr,
+                    const float* dy_amax = nullptr);
 
 // conv1x1.hip: 1x1 convolution (forward / data gradient) on prepared weights, activations staged through LDS
 bool conv1x1_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, int C1, int Nout);

@@ -21,6 +21,7 @@ int k_mlp_modln_fwd(const float* u, const float* e, const float* gamma, const fl
                     float* mean, float* rstd, hipStream_t st);
 int k_mlp_modln_bwd(const float* u, const float* e, const float* gamma, const float* beta, const float* mean, const float* rstd, const float* dy,
                     int R, int C, int norm, int act, float* du, float* de, float* tg, float* tb, hipStream_t st);
+int k_amax(const float* x, size_t n, float* out, hipStream_t st);
 int k_silu(const float* x, float* y, size_t n, hipStream_t st);
 int k_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int acc, hipStream_t st);
 int k_axpby(const float* x, float* y, size_t n, float alpha, float beta, hipStream_t st);

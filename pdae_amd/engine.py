@@ -141,6 +141,10 @@ class Builder:
         # ~2^-17 per product -- tighter than the TF32 convolutions of the reference's own cuDNN default -- and is NOT used for any reported number
         bm = os.environ.get("PDAE_BWD_MATH")
         self.bwd_math = H.MATH_NAMES[bm] if bm else None
+        # gradient convolutions of the f16x3 mode: fp16 format with a per-tensor power-of-two dY scale from its abs-max (pdae_amax), or ("0")
+        # the exact bf16 split
+        self.f16_grads = os.environ.get("PDAE_F16_GRADS", "1") != "0"
+        self._amax_dy, self._amax_buf, self._amax_until = None, None, -1
         self.fuse_db = os.environ.get("PDAE_FUSE_DB", "1") != "0"      # bias gradients ride in the weight-gradient launch
         self.fuse_skip = os.environ.get("PDAE_FUSE_SKIP", "1") != "0"  # ResBlock skip_connection rides in conv2's K loop (conv_skip)
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
@@ -169,14 +173,14 @@ class Builder:
             self.p.free(wp)
         return y, NS(c=c, x0=x0, x1=x1, wname=wname, y=y)
 
-    def _wprep(self, c, w, transposed, gn=False):
+    def _wprep(self, c, w, transposed, gn=False, f16_grad=False):
         """Fragment-ordered bf16 planes of w for the patch kernel (None when the conv is not eligible).  Refreshed right before
         every use -- the weights change each optimizer step and the copy costs ~10 bytes per parameter, noise next to the
         convolution itself -- so no cache has to be kept coherent with the optimizer."""
-        nbytes = c.wprep_bytes(transposed, gn=gn)
+        nbytes = c.wprep_bytes(transposed, gn=gn, f16_grad=f16_grad)
         if nbytes == 0:
             return None
-        transposed = int(transposed) | (4 if gn else 0)          # PDAE_WPREP_* flags from here on
+        transposed = int(transposed) | (4 if gn else 0) | (16 if f16_grad else 0)          # PDAE_WPREP_* flags from here on
         if self.frozen_of is not None and self.frozen_of.is_frozen_storage(w):
             # frozen weights (the pre-trained trunk of ShiftUNet: never touched by the optimizer / EMA kernels) are prepared once
             # per plan into a persistent buffer; Plan.run refreshes them when the module reports a parameter (re)load
@@ -192,6 +196,21 @@ class Builder:
         wp = self.p.buf((nbytes + 3) // 4)
         self.p.emit(H.op_conv_wprep(c, w, transposed, wp))
         return wp
+
+    def dy_amax(self, c, dy):
+        """Device scalar max|dy| for the fp16-format gradient kernels of conv c (None: they run the exact bf16 split).  wgrad and dgrad of
+        one layer are emitted back to back on the same dy: the scalar is computed once and shared."""
+        if not self.f16_grads or c.math != H.MATH_NAMES["f16x3"] or c.KH != 3 or c.stride != 1 or c.C1 != 0:
+            return None
+        if self._amax_dy is dy and self._amax_until == len(self.p.recs):
+            return self._amax_buf
+        buf = self.p.buf(4)
+        self.p.emit(H.op_amax(dy, dy.numel(), buf))
+        if self._amax_buf is not None:
+            self.p.free(self._amax_buf)
+        self._amax_dy, self._amax_buf = dy, buf
+        self._amax_until = len(self.p.recs)
+        return buf
 
     def _bwd_desc(self, c):
         """Descriptor of the backward launches of conv c: same geometry, arithmetic mode `bwd_math` when it is set (PDAE_BWD_MATH)."""
@@ -211,8 +230,11 @@ class Builder:
             self.p.need_ws(wsb)
             # the bias gradient rides along: the 3x3 kernel sums dY while staging it, the other paths run the column sum themselves
             ride = self.fuse_db
-            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None), ws_slot=4,
+            am = self.dy_amax(c, dy)
+            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am), ws_slot=4,
                         wsb_slot=len(c.fields()) + 1)
+            if am is not None:
+                self._amax_until = len(self.p.recs)
             if ride:
                 gb = None
         if gb is not None:
@@ -226,8 +248,11 @@ class Builder:
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
         whole = ci_off == 0 and ci_cnt == c.Cin
-        wp_t = self._wprep(c, w, 1) if (whole or (c.KH == 1 and ci_off % 32 == 0 and ci_cnt % 4 == 0)) else None
-        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate, wp_t=wp_t))
+        am = self.dy_amax(c, dy) if whole else None
+        wp_t = self._wprep(c, w, 1, f16_grad=am is not None) if (whole or (c.KH == 1 and ci_off % 32 == 0 and ci_cnt % 4 == 0)) else None
+        if wp_t is None:
+            am = None
+        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate, wp_t=wp_t, dy_amax=am))
         if wp_t is not None:
             self.p.free(wp_t)
         return dx

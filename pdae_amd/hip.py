@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
- OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP) = range(1, 34)
+ OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX) = range(1, 35)
 
 
 class PdaeOp(ctypes.Structure):
@@ -73,7 +73,7 @@ def lib():
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
            "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
-           "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
+           "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_adam_ema", "pdae_run_ops"]
 
@@ -151,11 +151,11 @@ class Conv:
             setattr(d, n, v)
         return d
 
-    def wprep_bytes(self, transposed=0, force=False, gn=False):
+    def wprep_bytes(self, transposed=0, force=False, gn=False, f16_grad=False):
         """Size of the prepared-weight copy for the patch kernel; 0 = not eligible (generic kernel runs).
         gn: for the fused-GroupNorm forward (op_conv_fwd_gn); pass flags = 4 to op_conv_wprep as well."""
         d = self.cdesc()
-        return int(lib().pdae_conv_wprep_bytes(ctypes.byref(d), int(transposed) | (2 if force else 0) | (4 if gn else 0)))
+        return int(lib().pdae_conv_wprep_bytes(ctypes.byref(d), int(transposed) | (2 if force else 0) | (4 if gn else 0) | (16 if f16_grad else 0)))
 
     def wgrad_ws_bytes(self):
         d = self.cdesc()
@@ -191,8 +191,13 @@ def conv_fwd_skip_ok(c, cs):
     return bool(lib().pdae_conv2d_fwd_skip_ok(ctypes.byref(d), ctypes.byref(ds)))
 
 
-def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0, wp_t=None):
-    return make_op(OP_CONV_DGRAD, [dy, w, dx, wp_t], c.fields() + [ci_off, c.Cin if ci_cnt is None else ci_cnt, accumulate, tile])
+def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0, wp_t=None, dy_amax=None):
+    return make_op(OP_CONV_DGRAD, [dy, w, dx, wp_t, dy_amax], c.fields() + [ci_off, c.Cin if ci_cnt is None else ci_cnt, accumulate, tile])
+
+
+def op_amax(x, n, out):
+    """out[0] = max |x| (device scalar): feeds the power-of-two dY scale of the fp16-format gradient kernels."""
+    return make_op(OP_AMAX, [x, out], [n])
 
 
 def op_conv_wprep(c, w, transposed, wp):
@@ -200,9 +205,9 @@ def op_conv_wprep(c, w, transposed, wp):
     return make_op(OP_CONV_WPREP, [w, wp], c.fields() + [transposed])
 
 
-def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0, db=None):
+def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0, db=None, dy_amax=None):
     """dw (+)= weight gradient; db (optional): bias gradient = column sums of dy, same accumulate flag."""
-    return make_op(OP_CONV_WGRAD, [x0, x1, dy, dw, ws, db], c.fields() + [accumulate, ws_bytes])
+    return make_op(OP_CONV_WGRAD, [x0, x1, dy, dw, ws, db, dy_amax], c.fields() + [accumulate, ws_bytes])
 
 
 def op_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=None, accumulate=0,

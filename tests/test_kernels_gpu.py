@@ -585,3 +585,34 @@ def test_conv_with_fused_skip_connection(H, case, math_mode):
     y = torch.empty(N, Hh, W, Cout, device="cuda")
     H.run(H.op_conv_fwd_skip(c, xd, None, coef, 1, wp, b.cuda(), cs, s0, s1, wps, bsk.cuda(), y))
     assert rel_err(nchw(y), y_ref) < tol
+
+
+@pytest.mark.parametrize("gscale", [1.0, 3e-7, 2e4])
+@pytest.mark.parametrize("case", [(4, 32, 32, 64, 128), (2, 16, 48, 128, 96), (3, 8, 8, 64, 64), (8, 64, 64, 32, 32)])
+def test_f16_format_gradient_kernels_with_dynamic_scale(H, case, gscale):
+    """math 4 with dy_amax: data gradient (patch kernel on transposed fp16-format weights) and weight gradient (conv3x3w, fp16 planes) with
+    the per-tensor power-of-two dY scale, for gradients of ordinary, tiny (3e-7) and large magnitude -- fp32-grade at every scale."""
+    N, Hh, W, Cin, Cout = case
+    x = rn(1, N, Cin, Hh, W)
+    w = rn(2, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(Cin * 9))
+    dy = rn(5, N, Cout, Hh, W) * gscale
+    c = H.Conv(N, Hh, W, Cin, 0, Cout, k=3, math=4)
+    xl = x.double().clone().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    (F.conv2d(xl, wr, None, padding=1) * dy.double()).sum().backward()
+    xd, wd, dyd = nhwc(x).cuda(), nhwc(w).cuda(), nhwc(dy).cuda()
+    am = torch.empty(4, device="cuda")
+    H.run(H.op_amax(dyd, dyd.numel(), am))
+    assert abs(float(am[0]) - float(dy.abs().max())) <= 1e-6 * float(dy.abs().max())
+    nbt = c.wprep_bytes(1, force=True, f16_grad=True)
+    assert nbt > 0
+    wp_t = torch.empty(nbt // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 1 | 16, wp_t))
+    dx = torch.empty(N, Hh, W, Cin, device="cuda")
+    H.run(H.op_conv_dgrad(c, dyd, wd, dx, wp_t=wp_t, dy_amax=am))
+    assert rel_err(nchw(dx), xl.grad) < 1e-5
+    wsb = c.wgrad_ws_bytes()
+    dw, db = torch.empty_like(wd), torch.empty(Cout, device="cuda")
+    H.run(H.op_conv_wgrad(c, xd, None, dyd, dw, ws(wsb), wsb, db=db, dy_amax=am))
+    assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2e-5
+    assert rel_err(db, dy.double().sum((0, 2, 3))) < 1e-5
