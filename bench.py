@@ -238,13 +238,14 @@ def main():
         def op_npm(op):                               # MFMAs issued per algorithmic product by the kernel that runs this op
             if math == "f16x3":                       # two fp16 planes in the forward 3x3 patch kernel only; everything else bf16x6
                 fwd3 = op.kind in (H.OP_CONV_FWD_GN, H.OP_CONV_FWD_SKIP) or (op.kind == H.OP_CONV_FWD and bool(op.p[6]) and op.i[8] == 3)
-                return 3 if fwd3 else 6
+                grad3 = (op.kind == H.OP_CONV_DGRAD and bool(op.p[4])) or (op.kind == H.OP_CONV_WGRAD and bool(op.p[6]))     # dy_amax given
+                return 3 if (fwd3 or grad3) else 6
             return npm
         # peak for the arithmetic actually executed: f32 MFMA 157.3 TF, or the dense bf16 MFMA peak divided by the number of
         # bf16 MFMAs issued per algorithmic product (6 for the exact 3-plane split)
         peak = PEAK_F32_MFMA_TFLOPS if math == "f32" else PEAK_BF16_MFMA_TFLOPS / npm
         out["dtype"] = {"f32": "f32", "bf16": "bf16",
-                        "f16x3": "f32 as split-operand MFMA (forward 3x3: 2 fp16 planes x3 products; gradients / 1x1: 3 bf16 planes x6), fp32 accumulate",
+                        "f16x3": "f32 as split-operand MFMA (3x3 convs fwd/dgrad/wgrad: 2 fp16 planes x3 products, power-of-two scaled; 1x1 / generic: 3 bf16 planes x6), fp32 accumulate",
                         }.get(math, f"f32 as {math} split-operand MFMA, fp32 accumulate")
         # dominant kernel: conv3x3p_kernel (3x3 forward + data gradient on the patch path = ops that carry prepared weights)
         def is_patch(op):

@@ -31,9 +31,10 @@ MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2, 3      # pdae_conv_desc
 MATH_NAMES = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
 # default arithmetic of the conv GEMMs on fp32 tensors.  Every fp32 operand is split into low-precision planes whose leading cross
 # products are accumulated in fp32 on the MFMA pipe:
-#   "f16x3"  (default): FORWARD 3x3 patch convolutions use two fp16 planes (11+11 mantissa bits, 3 products, power-of-two pre-scales keep
-#            both planes normal); measured 2.8e-7 relative error vs fp64 on a 256->128 conv (torch fp32: 2.3e-7).  Every gradient kernel,
-#            the 1x1 and the generic kernels run "bf16x6" (gradients leave the fp16 range).
+#   "f16x3"  (default): the 3x3 kernels (forward, data gradient, weight gradient) use two fp16 planes (11+11 mantissa bits, 3 products);
+#            power-of-two operand scales keep both planes normal -- static for weights / normalised activations, per-tensor dynamic
+#            (pdae_amax) for gradients.  Measured 2.8e-7 relative error vs fp64 on a 256->128 conv (torch fp32: 2.3e-7).  The 1x1 and the
+#            generic kernels run "bf16x6".
 #   "bf16x6": three exact bf16 planes, 6 products (3.7e-7 on the same conv) everywhere -- range-safe for any input.
 # Both pass the same parity gates as the exact f32-MFMA kernels ("f32"), which remain selectable with PDAE_CONV_MATH.
 DEFAULT_MATH = "f16x3"
