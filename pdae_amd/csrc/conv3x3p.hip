@@ -184,8 +184,10 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
         }
         if constexpr (NS == 4) {                // fp16 format: exact power-of-two pre-scale, window [2^-7, 4094] keeps both planes normal
           // saturate instead of overflowing to inf (|x| > 3750 cannot occur behind GroupNorm; a stray value must not poison the tile)
-          apre[l].x = fminf(fmaxf(apre[l].x * ascale, -60000.f), 60000.f); apre[l].y = fminf(fmaxf(apre[l].y * ascale, -60000.f), 60000.f);
-          apre[l].z = fminf(fmaxf(apre[l].z * ascale, -60000.f), 60000.f); apre[l].w = fminf(fmaxf(apre[l].w * ascale, -60000.f), 60000.f);
+          // skip chunks carry the RAW residual stream (no GroupNorm in front): unit activation scale, the 2^4 sits in their weights instead
+          const float sc = pre_raw ? 1.0f : ascale;
+          apre[l].x = fminf(fmaxf(apre[l].x * sc, -60000.f), 60000.f); apre[l].y = fminf(fmaxf(apre[l].y * sc, -60000.f), 60000.f);
+          apre[l].z = fminf(fmaxf(apre[l].z * sc, -60000.f), 60000.f); apre[l].w = fminf(fmaxf(apre[l].w * sc, -60000.f), 60000.f);
         }
         unsigned a[NPL(NS)], b[NPL(NS)];
         p_split2<NS>(apre[l].x, apre[l].y, a);
@@ -557,5 +559,5 @@ size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs) {
   return (((size_t)NS * (Cs >> 5) * 2 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short)) + 255) & ~(size_t)255;
 }
 int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s) {
-  return wprep_launch(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain), 1, wp, s);
+  return wprep_launch(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain) * PASCALE, 1, wp, s);      // x PASCALE: the skip chunks' activations are unscaled
 }
