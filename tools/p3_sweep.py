@@ -14,7 +14,7 @@ for Cout in (128, 256):
     for C in (32, 64, 128, 256, 512):
         x = torch.randn(N, S, S, C, device="cuda"); w = torch.randn(Cout, 3, 3, C, device="cuda") / (C * 9) ** 0.5
         b = torch.randn(Cout, device="cuda"); y = torch.empty(N, S, S, Cout, device="cuda")
-        for m in (3, 1):
+        for m in (4, 3):
             c = H.Conv(N, S, S, C, 0, Cout, math=m)
             wp = torch.empty(c.wprep_bytes(0) // 4, device="cuda")
             t_prep = t(H.op_conv_wprep(c, w, 0, wp))
