@@ -76,7 +76,7 @@ extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
     return transposed ? conv3x3p_wprep_bytes(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), Cin, d->Cout, Hl, Wl, d->N) : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
   if (kind == 1) {
     const long long M = (long long)d->N * d->Ho * d->Wo;
-    return transposed ? conv1x1_wprep_bytes(d->math, Cin, d->Cout, M) : conv1x1_wprep_bytes(d->math, d->Cout, Cin, M);
+    return transposed ? conv1x1_wprep_bytes(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), Cin, d->Cout, M) : conv1x1_wprep_bytes(d->math, d->Cout, Cin, M);
   }
   return 0;
 }
@@ -95,7 +95,7 @@ extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flag
     if (transposed) return conv3x3p_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
     return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream));
   }
-  if (transposed) return conv1x1_wprep(d->math, w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
+  if (transposed) return conv1x1_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
   return conv1x1_wprep(d->math, w, d->Cout, Cin, 0, (unsigned short*)wp, S(stream));
 }
 
@@ -186,8 +186,8 @@ extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const
     return conv3x3p_launch(bwd_math(d, dy_amax != nullptr), dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, (const unsigned short*)wp_t, Cin, dx, nullptr,
                            nullptr, 0, accumulate, S(stream), nullptr, 0, nullptr, 0, nullptr, dy_amax);
   if (kind == 1)
-    return conv1x1_launch(d->math, dy, d->Cout, nullptr, 0, (long long)d->N * d->Ho * d->Wo, (const unsigned short*)wp_t, Cin, ci_off, ci_cnt, dx,
-                          nullptr, nullptr, 0, d->Ho, d->Wo, accumulate, S(stream));
+    return conv1x1_launch(bwd_math(d, dy_amax != nullptr), dy, d->Cout, nullptr, 0, (long long)d->N * d->Ho * d->Wo, (const unsigned short*)wp_t, Cin,
+                          ci_off, ci_cnt, dx, nullptr, nullptr, 0, d->Ho, d->Wo, accumulate, S(stream), dy_amax);
   GemmParams P;
   memset(&P, 0, sizeof(P));
   ConvGeom& g = P.a.g;

@@ -10,11 +10,17 @@
 // instruction make it TA-bound, 45 TFLOP/s; the LDS transpose costs less.)
 //
 // Replaces F.conv2d(k=1) / conv1d(k=1) of model/module.py:276,412,420 (ResBlock skip, attention qkv / proj) and their dX.
+#include <stdlib.h>
+
 #include "common.h"
 #include "igemm.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// NS = 4: two fp16 planes, 3 products (see conv3x3p.hip).  Activations enter unscaled (1x1 inputs may be the raw residual stream:
+// window up to 6e4) or, as gradients, with the per-tensor power-of-two scale from pdae_amax; the weights carry 2^4 * 2^ceil(log2(sqrt(C)))
+#define QNPL(NS_) ((NS_) == 4 ? 2 : (NS_))
 
 __device__ __forceinline__ float q_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 __device__ __forceinline__ unsigned q_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
@@ -22,8 +28,22 @@ __device__ __forceinline__ unsigned q_rn(float a, float b) {
   unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
   return (unsigned)x | ((unsigned)y << 16);
 }
-template <int NS> __device__ __forceinline__ void q_split2(float e0, float e1, unsigned (&w)[NS]) {
-  if constexpr (NS == 1) { w[0] = q_rn(e0, e1); }
+__device__ __forceinline__ unsigned q_pack_h(_Float16 a, _Float16 b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ float q_pow2_scale(float amax) {            // 2^(10 - floor(log2(amax))); 1 for 0 / non-finite
+  const int ex = (__float_as_int(amax) >> 23) & 0xff;
+  if (ex == 0 || ex == 255) return 1.0f;
+  int sb = 127 + 10 - (ex - 127);
+  sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
+  return __int_as_float(sb << 23);
+}
+template <int NS> __device__ __forceinline__ void q_split2(float e0, float e1, unsigned (&w)[QNPL(NS)]) {
+  if constexpr (NS == 4) {
+    const _Float16 h0 = (_Float16)e0, h1 = (_Float16)e1;
+    w[0] = q_pack_h(h0, h1);
+    w[1] = q_pack_h((_Float16)(e0 - (float)h0), (_Float16)(e1 - (float)h1));
+  } else if constexpr (NS == 1) { w[0] = q_rn(e0, e1); }
   else {
     float h0 = q_trunc(e0), h1 = q_trunc(e1);
     float r0 = e0 - h0, r1 = e1 - h1;
@@ -43,6 +63,7 @@ struct PointParams {
   const unsigned short* wp; int NT;                  // prepared weights [NS][C/16][NT][64][8], NT 32-channel tiles in it
   int nt_off, Nout;                                  // output channels = prepared rows nt_off*32 .. + Nout
   float* y; const float* bias; const float* res; int accumulate;
+  float woscale; const float* amax;                  // fp16 format: 1 / weight scale; device scalar max|input| (gradients) or NULL
   int res_mode, H, W;                                // res_mode 2: residual stored at half resolution (needs the image geometry)
   int tiles_m, tiles_n, splits, sps;                 // split-K: `splits` ranges of `sps` 16-channel steps
   float* slab;
@@ -57,7 +78,7 @@ __device__ __forceinline__ long long half_row(long long row, int H, int W) {
 #define QLDH 72                                          // bf16 per LDS row: 64 channels + 8 pad = 144 bytes
 template <int NS>
 __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
-  constexpr int SA_PLANES = NS * 128 * QLDH, SA_EPI = 4 * 32 * 68 * 2;        // operand planes | epilogue transpose tiles (4 waves x 32 x 68 fp32)
+  constexpr int SA_PLANES = QNPL(NS) * 128 * QLDH, SA_EPI = 4 * 32 * 68 * 2;        // operand planes | epilogue transpose tiles (4 waves x 32 x 68 fp32)
   __shared__ __attribute__((aligned(16))) unsigned short sA[SA_PLANES > SA_EPI ? SA_PLANES : SA_EPI];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
   const int wm = wv >> 1, wn = wv & 1;
@@ -71,6 +92,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   const int nsteps = P.C >> 4;
   const int s_begin = sp * P.sps, s_end = min(nsteps, s_begin + P.sps);      // 16-channel steps; sps is a multiple of 2
 
+  const float ascale = NS == 4 ? (P.amax ? q_pow2_scale(*P.amax) : 1.0f) : 1.0f;
   // ---- A staging: thread -> (pixel row = idx >> 4, channel quad = idx & 15), 8 float4 per thread and stage
   float4 apre[8];
   auto a_gload = [&](int s0) {                     // stage starting at step s0 (4 steps = 64 channels, fewer at the tail)
@@ -90,23 +112,27 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
       const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
-      unsigned a[NS], b[NS];
+      if constexpr (NS == 4) {
+        apre[l].x = fminf(fmaxf(apre[l].x * ascale, -60000.f), 60000.f); apre[l].y = fminf(fmaxf(apre[l].y * ascale, -60000.f), 60000.f);
+        apre[l].z = fminf(fmaxf(apre[l].z * ascale, -60000.f), 60000.f); apre[l].w = fminf(fmaxf(apre[l].w * ascale, -60000.f), 60000.f);
+      }
+      unsigned a[QNPL(NS)], b[QNPL(NS)];
       q_split2<NS>(apre[l].x, apre[l].y, a);
       q_split2<NS>(apre[l].z, apre[l].w, b);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) *reinterpret_cast<uint2*>(&sA[(p * 128 + row) * QLDH + qd * 4]) = make_uint2(a[p], b[p]);
+      for (int p = 0; p < QNPL(NS); ++p) *reinterpret_cast<uint2*>(&sA[(p * 128 + row) * QLDH + qd * 4]) = make_uint2(a[p], b[p]);
     }
   };
 
   const int nt0 = P.nt_off + (n0 >> 5);
   const int nt_end = P.nt_off + ((P.Nout + 31) >> 5);
   const size_t plane_stride = (size_t)nsteps * P.NT * 512;
-  auto ldb = [&](uint4 (&bq)[2][NS], int s) {
+  auto ldb = [&](uint4 (&bq)[2][QNPL(NS)], int s) {
     const unsigned short* base = P.wp + ((size_t)s * P.NT + nt0) * 512 + lane * 8;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int p = 0; p < NS; ++p)
+      for (int p = 0; p < QNPL(NS); ++p)
         bq[b][p] = (nt0 + b < nt_end) ? *reinterpret_cast<const uint4*>(base + p * plane_stride + b * 512) : make_uint4(0u, 0u, 0u, 0u);
   };
 
@@ -118,30 +144,42 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  auto step = [&](int s, const uint4 (&bq)[2][NS], uint4 (&bn)[2][NS]) {
+  auto step = [&](int s, const uint4 (&bq)[2][QNPL(NS)], uint4 (&bn)[2][QNPL(NS)]) {
     if (s + 1 < s_end) ldb(bn, s + 1);
     const int ks = (s - s_begin) & 3;               // step inside the staged 64 channels
-    bf16x8 af[2][NS];
+    uint4 af[2][QNPL(NS)];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int p = 0; p < NS; ++p)
-        af[a][p] = *reinterpret_cast<const bf16x8*>(&sA[(p * 128 + wm * 64 + a * 32 + li) * QLDH + ks * 16 + h * 8]);
+      for (int p = 0; p < QNPL(NS); ++p)
+        af[a][p] = *reinterpret_cast<const uint4*>(&sA[(p * 128 + wm * 64 + a * 32 + li) * QLDH + ks * 16 + h * 8]);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
+#define PDAE_A(P_) __builtin_bit_cast(bf16x8, af[a][P_])
 #define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[b][P_])
-        if constexpr (NS == 3) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], PDAE_B(1), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(2), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], PDAE_B(0), acc[a][b], 0, 0, 0);
+#define PDAE_AH(P_) __builtin_bit_cast(f16x8, af[a][P_])
+#define PDAE_BH(P_) __builtin_bit_cast(f16x8, bq[b][P_])
+        if constexpr (NS == 4) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(1), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(1), PDAE_BH(0), acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(0), acc[a][b], 0, 0, 0);
+        } else {
+          if constexpr (NS == 3) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(1), acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(2), acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(2), PDAE_B(0), acc[a][b], 0, 0, 0);
+          }
+          if constexpr (NS >= 2) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(1), acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(0), acc[a][b], 0, 0, 0);
+          }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(0), acc[a][b], 0, 0, 0);
         }
-        if constexpr (NS >= 2) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(1), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], PDAE_B(0), acc[a][b], 0, 0, 0);
-        }
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], PDAE_B(0), acc[a][b], 0, 0, 0);
+#undef PDAE_A
+#undef PDAE_AH
+#undef PDAE_BH
 #undef PDAE_B
       }
     // tile hand-over after every 4th step
@@ -153,7 +191,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
     }
   };
 
-  uint4 q0[2][NS], q1[2][NS];
+  uint4 q0[2][QNPL(NS)], q1[2][QNPL(NS)];
   if (s_begin < s_end) {
     a_gload(s_begin);
     ldb(q0, s_begin);
@@ -169,6 +207,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 
   // ---- epilogue: each wave transposes its 32-pixel x 64-channel accumulator groups through a private LDS tile (the activation tile is
   // dead by now) so that global traffic is float4 per lane in 256-byte runs; residual / accumulate operands are loaded up front
+  const float oscale = NS == 4 ? P.woscale / ascale : 1.0f;      // exact: powers of two
   __syncthreads();
   float* tw = reinterpret_cast<float*>(sA) + wv * (32 * 68);
   const int er = lane >> 4, ec = (lane & 15) * 4;
@@ -198,7 +237,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + li] = acc[a][b][r];
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + li] = NS == 4 ? acc[a][b][r] * oscale : acc[a][b][r];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * 68 + ec]);
@@ -232,7 +271,7 @@ __global__ void __launch_bounds__(256) conv1x1_reduce_kernel(const PointParams P
 // weight preparation: GEMM weight w'[n][c] -> [NS][C/16][NT][64][8] bf16 planes in B-fragment order.
 //   transposed = 0: w' = w [Nout][C];   transposed = 1 (data gradient): w'[n][c] = w[c][n], w stored [C][Nout]
 template <int NS>
-__global__ void __launch_bounds__(256) conv1x1_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed,
+__global__ void __launch_bounds__(256) conv1x1_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed, float wscale,
                                                             unsigned short* __restrict__ wp) {
   const size_t nslot = (size_t)(C >> 4) * NT * 64;
   const size_t plane_stride = nslot * 8;
@@ -252,10 +291,14 @@ __global__ void __launch_bounds__(256) conv1x1_wprep_kernel(const float* __restr
         for (int j = 0; j < 8; ++j) e[j] = w[(size_t)n * C + c + j];
       }
     }
-    unsigned a[NS], b[NS], cc[NS], d[NS];
+    if constexpr (NS == 4) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] *= wscale;
+    }
+    unsigned a[QNPL(NS)], b[QNPL(NS)], cc[QNPL(NS)], d[QNPL(NS)];
     q_split2<NS>(e[0], e[1], a); q_split2<NS>(e[2], e[3], b); q_split2<NS>(e[4], e[5], cc); q_split2<NS>(e[6], e[7], d);
 #pragma unroll
-    for (int p = 0; p < NS; ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
+    for (int p = 0; p < QNPL(NS); ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
   }
 }
 
@@ -288,14 +331,21 @@ bool conv1x1_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, i
 }
 
 static size_t point_prep_bytes(int math, int Nrows, int C) {
-  const int NS = math < 1 ? 1 : (math > 3 ? 3 : math);
+  const int NS = math < 1 ? 1 : (math == 4 ? 2 : (math > 3 ? 3 : math));
   const size_t b = (size_t)NS * (C >> 4) * ((Nrows + 31) / 32) * 512 * sizeof(unsigned short);
   return (b + 255) & ~(size_t)255;
+}
+
+// PDAE_C1_BF16=1 (tuning aid): the 1x1 kernels run the three-plane bf16 split also in mode 4
+static int c1_math(int math) {
+  static const bool off = getenv("PDAE_C1_BF16") != nullptr;
+  return (math == 4 && off) ? 3 : math;
 }
 
 // prepared weights of all Nrows GEMM-N rows + split-K slabs sized for ANY launch on a 32-aligned sub-range of the rows
 // (the data gradient of one concat source computes only that source's rows)
 size_t conv1x1_wprep_bytes(int math, int Nrows, int C, long long M) {
+  math = c1_math(math);
   size_t slab = 0;
   for (int nsub = 32; nsub <= ((Nrows + 31) & ~31); nsub += 32) {
     const int n = nsub < Nrows ? nsub : Nrows;
@@ -305,19 +355,28 @@ size_t conv1x1_wprep_bytes(int math, int Nrows, int C, long long M) {
   return point_prep_bytes(math, Nrows, C) + slab;
 }
 
+// power-of-two scale of the fp16-format prepared weights (x 2^4: the activations enter unscaled)
+static float conv1x1_wscale(int C) { int k = 0; while ((1 << (2 * k)) < C) ++k; return (float)(16 << k); }
+
 int conv1x1_wprep(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, hipStream_t s) {
+  math = c1_math(math);
+  const float wscale = conv1x1_wscale(C);
   const int NT = (Nrows + 31) / 32;
   const size_t nslot = (size_t)(C >> 4) * NT * 64;
   int grid = (int)((nslot + 255) / 256); if (grid > 4096) grid = 4096;
-  if (math == 1) hipLaunchKernelGGL(conv1x1_wprep_kernel<1>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wp);
-  else if (math == 2) hipLaunchKernelGGL(conv1x1_wprep_kernel<2>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wp);
-  else hipLaunchKernelGGL(conv1x1_wprep_kernel<3>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wp);
+  if (math == 1) hipLaunchKernelGGL(conv1x1_wprep_kernel<1>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wscale, wp);
+  else if (math == 2) hipLaunchKernelGGL(conv1x1_wprep_kernel<2>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wscale, wp);
+  else if (math == 4) hipLaunchKernelGGL(conv1x1_wprep_kernel<4>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wscale, wp);
+  else hipLaunchKernelGGL(conv1x1_wprep_kernel<3>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wscale, wp);
   return pdae_launch_status("conv1x1_wprep");
 }
 
 int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const unsigned short* wp, int Nrows, int row_off,
-                   int Nout, float* y, const float* bias, const float* res, int res_mode, int H, int W, int accumulate, hipStream_t s) {
+                   int Nout, float* y, const float* bias, const float* res, int res_mode, int H, int W, int accumulate, hipStream_t s,
+                   const float* amax) {
+  math = c1_math(math);
   PointParams P;
+  P.woscale = 1.0f / conv1x1_wscale(C0 + C1); P.amax = amax;
   P.res_mode = res_mode; P.H = H; P.W = W;
   P.x0 = x0; P.x1 = x1; P.C0 = C0; P.C1 = C1; P.M = M; P.C = C0 + C1; P.wp = wp; P.NT = (Nrows + 31) / 32;
   P.nt_off = row_off >> 5; P.Nout = Nout; P.y = y; P.bias = bias; P.res = res; P.accumulate = accumulate;
@@ -331,7 +390,7 @@ int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, l
     long long nb = (M * (Nout >> 2) + 255) / 256; if (nb > 4096) nb = 4096;              \
     hipLaunchKernelGGL(conv1x1_reduce_kernel, dim3((int)nb), dim3(256), 0, s, P);        \
   }
-  if (math == 1) { PDAE_C1(1) } else if (math == 2) { PDAE_C1(2) } else { PDAE_C1(3) }
+  if (math == 1) { PDAE_C1(1) } else if (math == 2) { PDAE_C1(2) } else if (math == 4) { PDAE_C1(4) } else { PDAE_C1(3) }
 #undef PDAE_C1
   return pdae_launch_status("conv1x1");
 }

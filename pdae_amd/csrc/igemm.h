@@ -73,7 +73,8 @@ bool conv1x1_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, i
 size_t conv1x1_wprep_bytes(int math, int Nrows, int C, long long M);
 int conv1x1_wprep(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, hipStream_t s);
 int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const unsigned short* wp, int Nrows, int row_off,
-                   int Nout, float* y, const float* bias, const float* res, int res_mode, int H, int W, int accumulate, hipStream_t s);
+                   int Nout, float* y, const float* bias, const float* res, int res_mode, int H, int W, int accumulate, hipStream_t s,
+                   const float* amax = nullptr);
 
 // skinny.hip: M <= 32 linear layers (one wave per output feature)
 bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch);

@@ -200,7 +200,9 @@ class Builder:
     def dy_amax(self, c, dy):
         """Device scalar max|dy| for the fp16-format gradient kernels of conv c (None: they run the exact bf16 split).  wgrad and dgrad of
         one layer are emitted back to back on the same dy: the scalar is computed once and shared."""
-        if not self.f16_grads or c.math != H.MATH_NAMES["f16x3"] or c.KH != 3 or c.stride != 1 or c.C1 != 0:
+        if not self.f16_grads or c.math != H.MATH_NAMES["f16x3"] or c.stride != 1:
+            return None
+        if not ((c.KH == 3 and c.C1 == 0) or c.KH == 1):
             return None
         if self._amax_dy is dy and self._amax_until == len(self.p.recs):
             return self._amax_buf
@@ -248,7 +250,7 @@ class Builder:
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
         whole = ci_off == 0 and ci_cnt == c.Cin
-        am = self.dy_amax(c, dy) if whole else None
+        am = self.dy_amax(c, dy) if (whole or c.KH == 1) else None
         wp_t = self._wprep(c, w, 1, f16_grad=am is not None) if (whole or (c.KH == 1 and ci_off % 32 == 0 and ci_cnt % 4 == 0)) else None
         if wp_t is None:
             am = None

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from tests.conftest import rel_err
 
 pytestmark = pytest.mark.gpu
-TOL = {0: 1e-5, 1: 2e-2, 3: 1e-5}
+TOL = {0: 1e-5, 1: 2e-2, 3: 1e-5, 4: 1e-5}
 
 
 def rn(seed, *shape, scale=1.0):
@@ -41,7 +41,7 @@ def _cases():
         C1 = rng.choice([0, 0, 32, 64]) if ksz == 1 else 0
         Cout = rng.choice([3, 32, 36, 64, 96, 128, 160])
         res_mode = rng.choice([0, 0, 1, 2 if (up or ksz == 1) and Hh % 2 == 0 and W % 2 == 0 else 0])
-        mode = rng.choice([3, 3, 1, 0])
+        mode = rng.choice([4, 4, 3, 1, 0])
         out.append((k, N, Hh, W, C0, C1, Cout, ksz, up, res_mode, mode))
     return out
 

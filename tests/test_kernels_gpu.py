@@ -440,7 +440,7 @@ def test_conv_bf16_split_modes(H, case, math_mode):
     assert rel_err(db, dy.double().sum((0, 2, 3))) < 1e-5          # exact fp32 sums in every math mode
 
 
-@pytest.mark.parametrize("math_mode", [1, 3])
+@pytest.mark.parametrize("math_mode", [1, 3, 4])
 @pytest.mark.parametrize("case", [(3, 16, 16, 128, 64, 96), (1, 8, 8, 256, 0, 64), (2, 12, 20, 64, 32, 36), (4, 32, 32, 64, 64, 160), (2, 16, 16, 96, 0, 64)])
 def test_conv1x1_kernel(H, case, math_mode):
     """conv1x1.hip: dual-source 1x1 conv with bias / residual (full and half resolution), split-K on small layers, and the data
@@ -487,6 +487,14 @@ def test_conv1x1_kernel(H, case, math_mode):
         dx1 = torch.full((N, Hh, W, C1), 1.0, device="cuda")
         H.run(H.op_conv_dgrad(c, dyd, wd, dx1, ci_off=C0, ci_cnt=C1, accumulate=1, wp_t=wp_t))
         assert rel_err(nchw(dx1), dxr[:, C0:] + 1.0) < tol
+    if math_mode == 4:          # fp16-format data gradient with the dynamic dY scale, for a tiny-magnitude gradient
+        dys = dyd * 1e-6
+        am = torch.empty(4, device="cuda")
+        H.run(H.op_amax(dys, dys.numel(), am))
+        wp_h = torch.empty(c.wprep_bytes(1, f16_grad=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 1 | 16, wp_h))
+        H.run(H.op_conv_dgrad(c, dys, wd, dx, wp_t=wp_h, dy_amax=am))
+        assert rel_err(nchw(dx), dxr * 1e-6) < tol
 
 
 @pytest.mark.parametrize("case", [(32, 256, 512, 0), (32, 1024, 512, 1), (7, 64, 128, 0), (32, 512, 4096, 0), (16, 768, 1032, 1), (1, 96, 72, 0)])
