@@ -232,7 +232,7 @@ class Builder:
             self.p.need_ws(wsb)
             # the bias gradient rides along: the 3x3 kernel sums dY while staging it, the other paths run the column sum themselves
             ride = self.fuse_db
-            am = self.dy_amax(c, dy)
+            am = self.dy_amax(c, dy) if c.KH == 3 else None          # the generic 1x1 weight-gradient kernel has no fp16 format
             self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am), ws_slot=4,
                         wsb_slot=len(c.fields()) + 1)
             if am is not None:
