@@ -143,10 +143,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (config/ffhq_representation_learning.yml:29)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ddim-batch", type=int, default=128, help="batch of the DDIM-100 sampling measurement (0 = the training batch)")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--math", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16", "f16x3"],
-                    help="conv arithmetic on fp32 tensors (default bf16x6 = exact 3-plane split, fp32 grade; f32 = f32 MFMA)")
+                    help="conv arithmetic on fp32 tensors (default f16x3 = two-fp16-plane split with power-of-two scales, fp32 grade; "
+                         "bf16x6 = exact 3-bf16-plane split; f32 = f32 MFMA)")
     args = ap.parse_args()
 
     if args.math:
@@ -306,8 +308,9 @@ def main():
         if not args.no_ddim:
             dec.set_eval_mode()
             with torch.no_grad():
-                z = torch.randn(B, 512, device=dev)
-                xT = torch.randn(B, 3, 128, 128, device=dev)
+                Bd = args.ddim_batch or B
+                z = torch.randn(Bd, 512, device=dev)
+                xT = torch.randn(Bd, 3, 128, 128, device=dev)
                 gd.representation_learning_ddim_sample("ddim10", None, dec, None, xT, z)       # builds the inference plan
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -315,8 +318,8 @@ def main():
                 torch.cuda.synchronize()
                 dd = time.perf_counter() - t1
             log("ddim100 done")
-            out["ddim100"] = {"samples_per_sec": round(B / dd, 3), "batch": B, "seconds": round(dd, 3),
-                              "tflops_algorithmic": round(FWD_GFLOP_PER_IMG * B * 100 / dd / 1e3, 2)}
+            out["ddim100"] = {"samples_per_sec": round(Bd / dd, 3), "batch": Bd, "seconds": round(dd, 3),
+                              "tflops_algorithmic": round(FWD_GFLOP_PER_IMG * Bd * 100 / dd / 1e3, 2)}
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_cores())
             log(f"cpu baseline on {host_cores()} host cores")
