@@ -120,7 +120,9 @@ int pdae_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H
 int pdae_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
                 const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p,
                 uint64_t seed, uint64_t offset, const float* add, float* dx0, int acc0, float* dx1, int acc1, float* dgamma, float* dbeta,
-                int acc_param, float* dss, float* dzss, void* ws, pdae_stream_t stream);
+                int acc_param, float* dss, float* dzss, void* ws, float* dx0_amax, pdae_stream_t stream);
+/* dx0_amax (optional): device scalar that receives max|dx0| -- the dy_amax of the convolution whose output gradient dx0 is (saves the
+ * separate pdae_amax pass over it). */
 
 /* ---- MLPSkipNet layer body (model/mlp_skip_net.py:123-141): per row of a [R][C] activation
  *   y = act( LayerNorm_C( u * (1 + e) ) * gamma + beta );  e may be NULL (no condition), norm = 0 skips the LayerNorm, act: 1 = SiLU.

@@ -316,9 +316,11 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(int N, int HW, int
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ ss,
                                                               const float* __restrict__ zss, float* __restrict__ dss,
-                                                              float* __restrict__ dzss, float* __restrict__ c12, float* __restrict__ pgb) {
+                                                              float* __restrict__ dzss, float* __restrict__ c12, float* __restrict__ pgb,
+                                                              unsigned* __restrict__ amax0) {
   __shared__ float g1[1024], g2[1024], m1[64], m2[64];
   const int n = blockIdx.x, cg = C / G, t = threadIdx.x;
+  if (amax0 && n == 0 && t == 0) *amax0 = 0u;      // the apply kernel (next launch on this stream) accumulates max|dx0| into it
   for (int c = t; c < C; c += 256) {
     float S0 = 0.f, S1 = 0.f;
     for (int k = 0; k < S; ++k) { const float* o = part + (((size_t)n * S + k) * C + c) * 2; S0 += o[0]; S1 += o[1]; }
@@ -363,14 +365,18 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H,
                                                            const float* __restrict__ c12, const float* __restrict__ dA, int act, int mode,
                                                            float drop_p, unsigned long long seed, unsigned long long offset,
                                                            const float* __restrict__ add, float* __restrict__ dx0, int acc0,
-                                                           float* __restrict__ dx1, int acc1) {
+                                                           float* __restrict__ dx1, int acc1, unsigned* __restrict__ amax0) {
+  __shared__ float wmax[4];
   const int n = blockIdx.y, NQ = C >> 2, PL = 256 / NQ, HW = H * W;
   const int t = threadIdx.x, q = t % NQ, pl = t / NQ, c = q * 4;
-  if (pl >= PL) return;
-  float* dbase; int accf, Cd, cd;
-  if (c < s.C0) { dbase = dx0; accf = acc0; Cd = s.C0; cd = c; }
-  else { dbase = dx1; accf = acc1; Cd = s.C1; cd = c - s.C0; }
-  if (!dbase) return;
+  float* dbase = nullptr; int accf = 0, Cd = 0, cd = 0;
+  if (pl < PL) {
+    if (c < s.C0) { dbase = dx0; accf = acc0; Cd = s.C0; cd = c; }
+    else { dbase = dx1; accf = acc1; Cd = s.C1; cd = c - s.C0; }
+  }
+  float vmax = 0.f;                               // max |value written to dx0| by this thread (the dY scale of the next gradient convs)
+  const bool track = amax0 != nullptr && dbase == dx0;
+  if (dbase) {
   const size_t NC = (size_t)N * C;
   const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
   const float4 mu = *reinterpret_cast<const float4*>(coef + (size_t)n * C + c);
@@ -406,7 +412,16 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H,
       if (add) { o.x += ad[u].x; o.y += ad[u].y; o.z += ad[u].z; o.w += ad[u].w; }
       if (accf) { o.x += ex[u].x; o.y += ex[u].y; o.z += ex[u].z; o.w += ex[u].w; }
       *reinterpret_cast<float4*>(dbase + pix * Cd + cd) = o;
+      if (track) vmax = fmaxf(fmaxf(vmax, fabsf(o.x)), fmaxf(fmaxf(fabsf(o.y), fabsf(o.z)), fabsf(o.w)));
     }
+  }
+  }
+  if (amax0) {                                    // block-wide max -> one atomic (non-negative floats order like their bit patterns)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    if ((t & 63) == 0) wmax[t >> 6] = vmax;
+    __syncthreads();
+    if (t == 0) atomicMax(amax0, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
   }
 }
 
@@ -488,9 +503,10 @@ int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, i
 int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
              const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p,
              unsigned long long seed, unsigned long long offset, const float* add, float* dx0, int acc0, float* dx1, int acc1,
-             float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, float* ws, hipStream_t st) {
+             float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, float* ws, hipStream_t st, float* dx0_amax) {
   if (int e = check_c(C0, C1, G)) return e;
   const int C = C0 + C1, HW = H * W;
+  unsigned* am = (dx0 && dx0_amax) ? reinterpret_cast<unsigned*>(dx0_amax) : nullptr;
   Src2 s{x0, x1, C0, C1};
   int S = stats_chunks(HW, C), chunk = cdiv(HW, S);
   S = cdiv(HW, chunk);
@@ -498,14 +514,14 @@ int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int
   float* c12 = ws + (size_t)N * 64 * C * 2;           // [N][C][2]
   float* pgb = c12 + (size_t)N * C * 2;               // [N][C][2]
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am);
   if (dgamma)
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, N, C, pgb, dgamma, dbeta, acc_param);
   if (dx0 || dx1) {
     int Sa = stream_chunks(HW, C), chunk_a = cdiv(HW, Sa);
     Sa = cdiv(HW, chunk_a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(Sa, N), dim3(256), 0, st, s, N, H, W, C, chunk_a, coef, c12, dA, act, mode, drop_p, seed, offset,
-                       add, dx0, acc0, dx1, acc1);
+                       add, dx0, acc0, dx1, acc1, am);
   }
   return pdae_launch_status("gn_bwd");
 }

@@ -197,6 +197,11 @@ class Builder:
         self.p.emit(H.op_conv_wprep(c, w, transposed, wp))
         return wp
 
+    def amax_ok(self, c):
+        """True when conv c's gradient kernels take a dY abs-max (fp16 format)."""
+        c = self._bwd_desc(c)
+        return bool(self.f16_grads and c.math == H.MATH_NAMES["f16x3"] and c.stride == 1 and ((c.KH == 3 and c.C1 == 0) or c.KH == 1))
+
     def dy_amax(self, c, dy):
         """Device scalar max|dy| for the fp16-format gradient kernels of conv c (None: they run the exact bf16 split).  wgrad and dgrad of
         one layer are emitted back to back on the same dy: the scalar is computed once and shared."""
@@ -222,7 +227,7 @@ class Builder:
         b.math = self.bwd_math
         return b
 
-    def conv_bwd_params(self, cx, dy):
+    def conv_bwd_params(self, cx, dy, amax=None):
         """dW, db of a conv stage (only if the parameter is trained by this plan)."""
         c = self._bwd_desc(cx.c)
         gw = self.Gr.get(cx.wname + ".weight")
@@ -232,7 +237,7 @@ class Builder:
             self.p.need_ws(wsb)
             # the bias gradient rides along: the 3x3 kernel sums dY while staging it, the other paths run the column sum themselves
             ride = self.fuse_db
-            am = self.dy_amax(c, dy) if c.KH == 3 else None          # the generic 1x1 weight-gradient kernel has no fp16 format
+            am = (amax if amax is not None else self.dy_amax(c, dy)) if c.KH == 3 else None   # generic 1x1 wgrad: no fp16 format
             self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am), ws_slot=4,
                         wsb_slot=len(c.fields()) + 1)
             if am is not None:
@@ -244,13 +249,13 @@ class Builder:
             self.p.need_ws(H.colsum_ws_bytes(M, c.Cout))
             self.p.emit(H.op_colsum(dy, M, c.Cout, gb, None, acc=self.acc), ws_slot=2)
 
-    def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0):
+    def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0, amax=None):
         c = self._bwd_desc(cx.c)
         ci_cnt = c.Cin if ci_cnt is None else ci_cnt
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
         whole = ci_off == 0 and ci_cnt == c.Cin
-        am = self.dy_amax(c, dy) if (whole or c.KH == 1) else None
+        am = (amax if amax is not None else self.dy_amax(c, dy)) if (whole or c.KH == 1) else None
         wp_t = self._wprep(c, w, 1, f16_grad=am is not None) if (whole or (c.KH == 1 and ci_off % 32 == 0 and ci_cnt % 4 == 0)) else None
         if wp_t is None:
             am = None
@@ -387,7 +392,7 @@ class Builder:
             pl.free(mean, rstd, coef)
         return ctx
 
-    def gn_bwd(self, g, dA, bmode, add=None, dx0=None, acc0=0, dx1=None, acc1=0, want_dss=False, want_dzss=False):
+    def gn_bwd(self, g, dA, bmode, add=None, dx0=None, acc0=0, dx1=None, acc1=0, want_dss=False, want_dzss=False, dx0_amax=None):
         """Backward of a gn() stage.  bmode: 0 same, 1 y was pooled, 2 consumer read y upsampled."""
         pl = self.p
         C = g.C0 + g.C1
@@ -398,7 +403,7 @@ class Builder:
         pl.need_ws(H.gn_ws_bytes(g.N, C))
         idx = pl.emit(H.op_gn_bwd(g.x0, g.C0, g.x1, g.C1, g.N, g.H, g.W, GROUPS, g.coef, g.rstd, gamma, beta, g.ss, g.zss, dA, g.act,
                                   bmode, None, add=add, dx0=dx0, acc0=acc0, dx1=dx1, acc1=acc1, dgamma=dgamma, dbeta=dbeta, acc_param=self.acc, dss=dss,
-                                  dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0), ws_slot=16)
+                                  dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0, dx0_amax=dx0_amax), ws_slot=16)
         if g.drop_p > 0:
             pl.drop_ops.append((idx, 11, 12))
         return dss, dzss
@@ -474,7 +479,8 @@ class Builder:
                 dx1 = self.conv_dgrad(r.cs, dout, ci_off=C0, ci_cnt=C1)
         # AdaGN + SiLU (+dropout)
         dh1 = pl.buf(*r.h1.shape)
-        dss, dzss = self.gn_bwd(g2, d_a2, 0, dx0=dh1, want_dss=True, want_dzss=True)
+        am1 = pl.buf(4) if self.amax_ok(r.c1.c) else None      # max|dh1| falls out of the GroupNorm-backward apply pass
+        dss, dzss = self.gn_bwd(g2, d_a2, 0, dx0=dh1, want_dss=True, want_dzss=True, dx0_amax=am1)
         pl.free(d_a2)
         self.linear_bwd(r.l_ss, dss, dx=d_ea, dx_acc=1)
         pl.free(dss)
@@ -482,10 +488,10 @@ class Builder:
             self.linear_bwd(r.l_zss, dzss, dx=d_eza, dx_acc=1)
             pl.free(dzss)
         # conv1
-        self.conv_bwd_params(r.c1, dh1)
+        self.conv_bwd_params(r.c1, dh1, amax=am1)
         trainable_gn1 = (g1.gname + ".weight") in self.Gr
         if need_dx0 or need_dx1 or trainable_gn1:
-            d_a1 = self.conv_dgrad(r.c1, dh1)
+            d_a1 = self.conv_dgrad(r.c1, dh1, amax=am1)
             bmode = 1 if r.down else (2 if r.up else 0)
             if need_dx0 and dx0 is None:
                 dx0 = pl.buf(g1.N, g1.H, g1.W, C0)
@@ -494,7 +500,7 @@ class Builder:
             self.gn_bwd(g1, d_a1, bmode, add=None if r.has_skip else dout, dx0=dx0 if need_dx0 else None, acc0=int(r.has_skip),
                         dx1=dx1 if need_dx1 else None, acc1=int(r.has_skip))
             pl.free(d_a1)
-        pl.free(dh1)
+        pl.free(dh1, am1)
         return dx0, dx1
 
     # ------------------------------------------------------------------ AttentionBlock

@@ -221,8 +221,10 @@ def test_groupnorm_family(H, case):
     dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     dss = torch.empty(N, 2 * C, device="cuda") if use_ss else None
     dzss = torch.empty(N, 2 * C, device="cuda") if use_zss else None
+    am = torch.full((4,), 123.0, device="cuda")          # receives max|dx0| (stale content must be overwritten)
     H.run(H.op_gn_bwd(x0, C0, x1, C1, N, Hh, W, G, coef, rstd, f32(gamma), f32(beta), f32(ss), f32(zss), nhwc(dA).cuda(), act, mode, wsp,
-                      add=None if add is None else nhwc(add).cuda(), dx0=dx0, dx1=dx1, dgamma=dg, dbeta=db, dss=dss, dzss=dzss))
+                      add=None if add is None else nhwc(add).cuda(), dx0=dx0, dx1=dx1, dgamma=dg, dbeta=db, dss=dss, dzss=dzss, dx0_amax=am))
+    assert float(am[0]) == float(dx0.abs().max())
     dx = torch.cat([dx0, dx1], -1) if C1 else dx0
     assert rel_err(nchw(dx), x.grad) < 2e-5
     assert rel_err(dg, gamma.grad) < 2e-5 and rel_err(db, beta.grad) < 2e-5
