@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0, "/root/repo")
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, math
 import torch.nn.functional as F
 from pdae_amd import hip as H
