@@ -26,13 +26,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define WTH 8
 #define WTW 16
-#define WPW (WTW + 2)
-#define WNPIX ((WTH + 2) * WPW)      // 180 patch pixels
+#define WPW_(W8_) ((W8_) ? 20 : WTW + 2)          // 8-pixel-wide images: two images side by side, their 10-pixel halo rows = pitch 20
+#define WNPIX_(W8_) ((WTH + 2) * WPW_(W8_))     // 180 (200) patch pixels
 #define WTPIX (WTH * WTW)            // 128 tile pixels
 #define WSX 40                       // X row stride (bf16): 32 ci + 8 pad
 #define WSY 136                      // dY row stride (bf16): 128 co + 8 pad
 #define WTHREADS 512
-#define WX_LD ((WNPIX * 8 + WTHREADS - 1) / WTHREADS)    // 3 float4 per thread
+#define WX_LD_(W8_) ((WNPIX_(W8_) * 8 + WTHREADS - 1) / WTHREADS)    // 3 (4) float4 per thread
 #define WY_LD (WTPIX * 32 / WTHREADS)                    // 8 float4 per thread
 
 __device__ __forceinline__ float w_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
@@ -92,8 +92,9 @@ struct WgradParams {
   float* db_part;                        // optional bias-gradient partials [splits][Cout] (column sums of dY, written by the ci_chunk 0 blocks)
 };
 
-template <int NS>
+template <int NS, bool W8 = false>
 __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P) {
+  constexpr int WPW = WPW_(W8), WNPIX = WNPIX_(W8), WX_LD = WX_LD_(W8);
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   constexpr int SX = WNPL(NS) * WNPIX * WSX;
   unsigned short* sX = smem;                 // [NS][180][WSX]
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
 
   // lane-constant parts of the transposing-read addresses (bytes)
   const unsigned y_lane = (unsigned)(((h * 8 + (i16 >> 2)) * WSY + a * 32 + g16 * 16 + (i16 & 3) * 4) * 2);
-  const unsigned x_lane = (unsigned)(((h * 8 + (i16 >> 2)) * WSX + g16 * 16 + (i16 & 3) * 4) * 2);
+  const unsigned x_lane = (unsigned)(((h * (W8 ? 10 : 8) + (i16 >> 2)) * WSX + g16 * 16 + (i16 & 3) * 4) * 2);   // W8: columns 8..15 = second image
   const unsigned sX_base = 0u, sY_base = (unsigned)(SX * 2);   // LDS byte offsets: the dynamic segment is the only LDS of this kernel
 
   float4 xpre[WX_LD], ypre[WY_LD];
@@ -130,6 +131,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
   auto gload = [&](int tile) {
     int img = tile / (P.tiles_y * P.tiles_x); int rem = tile - img * P.tiles_y * P.tiles_x;
     int ty = rem / P.tiles_x, tx = rem - ty * P.tiles_x;
+    if constexpr (W8) img *= 2;                 // first image of the pair
     const int y0 = ty * WTH, x0 = tx * WTW;
 #pragma unroll
     for (int l = 0; l < WX_LD; ++l) {
@@ -137,19 +139,22 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
       xpre[l] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pix < WNPIX) {
         int py = pix / WPW, px = pix - py * WPW;
-        int ly = y0 - 1 + py, lx = x0 - 1 + px;
-        if ((unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
+        int ly = y0 - 1 + py, lx = x0 - 1 + px, im = img;
+        if constexpr (W8) { const int sub = px >= 10; im = img + sub; lx = px - 1 - 10 * sub; }
+        if (im < P.N && (unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
           int sy = P.up ? ly >> 1 : ly, sx = P.up ? lx >> 1 : lx;
-          xpre[l] = *reinterpret_cast<const float4*>(P.x + ((size_t)(img * P.Hs + sy) * P.Ws + sx) * C + ci0 + qd * 4);
+          xpre[l] = *reinterpret_cast<const float4*>(P.x + ((size_t)(im * P.Hs + sy) * P.Ws + sx) * C + ci0 + qd * 4);
         }
       }
     }
 #pragma unroll
     for (int l = 0; l < WY_LD; ++l) {
       int idx = t + WTHREADS * l; int pix = idx >> 5, c4 = idx & 31;
-      int oy = y0 + (pix >> 4), ox = x0 + (pix & 15);
+      int oy = y0 + (pix >> 4), ox = x0 + (pix & 15), im = img;
+      if constexpr (W8) { im = img + ((pix & 15) >> 3); ox = pix & 7; }
       int co = co0 + c4 * 4;
-      ypre[l] = (co < Cout) ? *reinterpret_cast<const float4*>(P.dy + ((size_t)(img * P.H + oy) * P.W + ox) * Cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ypre[l] = (co < Cout && im < P.N) ? *reinterpret_cast<const float4*>(P.dy + ((size_t)(im * P.H + oy) * P.W + ox) * Cout + co)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto lstore = [&]() {
@@ -262,7 +267,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
 // split of the pixel tiles over blocks: one block per CU (147 KB of LDS at NS=3), so the grid should fill 256 CUs in whole rounds:
 // minimise rounds(grid) x tiles-per-block (a 264-block grid costs two rounds for the work of one)
 static void wgradp_plan(int N, int H, int W, int C, int Cout, int& splits, int& tiles_per_split) {
-  const int ntiles = N * (H / WTH) * (W / WTW);
+  const int ntiles = W == 8 ? ((N + 1) / 2) * (H / WTH) : N * (H / WTH) * (W / WTW);
   const int base = ((Cout + 127) / 128) * (C / 32);
   int maxs = ntiles / 4; if (maxs < 1) maxs = 1;      // at least 4 tiles per block
   if (maxs > 128) maxs = 128;
@@ -280,7 +285,8 @@ static void wgradp_plan(int N, int H, int W, int C, int Cout, int& splits, int& 
 
 bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Cout) {
   if (math < 1 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || C1 != 0) return false;
-  if ((C & 31) || (H % WTH) || (W % WTW) || (Cout & 3) || Cout < 32) return false;
+  if ((C & 31) || (H % WTH) || ((W % WTW) && W != 8) || (Cout & 3) || Cout < 32) return false;
+  if (W == 8) return (long long)((N + 1) / 2) * (H / WTH) >= 8;       // image pairs: the 8x8 bottleneck layers
   return (long long)N * (H / WTH) * (W / WTW) >= 64;
 }
 
@@ -291,15 +297,15 @@ size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout) {
   return ((size_t)splits * 2 * Cout * 9 * C + (size_t)splits * Cout) * sizeof(float);
 }
 
-template <int NS> static int launch_w(const WgradParams& P, hipStream_t s) {
-  const size_t smem = (size_t)(WNPL(NS) * WNPIX * WSX + WNPL(NS) * WTPIX * WSY) * sizeof(unsigned short) + WTHREADS * sizeof(float4);   // + bias-sum slots
+template <int NS, bool W8 = false> static int launch_w(const WgradParams& P, hipStream_t s) {
+  const size_t smem = (size_t)(WNPL(NS) * WNPIX_(W8) * WSX + WNPL(NS) * WTPIX * WSY) * sizeof(unsigned short) + WTHREADS * sizeof(float4);   // + bias-sum slots
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3w_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3w_kernel<NS, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3w: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv3x3w_kernel<NS>, dim3(P.splits * P.co_tiles * P.ci_chunks), dim3(WTHREADS), smem, s, P);
+  hipLaunchKernelGGL((conv3x3w_kernel<NS, W8>), dim3(P.splits * P.co_tiles * P.ci_chunks), dim3(WTHREADS), smem, s, P);
   return pdae_launch_status("conv3x3w");
 }
 
@@ -309,14 +315,17 @@ int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   P.dy_amax = dy_amax;
   if (math == 4 && !dy_amax) math = 3;          // fp16 format needs the dY scale: without it the exact bf16 split runs
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.dy = dy; P.Cout = Cout; P.ws = ws;
-  P.tiles_x = W / WTW; P.tiles_y = H / WTH; P.ntiles = N * P.tiles_x * P.tiles_y;
+  const bool w8 = W == 8;
+  P.tiles_x = w8 ? 1 : W / WTW; P.tiles_y = H / WTH; P.ntiles = (w8 ? (N + 1) / 2 : N) * P.tiles_x * P.tiles_y;
   wgradp_plan(N, H, W, C, Cout, P.splits, P.tiles_per_split);
   P.co_tiles = (Cout + 127) / 128; P.ci_chunks = C / 32;
   const size_t need = ((size_t)P.splits * 2 * Cout * 9 * C + (size_t)P.splits * Cout) * sizeof(float);
   P.db_part = db_part ? ws + (size_t)P.splits * 2 * Cout * 9 * C : nullptr;
   if (db_part) { *db_part = P.db_part; *db_rows = P.splits; }
   if (!ws || ws_bytes < need) { pdae_set_error("conv3x3w: workspace too small (%zu < %zu)", ws_bytes, need); return PDAE_EINVAL; }
-  int e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : (math == 4 ? launch_w<4>(P, s) : launch_w<3>(P, s)));
+  int e;
+  if (w8) e = math == 1 ? launch_w<1, true>(P, s) : (math == 2 ? launch_w<2, true>(P, s) : (math == 4 ? launch_w<4, true>(P, s) : launch_w<3, true>(P, s)));
+  else e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : (math == 4 ? launch_w<4>(P, s) : launch_w<3>(P, s)));
   if (e) return e;
   return igemm_splitk_reduce(ws, dw, (long long)Cout * 9 * C, P.splits * 2, accumulate, s);
 }

@@ -391,7 +391,7 @@ MATH_TOL = {1: 2e-2, 2: 1e-4, 3: 1e-5, 4: 1e-5}     # bf16 | 2 bf16 planes (3 pr
                                   (2, 16, 16, 64, 0, 128, 3, 2, 0, 0), (2, 9, 9, 64, 32, 32, 1, 1, 0, 0), (3, 32, 32, 128, 0, 128, 3, 1, 0, 128),
                                   (4, 64, 48, 64, 0, 160, 3, 1, 0, 0), (3, 32, 32, 96, 0, 64, 3, 1, 1, 0), (6, 32, 32, 32, 0, 256, 3, 1, 0, 0), (2, 24, 32, 64, 0, 64, 3, 1, 0, 0),
                                   (4, 8, 8, 128, 0, 64, 3, 1, 0, 0), (3, 8, 8, 64, 0, 32, 3, 1, 0, 0), (2, 4, 4, 64, 0, 64, 3, 1, 1, 0),
-                                  (2, 16, 16, 96, 0, 64, 3, 1, 0, 0), (8, 64, 64, 32, 0, 32, 3, 1, 0, 0)])
+                                  (2, 16, 16, 96, 0, 64, 3, 1, 0, 0), (8, 64, 64, 32, 0, 32, 3, 1, 0, 0), (17, 8, 8, 64, 0, 64, 3, 1, 0, 0)])
 def test_conv_bf16_split_modes(H, case, math_mode):
     """The bf16-MFMA split-operand variants of conv fwd / dgrad / wgrad against fp64."""
     N, Hh, W, C0, C1, Cout, k, stride, up, tile = case
@@ -598,7 +598,8 @@ def test_conv_with_fused_skip_connection(H, case, math_mode):
 
 
 @pytest.mark.parametrize("gscale", [1.0, 3e-7, 2e4])
-@pytest.mark.parametrize("case", [(4, 32, 32, 64, 128), (2, 16, 48, 128, 96), (3, 8, 8, 64, 64), (8, 64, 64, 32, 32)])
+@pytest.mark.parametrize("case", [(4, 32, 32, 64, 128), (2, 16, 48, 128, 96), (3, 8, 8, 64, 64), (8, 64, 64, 32, 32),
+                                  (16, 8, 8, 64, 64), (17, 8, 8, 32, 96), (8, 16, 8, 64, 32)])      # 8-wide: image-pair tiles in conv3x3w
 def test_f16_format_gradient_kernels_with_dynamic_scale(H, case, gscale):
     """math 4 with dy_amax: data gradient (patch kernel on transposed fp16-format weights) and weight gradient (conv3x3w, fp16 planes) with
     the per-tensor power-of-two dY scale, for gradients of ordinary, tiny (3e-7) and large magnitude -- fp32-grade at every scale."""
