@@ -28,10 +28,19 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# FFHQ-128 UNet hyper-parameters: NOT in the reference tree (pre-trained-dpms/ffhq128/config.yml is a download);
-# Diff-AE-compatible values implied by the checkpoint key names -- [ASSUMED], SURVEY.md section 0.2.
-FFHQ128 = dict(input_channel=3, base_channel=128, channel_multiplier=[1, 1, 2, 3, 4], num_residual_blocks_of_a_block=2,
-               attention_resolutions=[8], num_heads=1, head_channel=-1, use_new_attention_order=False, dropout=0.1)
+CONFIG = "config/ffhq_representation_learning.yml"      # BASELINE.json configs[2]; its trained_ddpm_config names the UNet hyper-parameters
+# (pre-trained-dpms/ffhq128/config.yml is a download in the reference: the shipped stand-in holds the Diff-AE-compatible values implied by the
+# checkpoint key names -- [ASSUMED], SURVEY.md section 0.2.  Nothing below hard-codes them.)
+
+
+def load_workload():
+    """(training config, denoise_fn_config of the pre-trained DPM) from the shipped YAMLs."""
+    from pdae_amd.utils import load_yaml
+    c = load_yaml(os.path.join(ROOT, CONFIG))
+    ddpm = load_yaml(os.path.join(ROOT, c["trained_ddpm_config"]))["denoise_fn_config"]
+    return c, ddpm
+
+
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
 MFMA_PER_PRODUCT = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
@@ -81,12 +90,13 @@ def profile_plan(plan, first, last):
     return [evs[j].elapsed_time(evs[j + 1]) for j in range(last - first)]
 
 
-def cpu_baseline(batch, steps):
+def cpu_baseline(batch, steps, warm=3):
     """The CPU oracle (oracle/pdae_oracle.py, validated against the reference by tests/test_oracle_golden.py)
-    running the same train step: forward + autograd backward + Adam + EMA on all host threads."""
+    running the same train step: forward + autograd backward + Adam + EMA on all host threads; `warm` untimed + `steps` timed steps, median
+    (SURVEY 8d protocol: 3 + 5)."""
     from oracle import pdae_oracle as O
     torch.manual_seed(0)
-    cfg = dict(FFHQ128, dropout=0.0)
+    cfg = dict(load_workload()[1], dropout=0.0)
     enc_sd = O.synth_state_dict(O.encoder_param_shapes("FFHQEncoder", 512), 1)
     dec_sd = O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=512), 2)
     s = O.Schedules()
@@ -97,7 +107,7 @@ def cpu_baseline(batch, steps):
     ema = {k: v.clone() for k, v in train.items()}
     x0 = torch.rand(batch, 3, 128, 128) * 2 - 1
     times = []
-    for step in range(steps + 1):
+    for step in range(steps + warm):
         t0 = time.perf_counter()
         for p in train.values():
             p.requires_grad_(True)
@@ -113,7 +123,8 @@ def cpu_baseline(batch, steps):
                 p.copy_(pn)
                 ema[k] = O.ema_update(ema[k], p, 0.9999)
         times.append(time.perf_counter() - t0)
-    best = sorted(times[1:])[len(times[1:]) // 2]
+    timed = sorted(times[warm:])
+    best = timed[len(timed) // 2]
     return batch / best, best
 
 
@@ -136,92 +147,197 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the reference's launch is
+    torchrun --nproc_per_node, scripts/dist_train_representation_learning.sh:10-14).  Rank 0's JSON line is the only stdout."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+DRY_CFG = dict(input_channel=3, base_channel=32, channel_multiplier=[1, 2, 2], num_residual_blocks_of_a_block=1, attention_resolutions=[4],
+               num_heads=1, head_channel=32, use_new_attention_order=False, dropout=0.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (config/ffhq_representation_learning.yml:29)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: dataloader_config.train.batch_size of the YAML = 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ddim-batch", type=int, default=128, help="batch of the DDIM-100 sampling measurement (0 = the training batch)")
+    ap.add_argument("--ddim-batch", type=int, default=100, help="batch of the DDIM-100 measurement (sampler/autoencoding_eval.py:125 uses 100)")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--bucket-mb", type=float, default=0, help="gradient bucket size of the data-parallel all-reduce; 0 = sweep 16/48/96 MB in the "
+                                                             "warm-up phase and keep the fastest")
+    ap.add_argument("--dry", action="store_true", help="plumbing check without a GPU: gloo backend, a small network on CPU tensors, kernels "
+                                                      "replaced by a no-op recorder (exercises launcher, process group, buckets, JSON)")
     ap.add_argument("--math", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16", "f16x3"],
                     help="conv arithmetic on fp32 tensors (default f16x3 = two-fp16-plane split with power-of-two scales, fp32 grade; "
                          "bf16x6 = exact 3-bf16-plane split; f32 = f32 MFMA)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     if args.math:
         os.environ["PDAE_CONV_MATH"] = args.math
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dry = args.dry
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     import copy
-    from pdae_amd.model.shift_unet import ShiftUNet
-    from pdae_amd.model.representation_learning.encoder import FFHQEncoder
+    from pdae_amd.model.representation_learning import decoder as decoder_module, encoder as encoder_module
     from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
     from pdae_amd.trainer.fused_step import FusedRLStep
     from pdae_amd.utils import set_seed
 
+    cfg, ddpm_cfg = load_workload()
+    if dry:
+        ddpm_cfg = dict(DRY_CFG)
+    size = 64 if dry else int(cfg["train_dataset_config"]["image_size"])
+    oc, rc = cfg["optimizer_config"], cfg["runner_config"]
     log("building networks")
     set_seed(0)                                    # identical weights on every rank (trainer/base_trainer.py:27-28)
-    enc = FFHQEncoder(device=dev, latent_dim=512)
-    dec = ShiftUNet(device=dev, latent_dim=512, **FFHQ128)
-    randomize(enc, 11)
-    randomize(dec, 12)
+    enc_name = "CELEBA64Encoder" if dry else cfg["encoder_config"]["model"]
+    enc = getattr(encoder_module, enc_name)(device=dev, **cfg["encoder_config"])
+    dec = getattr(decoder_module, cfg["decoder_config"]["model"])(device=dev, latent_dim=cfg["decoder_config"]["latent_dim"], **ddpm_cfg)
+    if not dry:
+        randomize(enc, 11)
+        randomize(dec, 12)
     enc.train()
     dec.set_train_mode()
     ema_enc, ema_dec = copy.deepcopy(enc), copy.deepcopy(dec)
-    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, dev)
-    B = args.batch
+    gd = GaussianDiffusion(cfg["diffusion_config"], dev)
+    B = args.batch or (2 if dry else int(cfg["dataloader_config"]["train"]["batch_size"]))
     log("building the fused step plan")
-    st = FusedRLStep(gd, enc, dec, ema_enc, ema_dec, B, 128, 128, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                     ema_decay=0.9999, ema_every=1, num_iterations=1)
+    st = FusedRLStep(gd, enc, dec, ema_enc, ema_dec, B, size, size, lr=float(oc["lr"]), betas=eval(oc["adam_betas"]), eps=float(oc["adam_eps"]),
+                     weight_decay=float(oc["weight_decay"]), ema_decay=float(rc["ema_decay"]), ema_every=int(rc["ema_every"]),
+                     num_iterations=int(rc["num_iterations"]), bucket_mb=args.bucket_mb or 48)
+    if dry:
+        st.plan.run = lambda first=0, last=None, stream=None: None          # no kernels: launcher / process-group / bucket plumbing only
     log(f"plan: {st.plan.n} ops, {st.plan.bytes_alloc / 2**30:.1f} GiB of activations/workspaces")
     set_seed(rank)                                 # per-rank data / noise streams (base_trainer.py:50-52)
-    x0 = torch.rand(B, 3, 128, 128, device=dev) * 2 - 1
+    x0 = torch.rand(B, 3, size, size, device=dev) * 2 - 1
+
+    # ---- data-parallel exchange: is RCCL really spanning `world` ranks; bucket size (swept, untimed); exposed vs isolated all-reduce time
+    comm = None
+    if world > 1:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        comm = {"backend": dist.get_backend(), "rccl_ranks": int(ones.item()), "grad_bytes_per_step": int(4 * (dec.flat_grad.numel() + enc.flat_grad.numel()))}
+        sweep = {}
+        for mb in ([args.bucket_mb] if args.bucket_mb else [16, 48, 96]):
+            st.buckets = st._make_buckets(st._marks, mb)
+            st.step(x0); sync(); dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                st.step(x0)
+            sync(); dist.barrier()
+            sweep[str(mb)] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+        tt = torch.tensor([sweep[k] for k in sweep], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        sweep = {k: round(float(v), 3) for k, v in zip(sweep, tt.tolist())}
+        best = min(sweep, key=sweep.get)
+        st.buckets = st._make_buckets(st._marks, float(best))
+        comm.update(bucket_mb=float(best), bucket_sweep_ms_per_step=sweep, buckets=len(st.buckets),
+                    bucket_bytes=[int(v.numel() * 4) for _, v in st.buckets])
+        log(f"bucket sweep (ms/step): {sweep} -> {best} MB, {len(st.buckets)} buckets")
 
     for _ in range(args.warmup):
         st.step(x0)
-        torch.cuda.synchronize()
+        sync()
         log("warm-up step done")
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st.step(x0)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    loss_val = st.last_loss
+    loss_val = 0.0 if dry else st.last_loss
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     ms_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
+    sat = st.saturation()
 
+    if world > 1 and not dry:                      # after the timed region: collective tail of one step, and the all-reduce alone
+        ev = st.enable_comm_timing()
+        st.step(x0); sync()
+        exposed = ev["bwd_done"].elapsed_time(ev["comm_done"])
+        st.comm_events = None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier(); sync()
+        e0.record()
+        for _, v in st.buckets:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        e1.record(); sync()
+        alone = e0.elapsed_time(e1)
+        tt = torch.tensor([exposed, alone], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        exposed, alone = [float(v) for v in tt.tolist()]
+        comm.update(allreduce_ms_per_step=round(alone, 3), allreduce_exposed_ms_per_step=round(exposed, 3),
+                    overlap_frac=round(max(0.0, 1.0 - exposed / max(alone, 1e-9)), 4),
+                    allreduce_bus_gbps=round(2 * (world - 1) / world * comm["grad_bytes_per_step"] / max(alone, 1e-9) / 1e6, 1))
+
+    wl = "config/ffhq_representation_learning.yml: PDAE representation learning, FFHQ-128 [ASSUMED denoise_fn_config], encoder FFHQEncoder + ShiftUNet, " \
+         f"Adam lr {oc['lr']}, EMA {rc['ema_decay']}, dropout {ddpm_cfg['dropout']}"
     out = {"metric": "train_images_per_sec_ffhq128_representation_learning", "value": round(value, 3), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "config/ffhq_representation_learning.yml: PDAE representation learning, FFHQ-128 [ASSUMED denoise_fn_config], "
-                                  "encoder FFHQEncoder + ShiftUNet, Adam lr 1e-4, EMA 0.9999, dropout 0.1",
-                      "per_gpu_batch": B, "global_batch": B * world, "image": "3x128x128", "parallelism": f"dp{world}",
+           "config": {"workload": ("DRY RUN (no kernels, small network, gloo): " if dry else "") + wl,
+                      "per_gpu_batch": B, "global_batch": B * world, "image": f"3x{size}x{size}", "parallelism": f"dp{world}",
                       "params_total": int(sum(p.numel() for p in dec.P.values()) + sum(p.numel() for p in enc.P.values())),
                       "params_trainable": int(sum(p.numel() for p in dec.P.values() if p.requires_grad) + sum(p.numel() for p in enc.P.values()))},
            "images_per_sec_per_gpu": round(value / world, 3), "final_loss": round(loss_val, 6),
+           "fp16_window_events": sat[0], "optimizer_steps_discarded": sat[1],
            "step_tflops_algorithmic": round(TRAIN_GFLOP_PER_IMG * B / ms_step, 3),
            "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMG * B / ms_step / PEAK_F32_MFMA_TFLOPS, 4)}
+    if comm is not None:
+        out["comm"] = comm
+    if dry:
+        out["dry"] = True
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if rank == 0:
         # ---- roofline of the dominant kernel family, live, with HIP events (one extra, un-timed step)
@@ -281,17 +397,19 @@ def main():
         p_by = sum(patch_bytes(st.plan.arr[k]) for k in pk)
         traffic, traffic_src = None, None
         try:                                          # PMC counters cannot be read from inside the process: committed rocprofv3 --pmc passes
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+            prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            pmc_file = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof, f)))
+            pmc = json.load(open(os.path.join(prof, pmc_file)))
             kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3p_kernel<") and ", 8, false" in k_]   # every non-pair instantiation
             if kk and pmc.get("math", "bf16x6") == math:
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kk) / sum(v["dispatches"] for v in kk))
-                traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, gfx950 x2 fetch correction)"
-        except (OSError, ValueError, KeyError):
+                traffic_src = f"profiles/{pmc_file}: committed rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE, gfx950 x2 fetch correction) of this command -- PMC counters cannot be read inside the timed process"
+        except (OSError, ValueError, KeyError, StopIteration):
             pass
         out["roofline"] = {"bound": "mfma", "kernel": kname,
                            "math": math, "achieved": round(p_fl / p_ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                            "frac": round(p_fl / p_ms / 1e9 / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
-                           "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(p_by / max(len(pk), 1)),
+                           "traffic_source": traffic_src, "traffic_measured_in_this_run": False, "algorithmic_bytes_per_launch": round(p_by / max(len(pk), 1)),
                            "peak_note": "algorithmic TFLOP/s; peak = dense 16-bit MFMA peak (2500) / average MFMAs issued per algorithmic product of these launches",
                            "launches_per_step": len(pk), "avg_launch_ms": round(p_ms / max(len(pk), 1), 4),
                            "algorithmic_gflop_per_launch": round(p_fl / 1e9 / max(len(pk), 1), 2), "kernel_ms_per_step": round(p_ms, 3),
@@ -307,26 +425,32 @@ def main():
         # ---- DDIM-100 sampling throughput (second half of the BASELINE metric): 100 ShiftUNet forwards + fused updates
         if not args.no_ddim:
             dec.set_eval_mode()
+            out["ddim100"] = {}
             with torch.no_grad():
-                Bd = args.ddim_batch or B
-                z = torch.randn(Bd, 512, device=dev)
-                xT = torch.randn(Bd, 3, 128, 128, device=dev)
-                gd.representation_learning_ddim_sample("ddim10", None, dec, None, xT, z)       # builds the inference plan
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                gd.representation_learning_ddim_sample("ddim100", None, dec, None, xT, z)
-                torch.cuda.synchronize()
-                dd = time.perf_counter() - t1
+                for Bd in sorted({args.ddim_batch or B, 128} if args.ddim_batch == 100 else {args.ddim_batch or B}):
+                    z = torch.randn(Bd, 512, device=dev)
+                    xT = torch.randn(Bd, 3, size, size, device=dev)
+                    gd.representation_learning_ddim_sample("ddim10", None, dec, None, xT, z)       # builds the inference plan
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    gd.representation_learning_ddim_sample("ddim100", None, dec, None, xT, z)
+                    torch.cuda.synchronize()
+                    dd = time.perf_counter() - t1
+                    rec = {"samples_per_sec": round(Bd / dd, 3), "batch": Bd, "seconds": round(dd, 3),
+                           "tflops_algorithmic": round(FWD_GFLOP_PER_IMG * Bd * 100 / dd / 1e3, 2)}
+                    if Bd == (args.ddim_batch or B):
+                        out["ddim100"].update(rec)                     # headline: the evaluator's batch (100)
+                    else:
+                        out["ddim100"][f"batch_{Bd}"] = rec
+                    dec.invalidate_plans()
             log("ddim100 done")
-            out["ddim100"] = {"samples_per_sec": round(Bd / dd, 3), "batch": Bd, "seconds": round(dd, 3),
-                              "tflops_algorithmic": round(FWD_GFLOP_PER_IMG * Bd * 100 / dd / 1e3, 2)}
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_cores())
             log(f"cpu baseline on {host_cores()} host cores")
-            ips, sec = cpu_baseline(args.cpu_batch, 2)
+            ips, sec = cpu_baseline(args.cpu_batch, 5, warm=3)
             out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"same FFHQ-128 train step (fwd+bwd+Adam+EMA, dropout off), batch {args.cpu_batch}, "
-                                             f"median of 2 timed steps after 1 warm-up ({sec:.1f} s/step)"}
+                                             f"median of 5 timed steps after 3 warm-up ({sec:.1f} s/step)"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -42,9 +42,17 @@ typedef struct pdae_conv_desc {
                            * 1 = bf16 operands (rn); 2 = 2 bf16 planes, 3 products (~2^-17 per product);
                            * 3 = 3 exact bf16 planes, 6 products (~2^-23 per product, fp32 grade);
                            * 4 = 2 fp16 planes (11+11 mantissa bits), 3 products (~2^-21 per product) in the FORWARD 3x3 patch kernel -- operands must
-                           *     lie inside the fp16 range (post-GroupNorm activations, weights); every other kernel and all gradient kernels
-                           *     run mode 3.  fp32 accumulate in all modes. */
+                           *     lie inside the fp16 range (post-GroupNorm activations, weights): the 3x3 patch kernel (forward and, given dy_amax,
+                           *     data gradient), the 3x3 weight-gradient kernel (given dy_amax) and the 1x1 kernel; scaled operands outside
+                           *     +-60000 are clamped and COUNTED (pdae_set_saturation_counter).  The generic implicit-GEMM kernels and gradient
+                           *     launches without dy_amax run mode 3.  fp32 accumulate in all modes. */
 } pdae_conv_desc;
+
+/* fp16-window guard of math 4: counter = device word (zero it yourself) that every math-4 convolution launch increments when it had to clamp
+ * a scaled operand (|x| > 60000, NaN, Inf) into the fp16 window; NULL disarms the guard.  A non-zero counter means "results of this pass are
+ * not fp32-grade: discard and re-run with math 3" -- pdae_adam_ema refuses the update, the Python host (pdae_amd/hip.py SaturationGuard)
+ * rebuilds its plans in bf16x6.  One counter per process. */
+int pdae_set_saturation_counter(unsigned int* counter);
 
 /* Fast paths in the bf16 modes (math >= 1): 3x3 / stride-1 / pad-1 convolutions run on the LDS-patch kernel (conv3x3p.hip) and 1x1
  * convolutions on the 1x1 kernel (conv1x1.hip).  Both read their weights pre-split into bf16 planes in MFMA-fragment
@@ -158,9 +166,25 @@ int pdae_ddim_step(const float* x, const float* eps, const float* g, size_t tota
 int pdae_ddpm_step(const float* x, const float* eps, const float* g, const float* z, size_t total, float cx, float ce, float cs, float sigma,
                    float* out, pdae_stream_t stream);                                            /* gaussian_diffusion.py:112-126 */
 
+/* Per-sample-timestep forms of the single-step API (the reference takes t[B]: ddim.py:43-55,66-79,91-107,123-138; gaussian_diffusion.py:105-126,
+ * 148-164).  Coefficient rows are device arrays gathered from the schedule tables with t, so no value of t is ever read on the host.
+ *   axpby_rows:      out[n,:] = ca[n]*a[n,:] + cb[n]*b[n,:]   (q_posterior_mean :105-108, predicted_noise_to_predicted_x_0 :156-159, _mean :161-164)
+ *   ddim_step_rows:  coef[n] = {c_shift, sqrt_recip_ac, sqrt_recip_ac_m1, sqrt(ac_to), sqrt(1-ac_to)}
+ *   ddpm_step_rows:  coef[n] = {cx, ce, cs, mask, lv_min, lv_max}; out = cx*x - ce*(eps + cs*g) + mask*exp(0.5*lv)*noise with lv = lv_min, or
+ *                    lv_min + (learned_range+1)/2*(lv_max-lv_min) when learned_range != NULL (learn_sigma models, unet.py:49) */
+int pdae_axpby_rows(const float* a, const float* b, const float* ca, const float* cb, int N, size_t per_sample, float* out, pdae_stream_t stream);
+int pdae_ddim_step_rows(const float* x, const float* eps, const float* g, const float* coef, int N, size_t per_sample, int clamp, float* out,
+                        pdae_stream_t stream);
+int pdae_ddpm_step_rows(const float* x, const float* eps, const float* g, const float* noise, const float* learned_range, const float* coef, int N,
+                        size_t per_sample, float* out, pdae_stream_t stream);
+
 /* ---- optimizer: torch.optim.Adam / AdamW + EMA (train_representation_learning.py:58-70,192-212) over a flat segment */
+/* guard (optional) = device {saturation counter, skipped-step counter} (pdae_set_saturation_counter): while guard[0] != 0 the update is NOT
+ * applied (a convolution of this step clamped an operand into the fp16 window, so its gradients are not fp32-grade) and, when count_skip != 0,
+ * guard[1] is incremented -- the GradScaler-style "skip the step" of torch.cuda.amp, decided on the device without a host sync. */
 int pdae_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, pdae_stream_t stream);
+                  float weight_decay, int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay,
+                  unsigned int* guard, int count_skip, pdae_stream_t stream);
 
 /* ---- planned-graph executor: a network pass is a static array of ops, issued back-to-back on one stream
  * with a single host call (replaces the per-module Python dispatch of TimestepSequential, module.py:131-140). */
@@ -168,7 +192,8 @@ enum {
   PDAE_OP_CONV_FWD = 1, PDAE_OP_CONV_DGRAD, PDAE_OP_CONV_WGRAD, PDAE_OP_GEMM, PDAE_OP_GN_STATS, PDAE_OP_GN_COEF, PDAE_OP_GN_APPLY,
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
-  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX
+  PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
+  PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS
 };
 typedef struct pdae_op {
   int32_t kind;

@@ -451,6 +451,89 @@ def noise_p_sample_mean(s, x_t, t, eps):
     return _at(s.noise_posterior_mean_x_t_coef, t, x_t) * x_t - _at(s.noise_posterior_mean_noise_coef, t, x_t) * eps
 
 
+def q_posterior_mean(s, x_0, x_t, t):
+    """gaussian_diffusion.py:105-108."""
+    return _at(s.x_0_posterior_mean_x_0_coef, t, x_t) * x_0 + _at(s.x_0_posterior_mean_x_t_coef, t, x_t) * x_t
+
+
+def predicted_x_0(s, x_t, t, eps):
+    """gaussian_diffusion.py:156-159."""
+    return _at(s.sqrt_recip_alphas_cumprod, t, x_t) * x_t - _at(s.sqrt_recip_alphas_cumprod_m1, t, x_t) * eps
+
+
+def learned_range_to_log_variance(s, v, t):
+    """gaussian_diffusion.py:148-154: v in [-1, 1] interpolates between the clipped posterior log-variance and log(beta)."""
+    lo, hi = _at(s.posterior_log_variance_clipped, t, v), _at(torch.log(s.betas), t, v)
+    return lo + (v + 1) / 2 * (hi - lo)
+
+
+def noise_p_sample(s, x_t, t, eps, noise, learned_range=None):
+    """gaussian_diffusion.py:112-126 with the internally drawn noise injected."""
+    lv = learned_range_to_log_variance(s, learned_range, t) if learned_range is not None else _at(s.posterior_log_variance_clipped, t, x_t)
+    mask = (t != 0).float().reshape([-1] + [1] * (x_t.dim() - 1))
+    return noise_p_sample_mean(s, x_t, t, eps) + mask * (0.5 * lv).exp() * noise
+
+
+def regular_ddpm_sample(s, fn, x_T, noise_at):
+    """gaussian_diffusion.py:216-229; fn(x, t) -> eps or [eps | range]; noise_at(i) = the draw of step i."""
+    c = x_T.shape[1]
+    img = x_T
+    for i in reversed(range(s.timesteps)):
+        t = torch.full((x_T.shape[0],), i, dtype=torch.long)
+        o = fn(img, t)
+        eps, vr = (o[:, :c], o[:, c:]) if o.shape[1] == 2 * c else (o, None)
+        img = noise_p_sample(s, img, t, eps, noise_at(i), vr)
+    return img
+
+
+def rl_ddpm_sample(s, dec_sd, cfg, z, x_T, noise_at):
+    """gaussian_diffusion.py:257-270: the ancestral sampler on eps + shift_coef[t] * gradient."""
+    img = x_T
+    for i in reversed(range(s.timesteps)):
+        t = torch.full((x_T.shape[0],), i, dtype=torch.long)
+        eps, g = shift_unet_forward(dec_sd, cfg, img, t, z)
+        img = noise_p_sample(s, img, t, eps + _at(s.shift_coef, t, img) * g, noise_at(i))
+    return img
+
+
+def rl_two_x_0(s, dec_sd, cfg, z, x_t, t):
+    """The pair (x_0 from eps, x_0 from eps + shift_coef * gradient) of gaussian_diffusion.py:305-311 / 326-332."""
+    eps, g = shift_unet_forward(dec_sd, cfg, x_t, t, z)
+    return predicted_x_0(s, x_t, t, eps), predicted_x_0(s, x_t, t, eps + _at(s.shift_coef, t, x_t) * g)
+
+
+def rl_gap_measure(s, dec_sd, cfg, z, x_0, noise_at):
+    """gaussian_diffusion.py:292-318 (noise_at(i) replaces the UNIFORM rand_like draw of :302)."""
+    gp, ga = [], []
+    for i in reversed(range(s.timesteps)):
+        t = torch.full((x_0.shape[0],), i, dtype=torch.long)
+        x_t = q_sample(s, x_0, t, noise_at(i))
+        a, b = rl_two_x_0(s, dec_sd, cfg, z, x_t, t)
+        truth = q_posterior_mean(s, x_0, x_t, t)
+        gp.append(float(torch.mean((truth - q_posterior_mean(s, a, x_t, t)) ** 2)))
+        ga.append(float(torch.mean((truth - q_posterior_mean(s, b, x_t, t)) ** 2)))
+    return gp, ga
+
+
+def shift_ddim_trajectory_interpolation(s, style, dec_sd, cfg, z_1, z_2, x_T, alpha):
+    """diffusion/ddim.py:149-174."""
+    d = DDIMTables(s, style)
+    x = x_T
+    for i in reversed(range(1, d.timesteps + 1)):
+        t = torch.full((x.shape[0],), i, dtype=torch.long)
+        eps, g1 = shift_unet_forward(dec_sd, cfg, x, d.timestep_map[t], z_1)
+        _, g2 = shift_unet_forward(dec_sd, cfg, x, d.timestep_map[t], z_2)
+        x = ddim_update(d, x, t, eps, (1.0 - alpha) * g1 + alpha * g2)
+    return x
+
+
+def manipulated_latent(z, classifier_weight, class_id, scale, mean, std):
+    """gaussian_diffusion.py:435-441."""
+    zn = (z - mean) / std
+    zn = zn + scale * math.sqrt(512) * F.normalize(classifier_weight[class_id][None, :], dim=1)
+    return zn * std + mean
+
+
 # ----------------------------------------------------------------------------------
 # optimizer / EMA (trainer/train_representation_learning.py:58-70, 192-212)
 # ----------------------------------------------------------------------------------

@@ -19,7 +19,12 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 1; }
+extern "C" int pdae_abi_version(void) { return 2; }
+
+// fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
+static unsigned int* g_sat = nullptr;
+unsigned int* pdae_sat_counter() { return g_sat; }
+extern "C" int pdae_set_saturation_counter(unsigned int* counter) { g_sat = counter; return PDAE_OK; }
 
 static inline hipStream_t S(pdae_stream_t s) { return (hipStream_t)s; }
 
@@ -394,10 +399,25 @@ extern "C" int pdae_ddpm_step(const float* x, const float* eps, const float* g, 
   PDAE_CHECK_ARG(x && eps && out, "ddpm_step: null pointer");
   return k_ddpm_step(x, eps, g, z, total, cx, ce, cs, sigma, out, S(stream));
 }
+extern "C" int pdae_axpby_rows(const float* a, const float* b, const float* ca, const float* cb, int N, size_t per, float* out, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(a && b && ca && cb && out && N > 0 && N < 65536, "axpby_rows: bad arguments");
+  return k_axpby_rows(a, b, ca, cb, N, per, out, S(stream));
+}
+extern "C" int pdae_ddim_step_rows(const float* x, const float* eps, const float* g, const float* coef, int N, size_t per, int clamp, float* out,
+                                   pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x && eps && coef && out && N > 0 && N < 65536, "ddim_step_rows: bad arguments");
+  return k_ddim_step_rows(x, eps, g, coef, N, per, clamp, out, S(stream));
+}
+extern "C" int pdae_ddpm_step_rows(const float* x, const float* eps, const float* g, const float* noise, const float* learned_range, const float* coef,
+                                   int N, size_t per, float* out, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x && eps && coef && out && N > 0 && N < 65536, "ddpm_step_rows: bad arguments");
+  return k_ddpm_step_rows(x, eps, g, noise, learned_range, coef, N, per, out, S(stream));
+}
 extern "C" int pdae_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                             int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, pdae_stream_t stream) {
+                             int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, unsigned int* guard, int count_skip,
+                             pdae_stream_t stream) {
   PDAE_CHECK_ARG(p && g && m && v, "adam_ema: null pointer");
-  return k_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay, S(stream));
+  return k_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay, guard, count_skip, S(stream));
 }
 
 // ---- planned-graph executor
@@ -450,9 +470,12 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
       return pdae_ddim_step(F(0), F(1), F(2), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (int)i[1], FM(3), st);
     case PDAE_OP_DDPM_STEP:
       return pdae_ddpm_step(F(0), F(1), F(2), F(3), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], FM(4), st);
+    case PDAE_OP_AXPBY_ROWS: return pdae_axpby_rows(F(0), F(1), F(2), F(3), (int)i[0], (size_t)i[1], FM(4), st);
+    case PDAE_OP_DDIM_STEP_ROWS: return pdae_ddim_step_rows(F(0), F(1), F(2), F(3), (int)i[0], (size_t)i[1], (int)i[2], FM(4), st);
+    case PDAE_OP_DDPM_STEP_ROWS: return pdae_ddpm_step_rows(F(0), F(1), F(2), F(3), F(4), F(5), (int)i[0], (size_t)i[1], FM(6), st);
     case PDAE_OP_ADAM_EMA:
       return pdae_adam_ema(FM(0), F(1), FM(2), FM(3), FM(4), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (int)i[1],
-                           (float)f[5], (float)f[6], (float)f[7], (float)f[8], st);
+                           (float)f[5], (float)f[6], (float)f[7], (float)f[8], (unsigned int*)p[5], (int)i[2], st);
     case PDAE_OP_SOFTMAX: return pdae_softmax(FM(0), i[0], (int)i[1], st);
     case PDAE_OP_SOFTMAX_BWD: return pdae_softmax_bwd(F(0), FM(1), i[0], (int)i[1], st);
     case PDAE_OP_COLSUM: return pdae_colsum(F(0), i[0], (int)i[1], FM(1), (int)i[2], p[2], st);

@@ -28,3 +28,22 @@ static inline int pdae_launch_status(const char* what) {
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- fp16-window guard of the two-fp16-plane format (math 4).  Scaled operands must stay inside the fp16 range (|x| <= 65504) for both planes to
+// be finite.  Nothing is clamped: an operand beyond the window becomes Inf in the high plane and turns its output rows into NaN exactly like
+// an fp16 autocast overflow would, NaN / Inf inputs propagate as they do in fp32 arithmetic -- and the launch COUNTS the event in the device
+// counter registered with pdae_set_saturation_counter.  The optimizer kernel refuses to apply a step while that counter is non-zero and the
+// host falls back to the range-free bf16x6 split (pdae_amd/hip.py: SaturationGuard).  nullptr = guard not armed.
+unsigned int* pdae_sat_counter();
+#ifdef __HIPCC__
+#define PDAE_F16_LIMIT 60000.f        // margin below 65504 for the round-to-nearest of the high plane
+// v *= sc; amax = running per-lane max |scaled operand| (one VGPR for the whole kernel, 3 VALU per float4: v_max3 with |.| modifiers)
+__device__ __forceinline__ void pdae_f16_scale4(float4& v, float sc, float& amax) {
+  v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+  amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ void pdae_sat_report(unsigned int* counter, float amax) {
+  const unsigned long long over = __builtin_amdgcn_ballot_w64(!(amax <= PDAE_F16_LIMIT));
+  if (counter && over && (threadIdx.x & 63) == 0) atomicAdd(counter, 1u);
+}
+#endif

@@ -64,6 +64,7 @@ struct PointParams {
   int nt_off, Nout;                                  // output channels = prepared rows nt_off*32 .. + Nout
   float* y; const float* bias; const float* res; int accumulate;
   float woscale; const float* amax;                  // fp16 format: 1 / weight scale; device scalar max|input| (gradients) or NULL
+  unsigned int* sat;                                 // fp16 format: saturation counter (common.h) or NULL
   int res_mode, H, W;                                // res_mode 2: residual stored at half resolution (needs the image geometry)
   int tiles_m, tiles_n, splits, sps;                 // split-K: `splits` ranges of `sps` 16-channel steps
   float* slab;
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   const float ascale = NS == 4 ? (P.amax ? q_pow2_scale(*P.amax) : 1.0f) : 1.0f;
   // ---- A staging: thread -> (pixel row = idx >> 4, channel quad = idx & 15), 8 float4 per thread and stage
   float4 apre[8];
+  float sat_hit = 0.f;                            // fp16 format: lanes with a value clamped into the window (common.h)
   auto a_gload = [&](int s0) {                     // stage starting at step s0 (4 steps = 64 channels, fewer at the tail)
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
@@ -112,10 +114,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
       const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
-      if constexpr (NS == 4) {
-        apre[l].x = fminf(fmaxf(apre[l].x * ascale, -60000.f), 60000.f); apre[l].y = fminf(fmaxf(apre[l].y * ascale, -60000.f), 60000.f);
-        apre[l].z = fminf(fmaxf(apre[l].z * ascale, -60000.f), 60000.f); apre[l].w = fminf(fmaxf(apre[l].w * ascale, -60000.f), 60000.f);
-      }
+      if constexpr (NS == 4) pdae_f16_scale4(apre[l], ascale, sat_hit);
       unsigned a[QNPL(NS)], b[QNPL(NS)];
       q_split2<NS>(apre[l].x, apre[l].y, a);
       q_split2<NS>(apre[l].z, apre[l].w, b);
@@ -208,6 +207,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   // ---- epilogue: each wave transposes its 32-pixel x 64-channel accumulator groups through a private LDS tile (the activation tile is
   // dead by now) so that global traffic is float4 per lane in 256-byte runs; residual / accumulate operands are loaded up front
   const float oscale = NS == 4 ? P.woscale / ascale : 1.0f;      // exact: powers of two
+  if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
   __syncthreads();
   float* tw = reinterpret_cast<float*>(sA) + wv * (32 * 68);
   const int er = lane >> 4, ec = (lane & 15) * 4;
@@ -376,7 +376,7 @@ int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, l
                    const float* amax) {
   math = c1_math(math);
   PointParams P;
-  P.woscale = 1.0f / conv1x1_wscale(C0 + C1); P.amax = amax;
+  P.woscale = 1.0f / conv1x1_wscale(C0 + C1); P.amax = amax; P.sat = pdae_sat_counter();
   P.res_mode = res_mode; P.H = H; P.W = W;
   P.x0 = x0; P.x1 = x1; P.C0 = C0; P.C1 = C1; P.M = M; P.C = C0 + C1; P.wp = wp; P.NT = (Nrows + 31) / 32;
   P.nt_off = row_off >> 5; P.Nout = Nout; P.y = y; P.bias = bias; P.res = res; P.accumulate = accumulate;

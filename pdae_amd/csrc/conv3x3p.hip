@@ -85,6 +85,7 @@ struct PatchParams {
   float woscale;                        // fp16 format: 1 / (power-of-two scale of the prepared weights, conv3x3p_wscale)
   const float* amax;                    // fp16 format: NULL = activations (static 2^4 pre-scale); else device scalar max|input| (pdae_amax)
                                         // -> power-of-two scale putting the input's abs-max into [1024, 2048): gradients (dY) as input
+  unsigned int* sat;                    // fp16 format: saturation counter (common.h) or NULL
 };
 
 // 2^(10 - floor(log2(amax))): amax * scale in [1024, 2048)  (amax == 0 or non-finite: 1)
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   const float ascale = NS == 4 ? (P.amax ? p_pow2_scale(*P.amax) : PASCALE) : 1.0f;
   float4 apre[PA_LD];
   float4 gmu, gsc, gsh;                          // GN: coefficients of this thread's 4 channels in the chunk being loaded
+  float sat_hit = 0.f;                          // fp16 format: lanes that had a value clamped into the window (wave-uniform)
   bool pre_raw = false;                          // the registers hold a skip chunk (raw input: no GroupNorm map)
   const int nmain = C >> 5, nchunk = nmain + P.nx;            // virtual chunk list: main chunks (9 taps), then skip chunks (centre tap)
   auto a_gload = [&](int chunk) {
@@ -183,11 +185,10 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
           }
         }
         if constexpr (NS == 4) {                // fp16 format: exact power-of-two pre-scale, window [2^-7, 4094] keeps both planes normal
-          // saturate instead of overflowing to inf (|x| > 3750 cannot occur behind GroupNorm; a stray value must not poison the tile)
+          // a value outside the window (|x| > 3750 cannot occur behind GroupNorm unless the network has diverged) overflows to Inf / NaN
+          // like any fp16 overflow and is counted: the step is then discarded and re-run in the range-free bf16x6 split (common.h)
           // skip chunks carry the RAW residual stream (no GroupNorm in front): unit activation scale, the 2^4 sits in their weights instead
-          const float sc = pre_raw ? 1.0f : ascale;
-          apre[l].x = fminf(fmaxf(apre[l].x * sc, -60000.f), 60000.f); apre[l].y = fminf(fmaxf(apre[l].y * sc, -60000.f), 60000.f);
-          apre[l].z = fminf(fmaxf(apre[l].z * sc, -60000.f), 60000.f); apre[l].w = fminf(fmaxf(apre[l].w * sc, -60000.f), 60000.f);
+          pdae_f16_scale4(apre[l], pre_raw ? 1.0f : ascale, sat_hit);
         }
         unsigned a[NPL(NS)], b[NPL(NS)];
         p_split2<NS>(apre[l].x, apre[l].y, a);
@@ -303,6 +304,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   // instructions than storing the MFMA layout directly (the dword-per-lane form is store-issue bound)
   const long long Mtot = (long long)P.N * P.H * P.W;
   const float oscale = NS == 4 ? P.woscale / ascale : 1.0f;      // exact: powers of two
+  if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
   __syncthreads();                                        // all waves are done reading the patch
   float* tw = reinterpret_cast<float*>(smem) + wv * (32 * EPW);
   const int er = lane >> 4, ec = (lane & 15) * 4;         // read side: row within a group of 4, first of 4 channels
@@ -477,7 +479,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
                     const float* coef, int act, const PatchSkip* sk, const float* amax) {
   PatchParams P;
   P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
-  P.woscale = 1.0f / conv3x3p_wscale(C); P.amax = amax;
+  P.woscale = 1.0f / conv3x3p_wscale(C); P.amax = amax; P.sat = pdae_sat_counter();
   P.nx = 0; P.s0 = P.s1 = nullptr; P.Cs0 = P.Cs1 = 0; P.wps = nullptr; P.bias_x = nullptr;
   if (sk) { P.nx = (sk->C0 + sk->C1) >> 5; P.s0 = sk->s0; P.s1 = sk->s1; P.Cs0 = sk->C0; P.Cs1 = sk->C1; P.wps = sk->wps; P.bias_x = sk->bias; }
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.wp = wp; P.NT = (Nout + 31) / 32; P.Nout = Nout;

@@ -90,6 +90,7 @@ struct WgradParams {
   int co_tiles, ci_chunks;
   const float* dy_amax;                  // fp16 format: device scalar max|dY| (pdae_amax) -> power-of-two dY scale
   float* db_part;                        // optional bias-gradient partials [splits][Cout] (column sums of dY, written by the ci_chunk 0 blocks)
+  unsigned int* sat;                     // fp16 format: saturation counter (common.h) or NULL
 };
 
 template <int NS, bool W8 = false>
@@ -122,6 +123,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
   const unsigned sX_base = 0u, sY_base = (unsigned)(SX * 2);   // LDS byte offsets: the dynamic segment is the only LDS of this kernel
 
   float4 xpre[WX_LD], ypre[WY_LD];
+  float sat_hit = 0.f;                      // fp16 format: lanes with an activation clamped into the window (common.h)
   const bool want_db = P.db_part != nullptr && ci_chunk == 0;       // this block also owns the column sums of its dY tiles
   // per-thread running column sums live in LDS behind the operand planes (thread-private slots: deterministic, no registers held
   // across the MFMA phase -- the kernel sits at the 256-VGPR limit); thread: output channels (t & 31) * 4 .. +3, pixels idx >> 5
@@ -162,10 +164,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
     for (int l = 0; l < WX_LD; ++l) {
       int idx = t + WTHREADS * l; int pix = idx >> 3, qd = idx & 7;
       if (pix < WNPIX) {
-        if constexpr (NS == 4) {
-          xpre[l].x = fminf(fmaxf(xpre[l].x * WXSCALE, -60000.f), 60000.f); xpre[l].y = fminf(fmaxf(xpre[l].y * WXSCALE, -60000.f), 60000.f);
-          xpre[l].z = fminf(fmaxf(xpre[l].z * WXSCALE, -60000.f), 60000.f); xpre[l].w = fminf(fmaxf(xpre[l].w * WXSCALE, -60000.f), 60000.f);
-        }
+        if constexpr (NS == 4) pdae_f16_scale4(xpre[l], WXSCALE, sat_hit);
         unsigned u[WNPL(NS)], v[WNPL(NS)];
         w_split2<NS>(xpre[l].x, xpre[l].y, u); w_split2<NS>(xpre[l].z, xpre[l].w, v);
 #pragma unroll
@@ -253,6 +252,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
     }
   }
   const float oscale = NS == 4 ? 1.0f / (yscale * WXSCALE) : 1.0f;      // exact: both scales are powers of two
+  if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
   // epilogue: slab (split*2 + kh) of the workspace, layout [Cout][9][C]
   float* slab = P.ws + (size_t)(split * 2 + kh) * Cout * 9 * C;
 #pragma unroll
@@ -312,7 +312,7 @@ template <int NS, bool W8 = false> static int launch_w(const WgradParams& P, hip
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
                     int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax) {
   WgradParams P;
-  P.dy_amax = dy_amax;
+  P.dy_amax = dy_amax; P.sat = pdae_sat_counter();
   if (math == 4 && !dy_amax) math = 3;          // fp16 format needs the dY scale: without it the exact bf16 split runs
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.dy = dy; P.Cout = Cout; P.ws = ws;
   const bool w8 = W == 8;

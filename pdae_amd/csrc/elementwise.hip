@@ -208,12 +208,81 @@ int k_ddpm_step(const float* x, const float* eps, const float* g, const float* z
 }
 
 // ---------------------------------------------------------------------------------------------
+// Per-sample-coefficient forms (every sample of the batch may sit at a different timestep: the reference's single-step API takes
+// t[B], ddim.py:43-55, gaussian_diffusion.py:105-126,156-164).  coef rows are gathered on the device from the schedule tables, so there is
+// no host read of t.  grid = (chunks of the sample, N).
+// ---------------------------------------------------------------------------------------------
+// out[n,:] = ca[n] * a[n,:] + cb[n] * b[n,:]   -- q_posterior_mean, predicted_noise_to_predicted_x_0 / _mean (cb negated by the caller)
+__global__ void __launch_bounds__(256) axpby_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ ca,
+                                                         const float* __restrict__ cb, size_t per, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  const float fa = ca[n], fb = cb[n];
+  const size_t base = (size_t)n * per;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) out[base + i] = fa * a[base + i] + fb * b[base + i];
+}
+int k_axpby_rows(const float* a, const float* b, const float* ca, const float* cb, int N, size_t per, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(axpby_rows_kernel, dim3(ew_grid(per), N), dim3(256), 0, st, a, b, ca, cb, per, out);
+  return pdae_launch_status("axpby_rows");
+}
+
+// DDIM update with per-sample schedule values coef[n] = {c_shift, sqrt_recip_ac, sqrt_recip_ac_m1, sqrt(ac_to), sqrt(1 - ac_to)}
+__global__ void __launch_bounds__(256) ddim_step_rows_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ g,
+                                                             const float* __restrict__ coef, size_t per, int clamp, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  const float c_shift = coef[n * 5 + 0], ra = coef[n * 5 + 1], rm1 = coef[n * 5 + 2], sab = coef[n * 5 + 3], s1ab = coef[n * 5 + 4];
+  const size_t base = (size_t)n * per;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+    float e = eps[base + i];
+    if (g) e = e - c_shift * g[base + i];
+    const float rx = ra * x[base + i];
+    float x0 = rx - rm1 * e, ne = e;
+    if (clamp) { x0 = fminf(fmaxf(x0, -1.0f), 1.0f); ne = (rx - x0) / rm1; }
+    out[base + i] = x0 * sab + s1ab * ne;
+  }
+}
+int k_ddim_step_rows(const float* x, const float* eps, const float* g, const float* coef, int N, size_t per, int clamp, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(ddim_step_rows_kernel, dim3(ew_grid(per), N), dim3(256), 0, st, x, eps, g, coef, per, clamp, out);
+  return pdae_launch_status("ddim_step_rows");
+}
+
+// DDPM ancestral step with per-sample values coef[n] = {cx, ce, cs, mask, lv_min, lv_max}:
+//   mean = cx*x - ce*(eps + cs*g);  log-variance = lv_min (fixed small variance) or, with a learned range v in [-1,1],
+//   lv_min + (v+1)/2 * (lv_max - lv_min)  (gaussian_diffusion.py:148-154);  out = mean + mask * exp(0.5*logvar) * noise  (:112-126)
+__global__ void __launch_bounds__(256) ddpm_step_rows_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ g,
+                                                             const float* __restrict__ noise, const float* __restrict__ lrange,
+                                                             const float* __restrict__ coef, size_t per, float* __restrict__ out) {
+  const int n = blockIdx.y;
+  const float cx = coef[n * 6 + 0], ce = coef[n * 6 + 1], cs = coef[n * 6 + 2], mask = coef[n * 6 + 3], lv0 = coef[n * 6 + 4], lv1 = coef[n * 6 + 5];
+  const size_t base = (size_t)n * per;
+  const float sig0 = mask * expf(0.5f * lv0);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+    const float e = eps[base + i] + (g ? cs * g[base + i] : 0.f);
+    float sig = sig0;
+    if (lrange) { const float frac = (lrange[base + i] + 1.0f) * 0.5f; sig = mask * expf(0.5f * (lv0 + frac * (lv1 - lv0))); }
+    out[base + i] = cx * x[base + i] - ce * e + (noise ? sig * noise[base + i] : 0.f);
+  }
+}
+int k_ddpm_step_rows(const float* x, const float* eps, const float* g, const float* noise, const float* lrange, const float* coef, int N, size_t per,
+                     float* out, hipStream_t st) {
+  hipLaunchKernelGGL(ddpm_step_rows_kernel, dim3(ew_grid(per), N), dim3(256), 0, st, x, eps, g, noise, lrange, coef, per, out);
+  return pdae_launch_status("ddpm_step_rows");
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused Adam/AdamW + EMA over a flat parameter segment.  step_size = lr/bc1, inv_sqrt_bc2 = 1/sqrt(bc2)
 // computed on the host in double.  grad_scale folds the 1/world_size of the all-reduce(sum).
+// guard (optional) = {saturation counter, skipped-step counter}: while guard[0] != 0 the gradients of this step came out of a convolution
+// whose fp16 window clamped an operand (common.h) -- the update is NOT applied (parameters, moments and EMA untouched) and, when
+// count_skip is set, guard[1] counts the discarded step so that the host can rewind its bias-correction step number.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                        float* __restrict__ ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-                                                       int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay) {
+                                                       int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay,
+                                                       unsigned int* __restrict__ guard, int count_skip) {
+  if (guard && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (count_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(guard + 1, 1u);
+    return;
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float pi = p[i], gi = g[i] * grad_scale;
     if (decoupled) pi *= (1.0f - lr * wd);
@@ -227,9 +296,10 @@ __global__ void __launch_bounds__(256) adam_ema_kernel(float* __restrict__ p, co
   }
 }
 int k_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd,
-               int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, hipStream_t st) {
+               int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, unsigned int* guard, int count_skip,
+               hipStream_t st) {
   hipLaunchKernelGGL(adam_ema_kernel, dim3(ew_grid(n, 2)), dim3(256), 0, st, p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size,
-                     inv_sqrt_bc2, grad_scale, ema_decay);
+                     inv_sqrt_bc2, grad_scale, ema_decay, guard, count_skip);
   return pdae_launch_status("adam_ema");
 }
 

@@ -36,8 +36,12 @@ int k_ddim_step(const float* x, const float* eps, const float* g, size_t total, 
                 float* out, hipStream_t st);
 int k_ddpm_step(const float* x, const float* eps, const float* g, const float* z, size_t total, float cx, float ce, float cs, float sigma, float* out,
                 hipStream_t st);
+int k_axpby_rows(const float* a, const float* b, const float* ca, const float* cb, int N, size_t per, float* out, hipStream_t st);
+int k_ddim_step_rows(const float* x, const float* eps, const float* g, const float* coef, int N, size_t per, int clamp, float* out, hipStream_t st);
+int k_ddpm_step_rows(const float* x, const float* eps, const float* g, const float* noise, const float* lrange, const float* coef, int N, size_t per,
+                     float* out, hipStream_t st);
 int k_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float b1, float b2, float eps, float wd, int decoupled,
-               float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, hipStream_t st);
+               float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay, unsigned int* guard, int count_skip, hipStream_t st);
 int k_softmax(float* s, long long rows, int T, hipStream_t st);
 int k_softmax_bwd(const float* p, float* dp, long long rows, int T, hipStream_t st);
 size_t k_colsum_workspace_floats(long long M, int C);

@@ -1,156 +1,226 @@
-"""Respaced DDIM (eta = 0) sample / encode loops -- same class and method names as diffusion/ddim.py.
+"""Respaced DDIM (eta = 0): sample / encode steps and loops under the reference's class and method names (diffusion/ddim.py).
 
-Each step is ONE planned decoder forward followed by ONE fused update kernel (pdae_ddim_step) instead of the
-reference's ~15 elementwise launches and 8 gathers per step (ddim.py:94-107).  When the model is a planned
-network of this package the loop runs on the plan's static NHWC buffers with no per-step allocation; any other
-callable `fn(x, t, cond)` goes through the generic path with identical arithmetic.
+What is different from the reference:
+  * one step = ONE planned decoder forward + ONE fused update kernel (the reference: ~15 elementwise launches and 8 gathers,
+    ddim.py:94-107);
+  * the single-step methods take a per-sample `t` exactly like the reference and never read it on the host: the five schedule
+    values of every sample are gathered on the device into a [N,5] row block that `pdae_ddim_step_rows` consumes;
+  * the loops own their step index, so they use the scalar-coefficient kernel; when the model is a planned network of this package
+    they run on the plan's static NHWC buffers with no per-step allocation (any other callable `fn(x, t, cond)` takes the generic
+    path with identical arithmetic);
+  * loops on planned networks poll the fp16-window guard once at their end and re-run in bf16x6 if it fired (hip.SaturationGuard).
 """
-from functools import partial
+import sys
 
 import numpy as np
 import torch
 
+from .. import hip as H
 from . import ops
 
 
+def respaced_tables(betas):
+    """Schedule tables over a respaced beta sequence (ddim.py:8-33), evaluated in the dtype the reference's numpy expressions run in:
+    `betas` keeps its dtype (float32 when it comes from float32 alphas_cumprod, gaussian_diffusion.py:276), the products / roots of the
+    cumulative product stay in it, while the shifted copies are float64 because they are joined with a Python float."""
+    betas = np.asarray(betas)
+    ac = np.cumprod(1.0 - betas, axis=0)
+    shifted_prev = np.concatenate((np.ones(1), ac[:-1]))            # float64 by promotion with the float64 constant
+    shifted_next = np.concatenate((ac[1:], np.zeros(1)))
+    return {"alphas_cumprod_prev": shifted_prev, "alphas_cumprod_next": shifted_next,
+            "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - ac), "sqrt_recip_alphas_cumprod": np.sqrt(1.0 / ac),
+            "sqrt_recip_alphas_cumprod_m1": np.sqrt(1.0 / ac - 1.0)}
+
+
 class DDIM:
-    def __init__(self, betas, timestep_map, device):                       # ddim.py:8-33
+    TABLES = ("alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+              "sqrt_recip_alphas_cumprod_m1")
+
+    def __init__(self, betas, timestep_map, device):
         self.device = device
-        self.timestep_map = timestep_map.to(self.device)
-        self._map_host = [int(v) for v in timestep_map.tolist()]
-        self.timesteps = betas.shape[0] - 1
-        alphas = 1. - betas
-        alphas_cumprod = np.cumprod(alphas, axis=0)
-        alphas_cumprod_prev = np.append(1., alphas_cumprod[:-1])
-        alphas_cumprod_next = np.append(alphas_cumprod[1:], 0.)
-        f32 = lambda a: np.asarray(a, dtype=np.float32)
-        to_torch = partial(torch.tensor, dtype=torch.float32, device=self.device)
-        self._h = dict(prev=f32(alphas_cumprod_prev), next=f32(alphas_cumprod_next), s1m=f32(np.sqrt(1. - alphas_cumprod)),
-                       ra=f32(np.sqrt(1. / alphas_cumprod)), rm1=f32(np.sqrt(1. / alphas_cumprod - 1.)))
-        self.alphas_cumprod_prev = to_torch(alphas_cumprod_prev)
-        self.alphas_cumprod_next = to_torch(alphas_cumprod_next)
-        self.sqrt_one_minus_alphas_cumprod = to_torch(np.sqrt(1. - alphas_cumprod))
-        self.sqrt_recip_alphas_cumprod = to_torch(np.sqrt(1. / alphas_cumprod))
-        self.sqrt_recip_alphas_cumprod_m1 = to_torch(np.sqrt(1. / alphas_cumprod - 1.))
+        self.timestep_map = timestep_map.to(device)
+        self._map_host = timestep_map.tolist()
+        self.timesteps = int(betas.shape[0]) - 1
+        self._host = {}
+        for name, table in respaced_tables(betas).items():
+            f32 = np.asarray(table, dtype=np.float32)
+            self._host[name] = f32
+            setattr(self, name, torch.from_numpy(f32.copy()).to(device))
+        # targets of the update: sqrt(ac_to), sqrt(1 - ac_to) of the fp32 table values (the reference takes torch.sqrt of the gathered fp32 entries)
+        for tag in ("prev", "next"):
+            a = self._host["alphas_cumprod_" + tag]
+            self._host["to_" + tag] = np.stack([np.sqrt(a), np.sqrt(np.float32(1.0) - a)], 1).astype(np.float32)
+        self._rows = {}
 
     @staticmethod
     def extract_coef_at_t(schedule, t, x_shape):
-        return torch.gather(schedule, -1, t).reshape([x_shape[0]] + [1] * (len(x_shape) - 1))
+        return schedule.gather(-1, t).view(x_shape[0], *([1] * (len(x_shape) - 1)))
 
     def t_transform(self, t):
         return self.timestep_map[t]
 
-    # ---- scalar coefficients of step i (all samples of a DDIM loop share the step index)
+    # ------------------------------------------------------------------ coefficients
     def _coefs(self, i, encode):
-        h = self._h
-        ab = h["next"][i] if encode else h["prev"][i]
-        sab = np.sqrt(ab, dtype=np.float32)
-        s1ab = np.sqrt(np.float32(1.0) - ab, dtype=np.float32)
-        return float(h["s1m"][i]), float(h["ra"][i]), float(h["rm1"][i]), float(sab), float(s1ab)
+        """(c_shift, sqrt_recip_ac, sqrt_recip_ac_m1, sqrt(ac_to), sqrt(1-ac_to)) of step i as Python floats."""
+        h = self._host
+        to = h["to_next" if encode else "to_prev"][i]
+        return (float(h["sqrt_one_minus_alphas_cumprod"][i]), float(h["sqrt_recip_alphas_cumprod"][i]), float(h["sqrt_recip_alphas_cumprod_m1"][i]),
+                float(to[0]), float(to[1]))
 
-    def _update(self, x_t, i, eps, grad, encode, out=None):
-        c_shift, ra, rm1, sab, s1ab = self._coefs(i, encode)
-        return ops.ddim_step(x_t, eps, grad, c_shift, ra, rm1, sab, s1ab, out=out)
+    def _coef_rows(self, t, encode):
+        """[N,5] device rows for a per-sample t (gathered from a [T+1,5] table built once per direction)."""
+        tab = self._rows.get(encode)
+        if tab is None:
+            h = self._host
+            tab = np.concatenate([h["sqrt_one_minus_alphas_cumprod"][:, None], h["sqrt_recip_alphas_cumprod"][:, None],
+                                  h["sqrt_recip_alphas_cumprod_m1"][:, None], h["to_next" if encode else "to_prev"]], 1)
+            tab = torch.from_numpy(np.ascontiguousarray(tab, dtype=np.float32)).to(self.device)
+            self._rows[encode] = tab
+        return tab.index_select(0, t)
 
-    @staticmethod
-    def _step_index(t):
-        return int(t.reshape(-1)[0].item())
-
-    # ---- single steps (reference signatures)
+    # ------------------------------------------------------------------ single steps (reference signatures, per-sample t)
     def ddim_sample(self, denoise_fn, x_t, t, condition=None):                         # ddim.py:43-55
-        return self._update(x_t, self._step_index(t), denoise_fn(x_t, self.t_transform(t), condition), None, False)
+        return ops.ddim_step_rows(x_t, denoise_fn(x_t, self.t_transform(t), condition), None, self._coef_rows(t, False))
 
     def ddim_encode(self, denoise_fn, x_t, t, condition=None):                         # ddim.py:66-79
-        return self._update(x_t, self._step_index(t), denoise_fn(x_t, self.t_transform(t), condition), None, True)
+        return ops.ddim_step_rows(x_t, denoise_fn(x_t, self.t_transform(t), condition), None, self._coef_rows(t, True))
 
     def shift_ddim_sample(self, decoder, z, x_t, t, use_shift=True):                   # ddim.py:91-107
         eps, grad = decoder(x_t, self.t_transform(t), z)
-        return self._update(x_t, self._step_index(t), eps, grad if use_shift else None, False)
+        return ops.ddim_step_rows(x_t, eps, grad if use_shift else None, self._coef_rows(t, False))
 
     def shift_ddim_encode(self, decoder, z, x_t, t):                                   # ddim.py:123-138
         eps, grad = decoder(x_t, self.t_transform(t), z)
-        return self._update(x_t, self._step_index(t), eps, grad, True)
+        return ops.ddim_step_rows(x_t, eps, grad, self._coef_rows(t, True))
 
-    # ---- loops
-    def _planned_loop(self, net, x_start, steps, encode, z=None, condition=None, use_shift=lambda i: True, trajectory=None):
-        """Runs on the network's inference plan: static buffers, two host calls per step."""
-        N, _, Hh, W = x_start.shape
-        p = net.plan(N, Hh, W, False)
-        p.x.copy_(x_start.permute(0, 2, 3, 1))
-        if z is not None:
-            p.z.copy_(z)
-        if condition is not None and getattr(p, "cond", None) is not None:
-            p.cond.copy_(condition)
-        shift = getattr(p, "shift", None)
-        for i in steps:
-            p.t.fill_(self._map_host[i])
-            p.run(0, p.n_fwd)
-            c_shift, ra, rm1, sab, s1ab = self._coefs(i, encode)
-            g = shift if (shift is not None and use_shift(i)) else None
-            ops.ddim_step(p.x, p.eps, g, c_shift, ra, rm1, sab, s1ab, out=p.x)
-            if trajectory is not None:
-                trajectory.append(p.x.clone().permute(0, 3, 1, 2))
-        return p.x.clone().permute(0, 3, 1, 2)
+    def latent_ddim_sample(self, latent_denoise_fn, z_t, t):                           # ddim.py:179-198 (active body: no clamp, eps reused)
+        return ops.ddim_step_rows(z_t, latent_denoise_fn(z_t, self.t_transform(t)), None, self._coef_rows(t, False), clamp=False)
 
+    # ------------------------------------------------------------------ loops
     @staticmethod
     def _planned(net):
         return hasattr(net, "plan") and hasattr(net, "P") and not torch.is_grad_enabled()
 
-    def ddim_sample_loop(self, denoise_fn, x_T, condition=None):                        # ddim.py:57-64
-        steps = list(reversed(range(1, self.timesteps + 1)))
-        if self._planned(denoise_fn) and x_T.dim() == 4:
-            return self._planned_loop(denoise_fn, x_T, steps, False, condition=condition)
-        img = x_T
+    def _full(self, n, i):
+        return torch.full((n,), i, device=self.device, dtype=torch.long)
+
+    def _guarded(self, net, body):
+        """Runs body() on a planned network; if the fp16-window guard fired meanwhile, switches the process to bf16x6 and runs it again."""
+        out = body()
+        g = H.SaturationGuard.get(net.device)
+        if g is not None and H.default_math() == "f16x3" and g.read()[0]:
+            print("[pdae_amd] fp16 window exceeded during a DDIM loop: re-running it in bf16x6 arithmetic", file=sys.stderr, flush=True)
+            H.set_default_math("bf16x6")
+            net.invalidate_plans()
+            g.reset()
+            out = body()
+        return out
+
+    def _planned_loop(self, net, x_start, steps, encode, z=None, condition=None, use_shift=lambda i: True, trajectory=None, z_mix=None):
+        """Static-buffer loop: per step one op-list launch (two for trajectory interpolation) and one update kernel.
+        z_mix = (z_2, alpha): the shift term is (1-alpha)*g(z) + alpha*g(z_2), eps from the first pass (ddim.py:157-160)."""
+        N, _, Hh, W = x_start.shape
+
+        def body():
+            p = net.plan(N, Hh, W, False)
+            p.x.copy_(x_start.permute(0, 2, 3, 1))
+            if z is not None:
+                p.z.copy_(z)
+            if condition is not None and getattr(p, "cond", None) is not None:
+                p.cond.copy_(condition)
+            shift = getattr(p, "shift", None)
+            keep_eps = keep_g = None
+            if z_mix is not None:
+                keep_eps, keep_g = torch.empty_like(p.eps), torch.empty_like(p.shift)
+            if trajectory is not None:
+                del trajectory[:]
+            for i in steps:
+                p.t.fill_(self._map_host[i])
+                p.run(0, p.n_fwd)
+                eps, g = p.eps, (shift if (shift is not None and use_shift(i)) else None)
+                if z_mix is not None:
+                    z_2, alpha = z_mix
+                    keep_eps.copy_(p.eps)
+                    keep_g.copy_(p.shift)
+                    p.z.copy_(z_2)
+                    p.run(0, p.n_fwd)
+                    p.z.copy_(z)
+                    H.run(H.op_axpby(p.shift, keep_g, keep_g.numel(), alpha, 1.0 - alpha))      # keep_g = alpha*g_2 + (1-alpha)*g_1
+                    eps, g = keep_eps, keep_g
+                c_shift, ra, rm1, sab, s1ab = self._coefs(i, encode)
+                ops.ddim_step(p.x, eps, g, c_shift, ra, rm1, sab, s1ab, out=p.x)
+                if trajectory is not None:
+                    trajectory.append(p.x.clone().permute(0, 3, 1, 2))
+            return p.x.clone().permute(0, 3, 1, 2)
+
+        return self._guarded(net, body)
+
+    def _generic_loop(self, step_fn, x, steps):
         for i in steps:
-            t = torch.full((x_T.shape[0],), i, device=self.device, dtype=torch.long)
-            img = self.ddim_sample(denoise_fn, img, t, condition)
-        return img
+            x = step_fn(x, i)
+        return x
+
+    def _step(self, x, i, eps, grad, encode, clamp=True):
+        c_shift, ra, rm1, sab, s1ab = self._coefs(i, encode)
+        return ops.ddim_step(x, eps, grad, c_shift, ra, rm1, sab, s1ab, clamp=clamp)
+
+    def _down(self):
+        return range(self.timesteps, 0, -1)
+
+    def _up(self):
+        return range(0, self.timesteps)
+
+    def ddim_sample_loop(self, denoise_fn, x_T, condition=None):                        # ddim.py:57-64
+        if self._planned(denoise_fn) and x_T.dim() == 4:
+            return self._planned_loop(denoise_fn, x_T, self._down(), False, condition=condition)
+        n = x_T.shape[0]
+        return self._generic_loop(lambda x, i: self._step(x, i, denoise_fn(x, self.t_transform(self._full(n, i)), condition), None, False),
+                                  x_T, self._down())
 
     def ddim_encode_loop(self, denoise_fn, x_0, condition=None):                        # ddim.py:81-88
-        steps = list(range(0, self.timesteps))
         if self._planned(denoise_fn) and x_0.dim() == 4:
-            return self._planned_loop(denoise_fn, x_0, steps, True, condition=condition)
-        x_t = x_0
-        for i in steps:
-            t = torch.full((x_0.shape[0],), i, device=self.device, dtype=torch.long)
-            x_t = self.ddim_encode(denoise_fn, x_t, t, condition)
-        return x_t
+            return self._planned_loop(denoise_fn, x_0, self._up(), True, condition=condition)
+        n = x_0.shape[0]
+        return self._generic_loop(lambda x, i: self._step(x, i, denoise_fn(x, self.t_transform(self._full(n, i)), condition), None, True),
+                                  x_0, self._up())
 
     def shift_ddim_sample_loop(self, decoder, z, x_T, stop_percent=0.0, trajectory=None):   # ddim.py:110-120
         stop_step = int(stop_percent * self.timesteps)
-        steps = list(reversed(range(1, self.timesteps + 1)))
         use = lambda i: (i - 1) >= stop_step
         if self._planned(decoder):
-            return self._planned_loop(decoder, x_T, steps, False, z=z, use_shift=use, trajectory=trajectory)
-        img = x_T
-        for i in steps:
-            t = torch.full((x_T.shape[0],), i, device=self.device, dtype=torch.long)
-            img = self.shift_ddim_sample(decoder, z, img, t, use_shift=use(i))
-        return img
+            return self._planned_loop(decoder, x_T, self._down(), False, z=z, use_shift=use, trajectory=trajectory)
+        n = x_T.shape[0]
+
+        def one(x, i):
+            eps, grad = decoder(x, self.t_transform(self._full(n, i)), z)
+            return self._step(x, i, eps, grad if use(i) else None, False)
+        return self._generic_loop(one, x_T, self._down())
 
     def shift_ddim_encode_loop(self, decoder, z, x_0, trajectory=None):                 # ddim.py:140-147
-        steps = list(range(0, self.timesteps))
         if self._planned(decoder):
-            return self._planned_loop(decoder, x_0, steps, True, z=z, trajectory=trajectory)
-        x_t = x_0
-        for i in steps:
-            t = torch.full((x_0.shape[0],), i, device=self.device, dtype=torch.long)
-            x_t = self.shift_ddim_encode(decoder, z, x_t, t)
-        return x_t
+            return self._planned_loop(decoder, x_0, self._up(), True, z=z, trajectory=trajectory)
+        n = x_0.shape[0]
+
+        def one(x, i):
+            eps, grad = decoder(x, self.t_transform(self._full(n, i)), z)
+            return self._step(x, i, eps, grad, True)
+        return self._generic_loop(one, x_0, self._up())
 
     def shift_ddim_trajectory_interpolation(self, decoder, z_1, z_2, x_T, alpha):       # ddim.py:149-174
-        x_t = x_T
-        for i in reversed(range(1, self.timesteps + 1)):
-            t = torch.full((x_T.shape[0],), i, device=self.device, dtype=torch.long)
-            eps, g1 = decoder(x_t, self.t_transform(t), z_1)
-            _, g2 = decoder(x_t, self.t_transform(t), z_2)
-            grad = (1.0 - alpha) * g1 + alpha * g2
-            x_t = self._update(x_t, i, eps, grad, False)
-        return x_t
+        """Both latents are decoded at every step; eps comes from the z_1 pass, the shift terms are blended with weight alpha."""
+        alpha = float(alpha)
+        if self._planned(decoder):
+            return self._planned_loop(decoder, x_T, self._down(), False, z=z_1, z_mix=(z_2, alpha))
+        n = x_T.shape[0]
 
-    def latent_ddim_sample_loop(self, latent_denoise_fn, z_T):                          # ddim.py:200-207 (the clamping variant)
-        z = z_T
-        for i in reversed(range(1, self.timesteps + 1)):
-            t = torch.full((z_T.shape[0],), i, device=self.device, dtype=torch.long)
-            z = self._update(z, i, latent_denoise_fn(z, self.t_transform(t), None), None, False)
-        return z
+        def one(x, i):
+            t = self.t_transform(self._full(n, i))
+            eps, g_1 = decoder(x, t, z_1)
+            g_2 = decoder(x, t, z_2)[1]
+            return self._step(x, i, eps, ops.blend(g_1, g_2, alpha), False)
+        return self._generic_loop(one, x_T, self._down())
+
+    def latent_ddim_sample_loop(self, latent_denoise_fn, z_T):                          # ddim.py:200-207: the loop calls ddim_sample (clamping form)
+        n = z_T.shape[0]
+        return self._generic_loop(lambda z, i: self._step(z, i, latent_denoise_fn(z, self.t_transform(self._full(n, i)), None), None, False),
+                                  z_T, self._down())

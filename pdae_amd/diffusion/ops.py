@@ -58,3 +58,42 @@ def ddpm_step(x, eps, g, z, cx, ce, cs, sigma):
     out = torch.empty_like(x)
     H.run(H.op_ddpm_step(x, eps, None if g is None else _c(g), None if z is None else _c(z), x.numel(), cx, ce, cs, sigma, out))
     return out
+
+
+def _rows(x):
+    """(contiguous tensor, N, elements per sample)"""
+    x = _c(x)
+    return x, x.shape[0], x.numel() // x.shape[0]
+
+
+def axpby_rows(a, b, ca, cb):
+    """out[n] = ca[n] * a[n] + cb[n] * b[n]; ca / cb: float32 device vectors of length N."""
+    a, N, per = _rows(a)
+    b = _c(b)
+    out = torch.empty_like(a)
+    H.run(H.op_axpby_rows(a, b, _c(ca), _c(cb), N, per, out))
+    return out
+
+
+def ddim_step_rows(x, eps, g, coef, clamp=True):
+    """DDIM update with one coefficient row per sample: coef [N,5] = (c_shift, sqrt_recip_ac, sqrt_recip_ac_m1, sqrt(ac_to), sqrt(1-ac_to))."""
+    x, N, per = _rows(x)
+    out = torch.empty_like(x)
+    H.run(H.op_ddim_step_rows(x, _c(eps), None if g is None else _c(g), _c(coef), N, per, out, clamp=int(clamp)))
+    return out
+
+
+def ddpm_step_rows(x, eps, g, noise, learned_range, coef):
+    """Ancestral step with one coefficient row per sample: coef [N,6] = (cx, ce, cs, mask, lv_min, lv_max)."""
+    x, N, per = _rows(x)
+    out = torch.empty_like(x)
+    H.run(H.op_ddpm_step_rows(x, _c(eps), None if g is None else _c(g), None if noise is None else _c(noise),
+                              None if learned_range is None else _c(learned_range), _c(coef), N, per, out))
+    return out
+
+
+def blend(a, b, alpha):
+    """(1 - alpha) * a + alpha * b in one kernel (fresh tensor)."""
+    out = _c(a).clone()
+    H.run(H.op_axpby(_c(b), out, out.numel(), float(alpha), 1.0 - float(alpha)))
+    return out

@@ -83,6 +83,7 @@ class Plan:
             self.watch.append(module)
 
     def compile(self):
+        self.guard = H.SaturationGuard.get(self.device)       # arms the fp16-window counter of the math-4 kernels on this device
         self.ws = torch.empty(self.ws_bytes // 4 + 64, dtype=torch.float32, device=self.device)
         self.arr = H.ops_array(self.recs)
         self.n = len(self.recs)
@@ -151,7 +152,7 @@ class Builder:
         self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
         self._frozen_wp = {}
         self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
-        self.math = H.MATH_NAMES[os.environ.get("PDAE_CONV_MATH", H.DEFAULT_MATH)] if math is None else int(math)
+        self.math = H.MATH_NAMES[H.default_math()] if math is None else (H.MATH_NAMES[math] if isinstance(math, str) else int(math))
         self.P = params
         self.Gr = grads or {}
         self.save = save          # keep activations for backward (else buffers are recycled)

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
- OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX) = range(1, 35)
+ OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX,
+ OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS) = range(1, 38)
 
 
 class PdaeOp(ctypes.Structure):
@@ -38,6 +39,20 @@ MATH_NAMES = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
 #   "bf16x6": three exact bf16 planes, 6 products (3.7e-7 on the same conv) everywhere -- range-safe for any input.
 # Both pass the same parity gates as the exact f32-MFMA kernels ("f32"), which remain selectable with PDAE_CONV_MATH.
 DEFAULT_MATH = "f16x3"
+_math_override = None
+
+
+def default_math():
+    """Name of the arithmetic mode new plans are built with: set_default_math() > $PDAE_CONV_MATH > DEFAULT_MATH."""
+    return _math_override or os.environ.get("PDAE_CONV_MATH", DEFAULT_MATH)
+
+
+def set_default_math(name):
+    """Process-wide override (None restores the environment / built-in default).  Existing plans keep the mode they were built with:
+    call net.invalidate_plans() / rebuild the fused step to move them."""
+    global _math_override
+    assert name is None or name in MATH_NAMES, name
+    _math_override = name
 
 
 class PdaeError(RuntimeError):
@@ -68,15 +83,62 @@ def lib():
         L.pdae_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
         L.pdae_colsum_workspace_bytes.restype = ctypes.c_size_t
         L.pdae_abi_version.restype = ctypes.c_int
+        L.pdae_set_saturation_counter.argtypes = [ctypes.c_void_p]
+        L.pdae_set_saturation_counter.restype = ctypes.c_int
         _lib = L
     return _lib
 
 
-EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
+EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
            "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
-           "pdae_ddim_step", "pdae_ddpm_step", "pdae_adam_ema", "pdae_run_ops"]
+           "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops"]
+
+
+class SaturationGuard:
+    """fp16-window guard of the default "f16x3" arithmetic (include/pdae_hip.h: pdae_set_saturation_counter).
+
+    One int32[2] device tensor per process: [0] = number of math-4 convolution launches that met a scaled operand outside the fp16
+    window (|x| > 60000 after the power-of-two pre-scale: post-GroupNorm activations beyond ~3750, a raw residual stream beyond 6e4,
+    or Inf), [1] = optimizer steps the device refused to apply because [0] was non-zero.  Reading it synchronises: callers poll it at
+    their own cadence (trainers: every display interval; samplers: once per loop) and fall back to "bf16x6" when it fires."""
+    _inst = None
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.t = torch.zeros(2, dtype=torch.int32, device=self.device)
+        rc = lib().pdae_set_saturation_counter(ctypes.c_void_p(self.t.data_ptr()))
+        if rc != 0:
+            raise PdaeError("pdae_set_saturation_counter failed")
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            return None
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if cls._inst is None or cls._inst.device != device:
+            cls._inst = cls(device)
+        return cls._inst
+
+    def read(self):
+        """(saturated launches, skipped optimizer steps) -- host sync."""
+        a = self.t.tolist()
+        return int(a[0]) & 0xffffffff, int(a[1]) & 0xffffffff
+
+    def reset(self):
+        self.t.zero_()
+
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+def saturated(device="cuda"):
+    """True when a math-4 convolution has overflowed its fp16 window since the last reset (host sync)."""
+    g = SaturationGuard.get(device)
+    return g is not None and g.read()[0] != 0
 
 
 def _ptr(t):
@@ -296,8 +358,21 @@ def op_ddpm_step(x, eps, g, z, total, cx, ce, cs, sigma, out):
     return make_op(OP_DDPM_STEP, [x, eps, g, z, out], [total], [cx, ce, cs, sigma])
 
 
-def op_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay):
-    return make_op(OP_ADAM_EMA, [p, g, m, v, ema], [n, decoupled], [lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2, grad_scale, ema_decay])
+def op_axpby_rows(a, b, ca, cb, N, per, out):
+    return make_op(OP_AXPBY_ROWS, [a, b, ca, cb, out], [N, per])
+
+
+def op_ddim_step_rows(x, eps, g, coef, N, per, out, clamp=1):
+    return make_op(OP_DDIM_STEP_ROWS, [x, eps, g, coef, out], [N, per, clamp])
+
+
+def op_ddpm_step_rows(x, eps, g, noise, learned_range, coef, N, per, out):
+    return make_op(OP_DDPM_STEP_ROWS, [x, eps, g, noise, learned_range, coef, out], [N, per])
+
+
+def op_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay, guard=None, count_skip=0):
+    """guard: SaturationGuard tensor pointer -- the kernel leaves everything untouched while guard[0] != 0 (and counts the skip in guard[1])."""
+    return make_op(OP_ADAM_EMA, [p, g, m, v, ema, guard], [n, decoupled, count_skip], [lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2, grad_scale, ema_decay])
 
 
 def op_softmax(s, rows, T):

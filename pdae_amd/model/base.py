@@ -65,3 +65,31 @@ class PlannedNet(FlatModule):
 
     def _wants_grad(self):
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.P.values())
+
+    def _bridge(self, plan, run_fwd, run_bwd, n_out, *inputs):
+        """Hooks one planned forward / backward pair into torch autograd with torch's gradient semantics:
+          * backward ACCUMULATES into the flat gradient buffer (the bridge plans are built with acc_grads=True), so reference-style loops
+            that run several micro-batches between zero_grad() and optimizer.step() (runner_config.num_iterations) see the sum;
+          * `optimizer.zero_grad()` of a torch optimizer sets `.grad = None`: the next backward then starts from zero and re-binds every
+            parameter's `.grad` to its view of the flat buffer;
+          * a plan keeps ONE set of saved activations: a backward whose forward has been overwritten by a later forward of the same module
+            and input shape raises instead of returning the wrong gradient."""
+        plan.fwd_serial = getattr(plan, "fwd_serial", 0) + 1
+        serial = plan.fwd_serial
+
+        def bwd(*douts):
+            if plan.fwd_serial != serial:
+                raise RuntimeError("pdae_amd: backward() of a forward pass whose saved activations were overwritten by a later forward of the "
+                                   "same module and input shape (a planned network keeps one set of activations per plan) -- call backward "
+                                   "before the next forward, or run the extra forward under torch.no_grad()")
+            G = self.grads()
+            first = next(iter(G), None)
+            if first is not None and self.P[first].grad is None:          # zero_grad(set_to_none=True)
+                self.flat_grad.zero_()
+            out = run_bwd(*douts)
+            for k, g in G.items():
+                if self.P[k].grad is not g:
+                    self.P[k].grad = g
+            return out
+
+        return _Bridge.apply(self._dummy_leaf(), run_fwd, bwd, n_out, *inputs)

@@ -356,7 +356,8 @@ def unet_backward(B, fx, d_eps):
     pl.emit(H.op_silu_bwd(t.emb, d_ea, d_emb, N * E))
     gt = B.Gr.get("label_emb.weight") if t.cond is not None else None
     if gt is not None:
-        pl.emit(H.op_memset(gt, gt.numel() * 4))
+        if not B.acc:                                # accumulating plans add into the (pre-zeroed) table gradient
+            pl.emit(H.op_memset(gt, gt.numel() * 4))
         pl.emit(H.op_embedding_bwd(d_emb, t.cond, N, E, gt))
     d_hs = pl.buf(N, E)
     B.linear_bwd(t.l2, d_emb, dx=d_hs, dx_acc=0)

@@ -187,7 +187,7 @@ class MLPSkipNet(PlannedNet):
         p = Plan(self.device)
         x = p.buf(R, self.cfg["input_channel"])
         t = p.buf(R, dtype=torch.int64)
-        B = Builder(p, self.P, self.grads() if train else None, save=bool(train))
+        B = Builder(p, self.P, self.grads() if train else None, save=bool(train), acc_grads=bool(train))
         fx = self._emit_forward(B, x, t)
         p.n_fwd = len(p.recs)
         p.d_out = p.dx = None
@@ -220,5 +220,5 @@ class MLPSkipNet(PlannedNet):
             return (p.dx.clone(),) if x.requires_grad else ()
 
         if x.requires_grad:
-            return _Bridge.apply(self._dummy_leaf(), run_fwd, run_bwd, 1, x)
-        return _Bridge.apply(self._dummy_leaf(), run_fwd, run_bwd, 1)
+            return self._bridge(p, run_fwd, run_bwd, 1, x)
+        return self._bridge(p, run_fwd, run_bwd, 1)

@@ -27,7 +27,7 @@ class _Encoder(PlannedNet):
             return pl
         p = Plan(self.device)
         x = p.buf(N, Hh, W, 3)
-        B = Builder(p, self.P, self.grads() if train else None, save=bool(train))
+        B = Builder(p, self.P, self.grads() if train else None, save=bool(train), acc_grads=bool(train))
         z, ex = G.encoder_forward(B, self.NAME, x)
         p.n_fwd = len(p.recs)
         p.dz = None
@@ -57,7 +57,7 @@ class _Encoder(PlannedNet):
             p.run(p.n_fwd, p.n)
             return ()
 
-        return _Bridge.apply(self._dummy_leaf(), run_fwd, run_bwd, 1)
+        return self._bridge(p, run_fwd, run_bwd, 1)
 
 
 class FFHQEncoder(_Encoder):

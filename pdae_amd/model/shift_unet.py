@@ -59,7 +59,8 @@ class ShiftUNet(PlannedNet):
         x = p.buf(N, Hh, W, cfg["input_channel"])
         t = p.buf(N, dtype=torch.int64)
         z = p.buf(N, self.latent_dim)
-        B = Builder(p, self.P, self.grads() if train else None, save=False, drop_p=float(cfg["dropout"]) if dropout else 0.0, frozen_of=self)
+        B = Builder(p, self.P, self.grads() if train else None, save=False, drop_p=float(cfg["dropout"]) if dropout else 0.0, frozen_of=self,
+                    acc_grads=bool(train))
         fx = G.unet_forward(B, cfg, x, t, self.freqs, z=z, shift=True, train_shift=bool(train), dropout=dropout)
         p.n_fwd = len(p.recs)
         p.d_shift = p.dz = None
@@ -98,4 +99,4 @@ class ShiftUNet(PlannedNet):
             p.run(p.n_fwd, p.n)
             return (p.dz.clone(),)
 
-        return _Bridge.apply(self._dummy_leaf(), run_fwd, run_bwd, 2, condition)
+        return self._bridge(p, run_fwd, run_bwd, 2, condition)

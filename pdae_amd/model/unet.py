@@ -34,7 +34,8 @@ class UNet(PlannedNet):
 
     # ------------------------------------------------------------------ plans
     def plan(self, N, Hh, W, train):
-        key = (N, Hh, W, bool(train))
+        dropout = bool(train) and self.training and float(self.cfg["dropout"]) > 0       # fixed at plan-build time: part of the key
+        key = (N, Hh, W, bool(train), dropout)
         pl = self._plans.get(key)
         if pl is not None:
             return pl
@@ -43,8 +44,8 @@ class UNet(PlannedNet):
         x = p.buf(N, Hh, W, cfg["input_channel"])
         t = p.buf(N, dtype=torch.int64)
         cond = p.buf(N, dtype=torch.int64) if cfg["num_class"] is not None else None
-        B = Builder(p, self.P, self.grads() if train else None, save=bool(train), drop_p=float(cfg["dropout"]) if train else 0.0)
-        fx = G.unet_forward(B, cfg, x, t, self.freqs, cond=cond, dropout=bool(train) and self.training)
+        B = Builder(p, self.P, self.grads() if train else None, save=bool(train), drop_p=float(cfg["dropout"]) if dropout else 0.0, acc_grads=bool(train))
+        fx = G.unet_forward(B, cfg, x, t, self.freqs, cond=cond, dropout=dropout)
         p.n_fwd = len(p.recs)
         p.d_eps = None
         if train:
@@ -81,4 +82,4 @@ class UNet(PlannedNet):
             p.run(p.n_fwd, p.n)
             return ()
 
-        return _Bridge.apply(self._dummy_leaf(), run_fwd, run_bwd, 1)
+        return self._bridge(p, run_fwd, run_bwd, 1)

@@ -1,19 +1,27 @@
-"""One representation-learning optimisation step as a single planned graph.
+"""One optimisation step as a single planned graph (three variants share one driver).
 
-Replaces the body of RepresentationLearningTrainer.train (trainer/train_representation_learning.py:81-124):
+FusedRLStep replaces the body of RepresentationLearningTrainer.train (trainer/train_representation_learning.py:81-124):
     zero_grad -> encoder fwd -> randint/randn -> q_sample -> ShiftUNet fwd -> weighted L2 -> backward
     (DDP all-reduce of the trainable gradients) -> Adam -> EMA
 with one static op list over pre-allocated buffers:
   * the frozen trunk / eps-branch keep no activations and emit no backward;
   * loss and d(loss)/d(shift) come out of one kernel; the loss stays on the device (the reference's two
     `.item()` syncs per micro-batch, :107-108, are gone -- read `last_loss` when you want the value);
-  * gradients live in two flat buffers (decoder-trainable, encoder); the data-parallel exchange is an
-    all-reduce(sum) over contiguous ranges of them, launched as soon as the backward has finished each range
-    (reverse execution order) so RCCL overlaps with the rest of the backward; 1/world is folded into Adam;
-  * Adam (torch.optim.Adam semantics) and the EMA update are one kernel per flat buffer.
+  * gradients live in flat buffers (decoder-trainable, encoder); the data-parallel exchange is an all-reduce(sum)
+    over contiguous ranges of them, launched as soon as the backward has finished each range (reverse execution
+    order) so RCCL overlaps with the rest of the backward; 1/world is folded into Adam;
+  * Adam (torch.optim.Adam / AdamW semantics) and the EMA update are one kernel per flat buffer;
+  * `num_iterations` micro-batches accumulate into the flat gradients before one optimizer step, EMA every `ema_every`
+    steps (runner_config of every reference trainer: train_*.py main loops);
+  * fp16-window guard (hip.SaturationGuard): while the device counter is non-zero the optimizer kernel applies nothing;
+    `handle_saturation()` (host sync, call it at the logging cadence) rewinds the step counter by the discarded steps and
+    rebuilds the plan in the range-free "bf16x6" arithmetic.
+FusedRegularStep (config #1) and FusedLatentStep (config #5) are the same driver around other graphs.
 """
 import math
 import random
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -23,96 +31,81 @@ from ..engine import Plan, Builder
 from ..model import graph as G
 
 
-class FusedRLStep:
-    def __init__(self, gaussian_diffusion, encoder, decoder, ema_encoder, ema_decoder, batch, height, width, lr=1e-4, betas=(0.9, 0.999),
-                 eps=1e-8, weight_decay=0.0, decoupled=False, ema_decay=0.9999, ema_every=1, num_iterations=1, process_group=None,
-                 bucket_mb=48, math=None):
-        gd = gaussian_diffusion
-        self.gd, self.enc, self.dec, self.ema_enc, self.ema_dec = gd, encoder, decoder, ema_encoder, ema_decoder
-        self.N, self.Hh, self.W = batch, height, width
-        self.lr, self.b1, self.b2, self.eps, self.wd, self.decoupled = lr, betas[0], betas[1], eps, weight_decay, int(decoupled)
-        self.ema_decay, self.ema_every, self.num_iterations = ema_decay, ema_every, num_iterations
+class _FusedStep:
+    """Driver shared by the three fused steps.  A subclass provides `_build(math)` (emits forward + backward into self.plan, sets
+    self.n_bwd, self.loss and self._marks) and `_load(*inputs)` (copies one micro-batch into the plan's input buffers)."""
+
+    def _init_driver(self, nets, emas, lr, betas, eps, weight_decay, decoupled, ema_decay, ema_every, num_iterations, process_group,
+                     bucket_mb, math):
+        self.flat_nets = list(nets)
+        self.emas = list(emas)
+        self.lr, self.b1, self.b2, self.adam_eps, self.wd, self.decoupled = lr, betas[0], betas[1], eps, weight_decay, int(decoupled)
+        self.ema_decay, self.ema_every, self.num_iterations = ema_decay, int(ema_every), int(num_iterations)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.bucket_mb = bucket_mb
         self.step_count = 0
         self.micro = 0
-        dev = decoder.device
-        cfg = decoder.cfg
-        N, Hh, W, Cimg = batch, height, width, cfg["input_channel"]
-        per = Hh * W * Cimg
-        acc = num_iterations > 1
-        drop = float(cfg["dropout"]) if decoder._shift_train else 0.0
+        for n in self.flat_nets:
+            n.grads()                                   # allocate the flat gradient buffers
+        self.m = [torch.zeros_like(n.flat_train) for n in self.flat_nets]
+        self.v = [torch.zeros_like(n.flat_train) for n in self.flat_nets]
+        self.comm_events = None                         # set by enable_comm_timing()
+        self.rebuild(math)
 
-        p = Plan(dev)
-        self.plan = p
-        self.x0 = p.buf(N, Hh, W, Cimg)
-        self.noise = p.buf(N, Hh, W, Cimg)
-        self.t = p.buf(N, dtype=torch.int64)
-        self.loss = p.buf(1)
-        Be = Builder(p, encoder.P, encoder.grads(), save=True, acc_grads=acc, math=math)
-        Bd = Builder(p, decoder.P, decoder.grads(), save=False, drop_p=drop, acc_grads=acc, math=math, frozen_of=decoder)
-        # ---- forward
-        z, ex = G.encoder_forward(Be, encoder.NAME, self.x0)
-        x_t = p.buf(N, Hh, W, Cimg)
-        p.emit(H.op_q_sample(self.x0, self.noise, self.t, gd.sqrt_alphas_cumprod, gd.sqrt_one_minus_alphas_cumprod, N, per, x_t))
-        fx = G.unet_forward(Bd, cfg, x_t, self.t, decoder.freqs, z=z, shift=True, train_shift=True, dropout=drop > 0)
-        d_shift = p.buf(N, Hh, W, Cimg)
-        p.emit(H.op_loss(self.noise, fx.eps, fx.shift, self.t, gd.shift_coef, gd.weight, N, per, self.loss, None, dg=d_shift,
-                         scale=1.0 / num_iterations), ws_slot=9)
-        self.n_fwd = len(p.recs)
-        self.z, self.eps, self.shift = z, fx.eps, fx.shift
-        # ---- backward, with the op index at which each parameter block's gradients are final
-        marks = []
-        dz = G.shift_backward(Bd, fx, d_shift, mark=lambda prefix: marks.append((len(p.recs), prefix)))
-        G.encoder_backward(Be, ex, dz)
+    # ------------------------------------------------------------------ plan (re)construction
+    def rebuild(self, math=None):
+        """(Re)builds the op list in arithmetic `math` (None: hip.default_math()); optimizer state and step count are kept."""
+        self.math_name = math if isinstance(math, str) else (H.default_math() if math is None else
+                                                             {v: k for k, v in H.MATH_NAMES.items()}[int(math)])
+        self.plan = Plan(self.flat_nets[0].device)
+        self._marks = []
+        self._build(self.math_name)
+        p = self.plan
         self.n_bwd = len(p.recs)
-        # ---- optimizer (+EMA): one op per flat buffer; scalars are patched every step
-        self.m = [torch.zeros_like(decoder.flat_train), torch.zeros_like(encoder.flat_train)]
-        self.v = [torch.zeros_like(decoder.flat_train), torch.zeros_like(encoder.flat_train)]
+        guard = H.SaturationGuard.get(p.device)
+        self.guard = guard
         self.adam_idx = []
-        self.flat_nets = [decoder, encoder]
-        for k, (net, ema) in enumerate([(decoder, ema_decoder), (encoder, ema_encoder)]):
+        for k, (net, ema) in enumerate(zip(self.flat_nets, self.emas)):
             idx = p.emit(H.op_adam_ema(net.flat_train, net.flat_grad, self.m[k], self.v[k], ema.flat_train if ema is not None else None,
-                                       net.flat_train.numel(), lr, self.b1, self.b2, eps, weight_decay, self.decoupled, lr, 1.0, 1.0, ema_decay))
+                                       net.flat_train.numel(), self.lr, self.b1, self.b2, self.adam_eps, self.wd, self.decoupled, self.lr, 1.0, 1.0,
+                                       self.ema_decay, guard=guard.ptr() if guard is not None else None, count_skip=int(k == 0)))
             self.adam_idx.append((idx, ema.flat_train.data_ptr() if ema is not None else 0))
         p.compile()
-        self.buckets = self._make_buckets(marks, bucket_mb)
+        self.buckets = self._make_buckets(self._marks, self.bucket_mb)
 
     # ------------------------------------------------------------------ DDP buckets
     def _make_buckets(self, marks, bucket_mb):
-        """[(op_index_after_which_ready, flat_grad_tensor_slice)] in backward order."""
-        dec = self.dec
-        limit = bucket_mb * (1 << 20) // 4
-        ranges = []
-        for op_idx, prefix in marks:
-            offs = [(o, n) for k, (tr, o, n) in dec._offs.items() if tr and k.startswith(prefix)]
-            if offs:
-                ranges.append((op_idx, min(o for o, _ in offs), max(o + n for o, n in offs)))
-        buckets, cur_hi = [], dec.flat_grad.numel()
-        pend_lo = cur_hi
-        for op_idx, lo, hi in ranges:                    # backward order: descending offsets
-            pend_lo = min(pend_lo, lo)
-            if cur_hi - pend_lo >= limit:
-                buckets.append((op_idx, dec.flat_grad[pend_lo:cur_hi]))
-                cur_hi = pend_lo
-        if cur_hi > 0:
-            buckets.append((ranges[-1][0] if ranges else self.n_bwd, dec.flat_grad[0:cur_hi]))
-        buckets.append((self.n_bwd, self.enc.flat_grad))
+        """[(op_index_after_which_ready, flat_grad_tensor_slice)] in backward order.  marks = [(op index, net, prefix)]: every
+        parameter gradient of `net` under `prefix` is final once the ops before `op index` have run."""
+        limit = int(bucket_mb * (1 << 20)) // 4
+        buckets = []
+        seen = []
+        for net in self.flat_nets:
+            ranges = []
+            for op_idx, mnet, prefix in marks:
+                if mnet is not net:
+                    continue
+                offs = [(o, n) for k, (tr, o, n) in net._offs.items() if tr and k.startswith(prefix)]
+                if offs:
+                    ranges.append((op_idx, min(o for o, _ in offs), max(o + n for o, n in offs)))
+            if not ranges:                               # no marks for this network: one bucket after the whole backward
+                seen.append((self.n_bwd, net.flat_grad))
+                continue
+            cur_hi = net.flat_grad.numel()
+            pend_lo = cur_hi
+            for op_idx, lo, hi in ranges:                # backward order: descending offsets
+                pend_lo = min(pend_lo, lo)
+                if cur_hi - pend_lo >= limit:
+                    buckets.append((op_idx, net.flat_grad[pend_lo:cur_hi]))
+                    cur_hi = pend_lo
+            if cur_hi > 0:
+                buckets.append((ranges[-1][0], net.flat_grad[0:cur_hi]))
+        buckets.extend(seen)
+        buckets.sort(key=lambda b: b[0])
         return buckets
 
     # ------------------------------------------------------------------ one micro-batch / one step
-    def load_batch(self, x_0, t=None, noise=None):
-        """x_0 / noise: (N,C,H,W) tensors of any strides.  t, noise are drawn like the reference
-        (torch.randint then torch.randn_like, gaussian_diffusion.py:240-241) unless injected."""
-        self.x0.copy_(x_0.permute(0, 2, 3, 1))
-        if t is None:
-            t = torch.randint(0, self.gd.timesteps, (self.N,), device=self.x0.device, dtype=torch.long)
-        self.t.copy_(t)
-        if noise is None:
-            self.noise.normal_()
-        else:
-            self.noise.copy_(noise.permute(0, 2, 3, 1))
-
     def _patch_adam(self):
         step = self.step_count + 1
         bc1, bc2 = 1.0 - self.b1 ** step, 1.0 - self.b2 ** step
@@ -124,14 +117,11 @@ class FusedRLStep:
             op.f[7] = 1.0 / self.world
             op.p[4] = ema_ptr if (use_ema and ema_ptr) else None
 
-    def step(self, x_0, t=None, noise=None):
-        """Runs one micro-batch; every `num_iterations`-th call also reduces gradients and applies Adam + EMA.
-        Returns the (device-resident) loss of this micro-batch."""
+    def _run_micro(self):
         p = self.plan
         if self.micro == 0 and self.num_iterations > 1:
-            self.dec.flat_grad.zero_()
-            self.enc.flat_grad.zero_()
-        self.load_batch(x_0, t, noise)
+            for n in self.flat_nets:
+                n.flat_grad.zero_()
         if p.drop_ops:
             p.set_dropout(random.getrandbits(31), self.step_count * self.num_iterations + self.micro)   # host RNG: no device sync
         last = self.micro == self.num_iterations - 1
@@ -149,19 +139,112 @@ class FusedRLStep:
 
     def backward_with_allreduce(self, run):
         """Issues the forward+backward op list in segments; as soon as a bucket's gradients are final its all-reduce(sum) is
-        launched asynchronously (RCCL stream), overlapping with the rest of the backward.  `run(first, last)` issues plan ops."""
+        launched asynchronously (RCCL stream), overlapping with the rest of the backward.  `run(first, last)` issues plan ops.
+        The saturation word travels with the last bucket (MAX) so that every rank takes the same skip decision."""
         works, cur = [], 0
+        ev = self.comm_events
+        if ev is not None:
+            ev["t0"].record()
         for op_idx, view in self.buckets:
             run(cur, op_idx)
             cur = op_idx
             works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         run(cur, self.n_bwd)
+        if ev is not None:
+            ev["bwd_done"].record()
+        if self.guard is not None and self.math_name == "f16x3":
+            works.append(dist.all_reduce(self.guard.t[0:1], op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
         for w in works:
             w.wait()
+        if ev is not None:
+            ev["comm_done"].record()
+
+    def enable_comm_timing(self):
+        """Event triple around one step's backward / collective tail (bench.py: exposed all-reduce time = comm_done - bwd_done)."""
+        self.comm_events = {k: torch.cuda.Event(enable_timing=True) for k in ("t0", "bwd_done", "comm_done")}
+        return self.comm_events
 
     @property
     def last_loss(self):
         return float(self.loss.item())
+
+    # ------------------------------------------------------------------ fp16-window guard
+    def saturation(self):
+        """(saturated launches, optimizer steps discarded) since the last reset -- host sync."""
+        return self.guard.read() if self.guard is not None else (0, 0)
+
+    def handle_saturation(self, log=True):
+        """Polls the guard; if it fired: rewinds the step counter by the discarded steps, switches the process default to "bf16x6",
+        rebuilds this plan and resets the counter.  Returns the number of discarded steps (0 = nothing happened)."""
+        events, skipped = self.saturation()
+        if events == 0:
+            return 0
+        self.step_count -= skipped
+        if log:
+            print(f"[pdae_amd] fp16 window exceeded in {events} convolution launch(es): {skipped} optimizer step(s) discarded, "
+                  "continuing in bf16x6 arithmetic", file=sys.stderr, flush=True)
+        H.set_default_math("bf16x6")
+        for n in self.flat_nets:
+            n.invalidate_plans()
+        self.rebuild("bf16x6")
+        self.guard.reset()
+        return max(skipped, 1)
+
+
+class FusedRLStep(_FusedStep):
+    def __init__(self, gaussian_diffusion, encoder, decoder, ema_encoder, ema_decoder, batch, height, width, lr=1e-4, betas=(0.9, 0.999),
+                 eps=1e-8, weight_decay=0.0, decoupled=False, ema_decay=0.9999, ema_every=1, num_iterations=1, process_group=None,
+                 bucket_mb=48, math=None):
+        self.gd, self.enc, self.dec, self.ema_enc, self.ema_dec = gaussian_diffusion, encoder, decoder, ema_encoder, ema_decoder
+        self.N, self.Hh, self.W = batch, height, width
+        self._init_driver([decoder, encoder], [ema_decoder, ema_encoder], lr, betas, eps, weight_decay, decoupled, ema_decay, ema_every,
+                          num_iterations, process_group, bucket_mb, math)
+
+    def _build(self, math):
+        gd, encoder, decoder = self.gd, self.enc, self.dec
+        cfg = decoder.cfg
+        N, Hh, W, Cimg = self.N, self.Hh, self.W, cfg["input_channel"]
+        per = Hh * W * Cimg
+        acc = self.num_iterations > 1
+        drop = float(cfg["dropout"]) if decoder._shift_train else 0.0
+        p = self.plan
+        self.x0 = p.buf(N, Hh, W, Cimg)
+        self.noise = p.buf(N, Hh, W, Cimg)
+        self.t = p.buf(N, dtype=torch.int64)
+        self.loss = p.buf(1)
+        Be = Builder(p, encoder.P, encoder.grads(), save=True, acc_grads=acc, math=math)
+        Bd = Builder(p, decoder.P, decoder.grads(), save=False, drop_p=drop, acc_grads=acc, math=math, frozen_of=decoder)
+        # ---- forward
+        z, ex = G.encoder_forward(Be, encoder.NAME, self.x0)
+        x_t = p.buf(N, Hh, W, Cimg)
+        p.emit(H.op_q_sample(self.x0, self.noise, self.t, gd.sqrt_alphas_cumprod, gd.sqrt_one_minus_alphas_cumprod, N, per, x_t))
+        fx = G.unet_forward(Bd, cfg, x_t, self.t, decoder.freqs, z=z, shift=True, train_shift=True, dropout=drop > 0)
+        d_shift = p.buf(N, Hh, W, Cimg)
+        p.emit(H.op_loss(self.noise, fx.eps, fx.shift, self.t, gd.shift_coef, gd.weight, N, per, self.loss, None, dg=d_shift,
+                         scale=1.0 / self.num_iterations), ws_slot=9)
+        self.n_fwd = len(p.recs)
+        self.z, self.eps, self.shift = z, fx.eps, fx.shift
+        # ---- backward, with the op index at which each parameter block's gradients are final
+        dz = G.shift_backward(Bd, fx, d_shift, mark=lambda prefix: self._marks.append((len(p.recs), decoder, prefix)))
+        G.encoder_backward(Be, ex, dz)
+
+    def load_batch(self, x_0, t=None, noise=None):
+        """x_0 / noise: (N,C,H,W) tensors of any strides.  t, noise are drawn like the reference
+        (torch.randint then torch.randn_like, gaussian_diffusion.py:240-241) unless injected."""
+        self.x0.copy_(x_0.permute(0, 2, 3, 1))
+        if t is None:
+            t = torch.randint(0, self.gd.timesteps, (self.N,), device=self.x0.device, dtype=torch.long)
+        self.t.copy_(t)
+        if noise is None:
+            self.noise.normal_()
+        else:
+            self.noise.copy_(noise.permute(0, 2, 3, 1))
+
+    def step(self, x_0, t=None, noise=None):
+        """Runs one micro-batch; every `num_iterations`-th call also reduces gradients and applies Adam + EMA.
+        Returns the (device-resident) loss of this micro-batch."""
+        self.load_batch(x_0, t, noise)
+        return self._run_micro()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -190,7 +273,9 @@ def export_adam_state(step_obj, groups, lr, betas, eps, weight_decay):
                           "exp_avg_sq": net._view(step_obj.v[fi], o, net._shapes[k]).clone()}
             ids.append(idx)
             idx += 1
-        param_groups.append({"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "params": ids})
+        # torch.optim.AdamW state dicts carry the same keys as Adam's: `decoupled_weight_decay` (torch >= 2.6 naming) tells them apart
+        param_groups.append({"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False,
+                             "decoupled_weight_decay": bool(step_obj.decoupled), "params": ids})
     return {"state": state, "param_groups": param_groups}
 
 
@@ -209,45 +294,39 @@ def load_adam_state(step_obj, groups, sd):
             idx += 1
 
 
-class FusedRegularStep:
+class FusedRegularStep(_FusedStep):
     """One optimisation step of a plain DDPM UNet (config #1, trainer/train_regular_diffusion.py:59-141 +
     gaussian_diffusion.py:199-211): q_sample -> UNet fwd -> L2 -> full backward -> all-reduce -> Adam -> EMA, one plan."""
 
     def __init__(self, gaussian_diffusion, net, ema_net, batch, height, width, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 decoupled=False, ema_decay=0.9999, process_group=None):
-        gd = gaussian_diffusion
-        self.gd, self.net, self.ema = gd, net, ema_net
-        self.N = batch
-        self.lr, self.b1, self.b2 = lr, betas[0], betas[1]
-        self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.step_count = 0
+                 decoupled=False, ema_decay=0.9999, ema_every=1, num_iterations=1, process_group=None, bucket_mb=48, math=None):
+        self.gd, self.net, self.ema = gaussian_diffusion, net, ema_net
+        self.N, self.Hh, self.W = batch, height, width
+        self._init_driver([net], [ema_net], lr, betas, eps, weight_decay, decoupled, ema_decay, ema_every, num_iterations, process_group,
+                          bucket_mb, math)
+
+    def _build(self, math):
+        gd, net = self.gd, self.net
         cfg = net.cfg
-        N, Hh, W, Cimg = batch, height, width, cfg["input_channel"]
+        N, Hh, W, Cimg = self.N, self.Hh, self.W, cfg["input_channel"]
         per = Hh * W * Cimg
-        p = Plan(net.device)
-        self.plan = p
+        p = self.plan
         self.x0, self.noise = p.buf(N, Hh, W, Cimg), p.buf(N, Hh, W, Cimg)
         self.t = p.buf(N, dtype=torch.int64)
         self.cond = p.buf(N, dtype=torch.int64) if cfg.get("num_class") is not None else None
         self.loss = p.buf(1)
         drop = float(cfg["dropout"])
-        B = Builder(p, net.P, net.grads(), save=True, drop_p=drop)
+        B = Builder(p, net.P, net.grads(), save=True, drop_p=drop, acc_grads=self.num_iterations > 1, math=math)
         x_t = p.buf(N, Hh, W, Cimg)
         p.emit(H.op_q_sample(self.x0, self.noise, self.t, gd.sqrt_alphas_cumprod, gd.sqrt_one_minus_alphas_cumprod, N, per, x_t))
         fx = G.unet_forward(B, cfg, x_t, self.t, net.freqs, cond=self.cond, dropout=drop > 0)
+        self.eps = fx.eps
         d_eps = p.buf(*fx.eps.shape)
-        p.emit(H.op_loss(self.noise, fx.eps, None, None, None, None, N, fx.eps.numel() // N, self.loss, None, deps=d_eps), ws_slot=9)
+        p.emit(H.op_loss(self.noise, fx.eps, None, None, None, None, N, fx.eps.numel() // N, self.loss, None, deps=d_eps,
+                         scale=1.0 / self.num_iterations), ws_slot=9)
         G.unet_backward(B, fx, d_eps)
-        self.n_bwd = len(p.recs)
-        self.m, self.v = [torch.zeros_like(net.flat_train)], [torch.zeros_like(net.flat_train)]
-        self.flat_nets = [net]
-        self.adam_idx = p.emit(H.op_adam_ema(net.flat_train, net.flat_grad, self.m[0], self.v[0], ema_net.flat_train if ema_net is not None else None,
-                                             net.flat_train.numel(), lr, self.b1, self.b2, eps, weight_decay, int(decoupled), lr, 1.0, 1.0, ema_decay))
-        p.compile()
 
     def step(self, x_0, condition=None, t=None, noise=None):
-        p = self.plan
         self.x0.copy_(x_0.permute(0, 2, 3, 1))
         self.t.copy_(torch.randint(0, self.gd.timesteps, (self.N,), device=self.x0.device, dtype=torch.long) if t is None else t)
         if noise is None:
@@ -256,72 +335,43 @@ class FusedRegularStep:
             self.noise.copy_(noise.permute(0, 2, 3, 1))
         if self.cond is not None:
             self.cond.copy_(condition)
-        if p.drop_ops:
-            p.set_dropout(random.getrandbits(31), self.step_count)
-        p.run(0, self.n_bwd)
-        if self.world > 1:
-            dist.all_reduce(self.net.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-        step = self.step_count + 1
-        op = p.arr[self.adam_idx]
-        op.f[5] = self.lr / (1.0 - self.b1 ** step)
-        op.f[6] = 1.0 / math.sqrt(1.0 - self.b2 ** step)
-        op.f[7] = 1.0 / self.world
-        p.run(self.n_bwd, p.n)
-        self.step_count = step
-        return self.loss
+        return self._run_micro()
 
 
-class FusedLatentStep:
+class FusedLatentStep(_FusedStep):
     """One optimisation step of the latent DPM (config #5, trainer/train_latent_diffusion.py:95-178 +
     gaussian_diffusion.py:373-398): q_sample on the latent schedule (constant beta 0.008) -> MLPSkipNet fwd -> L1 ->
     backward -> all-reduce -> Adam / AdamW -> EMA, one plan.  `z_0` is the already normalised latent."""
 
     def __init__(self, gaussian_diffusion, net, ema_net, batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, decoupled=True,
-                 ema_decay=0.9999, process_group=None):
-        gd = gaussian_diffusion
-        lcfg = gd.latent_diffusion_config
-        self.gd, self.net, self.ema = gd, net, ema_net
-        self.N, self.timesteps = batch, lcfg["timesteps"]
-        self.lr, self.b1, self.b2 = lr, betas[0], betas[1]
-        self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.step_count = 0
+                 ema_decay=0.9999, ema_every=1, num_iterations=1, process_group=None, bucket_mb=48, math=None):
+        self.gd, self.net, self.ema = gaussian_diffusion, net, ema_net
+        self.N, self.timesteps = batch, gaussian_diffusion.latent_diffusion_config["timesteps"]
+        self._init_driver([net], [ema_net], lr, betas, eps, weight_decay, decoupled, ema_decay, ema_every, num_iterations, process_group,
+                          bucket_mb, math)
+
+    def _build(self, math):
+        net, batch = self.net, self.N
+        lcfg = self.gd.latent_diffusion_config
         ic = net.cfg["input_channel"]
-        p = Plan(net.device)
-        self.plan = p
+        p = self.plan
         self.z0, self.noise = p.buf(batch, ic), p.buf(batch, ic)
         self.t = p.buf(batch, dtype=torch.int64)
         self.loss = p.buf(1)
-        B = Builder(p, net.P, net.grads(), save=True)
+        B = Builder(p, net.P, net.grads(), save=True, acc_grads=self.num_iterations > 1, math=math)
         z_t = p.buf(batch, ic)
         p.emit(H.op_q_sample(self.z0, self.noise, self.t, lcfg["sqrt_alphas_cumprod"], lcfg["sqrt_one_minus_alphas_cumprod"], batch, ic, z_t))
         fx = net._emit_forward(B, z_t, self.t)
         d_out = p.buf(batch, ic)
-        p.emit(H.op_loss(self.noise, fx.out, None, None, None, None, batch, ic, self.loss, None, deps=d_out, l1=1), ws_slot=9)
+        p.emit(H.op_loss(self.noise, fx.out, None, None, None, None, batch, ic, self.loss, None, deps=d_out, l1=1,
+                         scale=1.0 / self.num_iterations), ws_slot=9)
         net._emit_backward(B, fx, d_out)
-        self.n_bwd = len(p.recs)
-        self.m, self.v = [torch.zeros_like(net.flat_train)], [torch.zeros_like(net.flat_train)]
-        self.flat_nets = [net]
-        self.adam_idx = p.emit(H.op_adam_ema(net.flat_train, net.flat_grad, self.m[0], self.v[0], ema_net.flat_train if ema_net is not None else None,
-                                             net.flat_train.numel(), lr, self.b1, self.b2, eps, weight_decay, int(decoupled), lr, 1.0, 1.0, ema_decay))
-        p.compile()
 
     def step(self, z_0, t=None, noise=None):
-        p = self.plan
         self.z0.copy_(z_0)
         self.t.copy_(torch.randint(0, self.timesteps, (self.N,), device=self.z0.device, dtype=torch.long) if t is None else t)
         if noise is None:
             self.noise.normal_()
         else:
             self.noise.copy_(noise)
-        p.run(0, self.n_bwd)
-        if self.world > 1:
-            dist.all_reduce(self.net.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
-        step = self.step_count + 1
-        op = p.arr[self.adam_idx]
-        op.f[5] = self.lr / (1.0 - self.b1 ** step)
-        op.f[6] = 1.0 / math.sqrt(1.0 - self.b2 ** step)
-        op.f[7] = 1.0 / self.world
-        p.run(self.n_bwd, p.n)
-        self.step_count = step
-        return self.loss
+        return self._run_micro()

@@ -43,8 +43,10 @@ class LatentDiffusionTrainer(_LoopMixin):
             data = torch.load(ck, map_location=torch.device("cpu"))
             self.encoder.load_state_dict(data["ema_encoder"])
             self.decoder.load_state_dict(data["ema_decoder"])
+        elif not self.allow_random_init:                  # the reference fails in torch.load (train_latent_diffusion.py:44)
+            raise FileNotFoundError(f"autoencoder checkpoint {ck!r} not found (pass --allow_random_init for synthetic benchmarking runs)")
         elif self.global_rank == 0:
-            print(f"rank0: autoencoder checkpoint {ck!r} not found -- encoder / decoder keep their random initialisation", flush=True)
+            print(f"rank0: autoencoder checkpoint {ck!r} not found -- --allow_random_init: encoder / decoder keep their random initialisation", flush=True)
         for m in (self.encoder, self.decoder):
             m.eval(); m.requires_grad_(False)
         # latent statistics (:57-61); N(0,1) stand-in when the inferred-latents file is absent
@@ -53,6 +55,8 @@ class LatentDiffusionTrainer(_LoopMixin):
         if lat and os.path.exists(lat):
             st = torch.load(lat, map_location=torch.device("cpu"))
             self.latents_mean, self.latents_std = st["mean"].to(self.device), st["std"].to(self.device)
+        elif not self.allow_random_init:
+            raise FileNotFoundError(f"inferred latents {lat!r} not found (pass --allow_random_init to train on N(0,1) stand-in statistics)")
         else:
             self.latents_mean, self.latents_std = torch.zeros(d, device=self.device), torch.ones(d, device=self.device)
         oc = c["optimizer_config"]
@@ -61,7 +65,9 @@ class LatentDiffusionTrainer(_LoopMixin):
             raise NotImplementedError(name)                                      # train_latent_diffusion.py:93
         self.opt = self._opt_kwargs()
         self.fused = FusedLatentStep(self.gaussian_diffusion, self.latent_denoise_fn, self.ema_latent_denoise_fn, self.batch_size,
-                                     decoupled=(name == "AdamW"), ema_decay=float(c["runner_config"]["ema_decay"]), **self.opt)
+                                     decoupled=(name == "AdamW"), ema_decay=float(c["runner_config"]["ema_decay"]),
+                                     ema_every=int(c["runner_config"].get("ema_every", 1)), num_iterations=int(c["runner_config"].get("num_iterations", 1)),
+                                     **self.opt)
         if args.resume:
             self.load(args.resume)
         set_seed(self.global_rank)

@@ -28,6 +28,7 @@ class _LoopMixin:
         set_seed(0)                                      # identical initialisation on every rank (base_trainer.py:27-28)
         self.config = load_yaml(args.config_path)
         self.run_path, self.max_steps, self.step = args.run_path, args.max_steps, 0
+        self.allow_random_init = bool(getattr(args, "allow_random_init", False))
         if self.global_rank == 0:
             os.makedirs(os.path.join(self.run_path, "checkpoints"), exist_ok=True)
             save_yaml(os.path.join(self.run_path, "config.yml"), self.config)
@@ -43,10 +44,15 @@ class _LoopMixin:
         display = int(rc["display_steps"])
         acc = torch.zeros(1, device=self.device)
         t_top = time.time()
+        n_it = int(rc.get("num_iterations", 1))
         while self.max_steps is None or self.step < self.max_steps:
-            acc += one_step()
+            for _ in range(n_it):                        # micro-batches of one optimizer step (train_regular_diffusion.py:82-110)
+                acc += one_step()
             self.step += 1
             if self.step % display == 0:
+                lost = self.fused.handle_saturation()    # fp16-window guard: discarded steps are re-counted, plan -> bf16x6
+                if lost:
+                    self.step -= lost
                 loss = float(acc.item()) / display
                 if torch.distributed.is_initialized():
                     t = torch.tensor([loss], device=self.device)
@@ -55,7 +61,7 @@ class _LoopMixin:
                 if self.global_rank == 0:
                     dt = time.time() - t_top
                     rec = {"step": self.step, "prediction_loss": loss, "secs": round(dt, 2),
-                           "samples_per_sec": round(display * samples_per_step * self.global_world_size / dt, 2)}
+                           "samples_per_sec": round(display * n_it * samples_per_step * self.global_world_size / dt, 2)}
                     print(json.dumps(rec), flush=True)
                     with open(os.path.join(self.run_path, "log.jsonl"), "a") as f:
                         f.write(json.dumps(rec) + "\n")
@@ -82,7 +88,8 @@ class RegularDiffusionTrainer(_LoopMixin):
         self.opt = self._opt_kwargs()
         size = c["train_dataset_config"]["image_size"]
         self.fused = FusedRegularStep(self.gaussian_diffusion, self.denoise_fn, self.ema_denoise_fn, self.batch_size, size, size,
-                                      ema_decay=float(c["runner_config"]["ema_decay"]), **self.opt)
+                                      ema_decay=float(c["runner_config"]["ema_decay"]), ema_every=int(c["runner_config"].get("ema_every", 1)),
+                                      num_iterations=int(c["runner_config"].get("num_iterations", 1)), **self.opt)
         if args.resume:
             self.load(args.resume)
         set_seed(self.global_rank)
@@ -114,6 +121,8 @@ def _parser():
     parser.add_argument("--run_path", type=str, required=True)
     parser.add_argument("--resume", type=str, default="", help="resume from checkpoint")
     parser.add_argument("--max_steps", type=int, default=None, help="stop after this many optimizer steps (the reference loops forever)")
+    parser.add_argument("--allow_random_init", action="store_true", help="continue with randomly initialised frozen networks / N(0,1) latent "
+                        "statistics when a pre-trained file is absent (synthetic benchmarking only; default: fail like the reference's torch.load)")
     return parser
 
 

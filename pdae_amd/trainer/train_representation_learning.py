@@ -30,6 +30,7 @@ class RepresentationLearningTrainer:
         self.config = load_yaml(args.config_path)
         self.run_path = args.run_path
         self.max_steps = args.max_steps
+        self.allow_random_init = bool(getattr(args, "allow_random_init", False))
         self.step = 0
         if self.global_rank == 0:
             os.makedirs(os.path.join(self.run_path, "checkpoints"), exist_ok=True)
@@ -62,8 +63,12 @@ class RepresentationLearningTrainer:
         ck = c.get("trained_ddpm_checkpoint")
         if ck and os.path.exists(ck):
             self.load_trained_ddpm(ck)
+        elif not self.allow_random_init:
+            # the reference fails in torch.load (train_representation_learning.py:241): training the shift branch against a random trunk
+            # produces checkpoints that look valid and mean nothing
+            raise FileNotFoundError(f"pre-trained DPM checkpoint {ck!r} not found (pass --allow_random_init for synthetic benchmarking runs)")
         elif self.global_rank == 0:
-            print(f"rank0: pre-trained DPM checkpoint {ck!r} not found -- the frozen half keeps its random initialisation", flush=True)
+            print(f"rank0: pre-trained DPM checkpoint {ck!r} not found -- --allow_random_init: the frozen half keeps its random initialisation", flush=True)
         for m in (self.ema_encoder, self.ema_decoder):
             m.eval()
             m.requires_grad_(False)
@@ -101,6 +106,9 @@ class RepresentationLearningTrainer:
                 acc += self.fused.step(batch["x_0"])                    # device-side accumulation: no per-step host sync
             self.step += 1
             if self.step % display == 0:
+                lost = self.fused.handle_saturation()                  # fp16-window guard: discarded steps are re-counted, plan -> bf16x6
+                if lost:
+                    self.step -= lost
                 loss = float(acc.item()) / display
                 if torch.distributed.is_initialized():
                     t = torch.tensor([loss], device=self.device)
@@ -164,5 +172,7 @@ if __name__ == "__main__":
     parser.add_argument("--run_path", type=str, required=True)
     parser.add_argument("--resume", type=str, default="", help="resume from checkpoint")
     parser.add_argument("--max_steps", type=int, default=None, help="stop after this many optimizer steps (the reference loops forever)")
+    parser.add_argument("--allow_random_init", action="store_true", help="train against a randomly initialised frozen trunk when the pre-trained "
+                        "DPM checkpoint is absent (synthetic benchmarking only; default: fail like the reference's torch.load)")
     runner = RepresentationLearningTrainer(parser.parse_args())
     runner.train()

@@ -15,7 +15,7 @@ def _help(args):
 
 def test_bench_cli_parses():
     out = _help(["bench.py"])
-    for flag in ("--gpus", "--steps", "--warmup", "--math", "--ddim-batch", "--no-cpu-baseline"):
+    for flag in ("--gpus", "--steps", "--warmup", "--math", "--ddim-batch", "--no-cpu-baseline", "--bucket-mb", "--dry"):
         assert flag in out
 
 
@@ -31,3 +31,30 @@ def test_bench_flop_model_matches_survey():
     import bench
     assert abs(bench.TRAIN_GFLOP_PER_IMG - 481.4) < 1.0 and abs(bench.FWD_GFLOP_PER_IMG - 258.4) < 1.0
     assert bench.MFMA_PER_PRODUCT["f16x3"] == 3 and bench.MFMA_PER_PRODUCT["bf16x6"] == 6
+
+
+def test_bench_self_launches_two_ranks_dry():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver may call it): bench.py re-execs itself under torch.distributed.run,
+    one rank per GPU; --dry swaps RCCL for gloo and the kernels for a recorder so that the whole path -- launcher, process group, bucketed
+    all-reduce, bucket sweep, max-over-ranks timing, ONE JSON line from rank 0 -- runs in this container."""
+    import json
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry"] is True and out["steps"] == 2 and out["scaling"] == "weak"
+    c = out["comm"]
+    assert c["rccl_ranks"] == 2 and c["buckets"] >= 2 and sum(c["bucket_bytes"]) == c["grad_bytes_per_step"]
+    assert set(c["bucket_sweep_ms_per_step"]) == {"16", "48", "96"}
+    assert out["config"]["global_batch"] == 2 * out["config"]["per_gpu_batch"]
+
+
+def test_bench_workload_comes_from_the_yaml_files():
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg, ddpm = bench.load_workload()
+    assert cfg["dataloader_config"]["train"]["batch_size"] == 32 and cfg["train_dataset_config"]["image_size"] == 128
+    assert ddpm["base_channel"] == 128 and ddpm["channel_multiplier"] == [1, 1, 2, 3, 4]
+    assert "FFHQ128 = dict" not in open(os.path.join(ROOT, "bench.py")).read()

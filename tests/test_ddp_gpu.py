@@ -60,6 +60,8 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch(monkeypatch):
     calls = []
 
     def fake_all_reduce(view, op=None, group=None, async_op=False):
+        if view.dtype == torch.int32:              # the fp16-window guard word travels with the last bucket (MAX): nothing to add here
+            return _Work()
         for mine, other in ((dec0.flat_grad, dec1.flat_grad), (enc0.flat_grad, enc1.flat_grad)):
             off = (view.data_ptr() - mine.data_ptr()) // 4
             if 0 <= off and off + view.numel() <= mine.numel() and view.data_ptr() >= mine.data_ptr():

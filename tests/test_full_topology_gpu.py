@@ -1,0 +1,206 @@
+"""GPU: every BASELINE.json configuration at its REAL topology -- networks built from the shipped YAMLs with no size override --
+through the fused-step / planned-network HIP path against the CPU oracle computed on this box from the same seeded weights.
+
+  F128  config/ffhq_representation_learning.yml  + pre-trained-dpms/ffhq128/config.yml   (base 128, [1,1,2,3,4], 128x128, FFHQEncoder)
+  C64   config/celeba64_representation_learning.yml + pre-trained-dpms/celeba64/config.yml (base 64, [1,2,4,8], 64x64), fp32 and bf16 (enable_amp)
+  M32   config/mnist_regular.yml                                                          (base 64, [1,2,2,4], 1x32x32, B=16)
+
+Gates (north_star): z / eps / shift / loss within 1e-4 relative, every trainable gradient within 1e-3 in norm, DDIM x_0 PSNR stated
+below; the fp16-window counter must stay zero.  The per-GPU batch of the benchmark (B=32) is covered by a size-independent property:
+16 copies of the B=2 batch give the same mean loss and the same mean gradient.  Dropout is switched off (it is not a size; RNG streams cannot
+match across devices)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import ROOT, rel_err
+from oracle import pdae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF16_TOL = dict(out=5e-2, loss=3e-2, grad=1e-1)       # enable_amp: bf16 operands (2^-9 per product), fp32 accumulate -- vs the fp32-grade path
+
+
+def _yaml(path):
+    from pdae_amd.utils import load_yaml
+    return load_yaml(os.path.join(ROOT, path))
+
+
+def _rl_setup(cfg_file, seed_enc=1, seed_dec=2):
+    """(config, denoise_fn cfg with dropout 0, encoder name, encoder / decoder state dicts, HIP encoder, HIP decoder)."""
+    from pdae_amd.model.representation_learning import decoder as decoder_module, encoder as encoder_module
+    c = _yaml(cfg_file)
+    dcfg = dict(_yaml(c["trained_ddpm_config"])["denoise_fn_config"], dropout=0.0)
+    ename, latent = c["encoder_config"]["model"], c["encoder_config"]["latent_dim"]
+    enc_sd = O.synth_state_dict(O.encoder_param_shapes(ename, latent), seed_enc)
+    dec_sd = O.synth_state_dict(O.unet_param_shapes(dcfg, shift=True, latent_dim=latent), seed_dec)
+    enc = getattr(encoder_module, ename)(device=DEV, **c["encoder_config"])
+    dec = getattr(decoder_module, c["decoder_config"]["model"])(device=DEV, latent_dim=c["decoder_config"]["latent_dim"], **dcfg)
+    enc.load_state_dict(enc_sd)
+    dec.load_state_dict(dec_sd)
+    enc.train()
+    dec.set_train_mode()
+    return c, dcfg, ename, enc_sd, dec_sd, enc, dec
+
+
+def _batch(B, ch, size, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x0 = torch.rand(B, ch, size, size, generator=g) * 2 - 1
+    t = torch.tensor([100, 900] + [int(v) for v in torch.randint(0, 1000, (max(B - 2, 0),), generator=g)])[:B]
+    noise = torch.randn(B, ch, size, size, generator=g)
+    return x0, t, noise
+
+
+def _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise):
+    """z, eps, shift, loss and every trainable gradient of gaussian_diffusion.py:234-255 on the CPU."""
+    s = O.Schedules()
+    train = {"enc::" + k: v for k, v in enc_sd.items()}
+    train.update({"dec::" + k: v for k, v in dec_sd.items() if O.shift_unet_trainable(k)})
+    for v in train.values():
+        v.requires_grad_(True)
+    z = O.encoder_forward(enc_sd, ename, x0)
+    eps, shift = O.shift_unet_forward(dec_sd, dcfg, O.q_sample(s, x0, t, noise), t, z)
+    loss = O.p_loss(noise, eps + O._at(s.shift_coef, t, x0) * shift, weight=O._at(s.weight, t, x0))
+    loss.backward()
+    grads = {k: v.grad.detach() for k, v in train.items()}
+    for v in train.values():
+        v.requires_grad_(False)
+        v.grad = None
+    return z.detach(), eps.detach(), shift.detach(), float(loss), grads
+
+
+def _check_grads(got, ref, tol):
+    floor = 1e-6 * max(float(v.double().norm()) for v in ref.values())
+    bad = []
+    for k, r in ref.items():
+        rn = float(r.double().norm())
+        err = float((got[k].detach().double().cpu() - r.double()).norm())
+        if err > tol * rn + floor:
+            bad.append((k, err / max(rn, 1e-30)))
+    assert not bad, (len(bad), sorted(bad, key=lambda b: -b[1])[:6])
+
+
+def _run_rl(gd, enc, dec, B, size, x0, t, noise, math=None):
+    from pdae_amd.trainer.fused_step import FusedRLStep
+    st = FusedRLStep(gd, enc, dec, None, None, B, size, size, math=math)
+    st.load_batch(x0.to(DEV), t.to(DEV), noise.to(DEV))
+    st.plan.run(0, st.n_bwd)
+    torch.cuda.synchronize()
+    grads = {"enc::" + k: v.clone() for k, v in enc.grads().items()}
+    grads.update({"dec::" + k: v.clone() for k, v in dec.grads().items()})
+    out = dict(z=st.z.clone(), eps=st.eps.permute(0, 3, 1, 2).clone(), shift=st.shift.permute(0, 3, 1, 2).clone(), loss=float(st.loss.item()), grads=grads)
+    return st, out
+
+
+@pytest.fixture(scope="module")
+def gd():
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    return GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device(DEV))
+
+
+def _guard():
+    from pdae_amd import hip as H
+    g = H.SaturationGuard.get(DEV)
+    return g
+
+
+def test_f128_train_step_full_topology_vs_oracle(gd):
+    c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml")
+    assert dcfg["base_channel"] == 128 and dcfg["channel_multiplier"] == [1, 1, 2, 3, 4] and c["train_dataset_config"]["image_size"] == 128
+    n_dec, n_enc = sum(p.numel() for p in dec.P.values()), sum(p.numel() for p in enc.P.values())
+    assert abs(n_dec - 177.14e6) < 0.01e6 and abs(n_enc - 3.91e6) < 0.01e6, (n_dec, n_enc)
+    x0, t, noise = _batch(2, 3, 128)
+    _guard().reset()
+    st, got = _run_rl(gd, enc, dec, 2, 128, x0, t, noise)
+    assert _guard().read()[0] == 0, "fp16 window exceeded on N(0, 1/fan_in) weights"
+    z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise)
+    assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
+    assert abs(got["loss"] - loss) < 1e-4 * abs(loss), (got["loss"], loss)
+    assert set(got["grads"]) == set(grads) and len(grads) > 300
+    _check_grads(got["grads"], grads, 1e-3)
+    # the benchmark's per-GPU batch (B = 32: other split-K plans, image-pair tiles with 16 pairs): 16 copies of the batch above give the
+    # same mean loss and mean gradients
+    del st
+    rep = lambda a: a.repeat(16, *([1] * (a.dim() - 1)))
+    st32, got32 = _run_rl(gd, enc, dec, 32, 128, rep(x0), rep(t), rep(noise))
+    assert _guard().read()[0] == 0
+    assert abs(got32["loss"] - got["loss"]) < 1e-5 * abs(got["loss"])
+    assert rel_err(got32["eps"][:2], got["eps"]) < 1e-5 and rel_err(got32["shift"][30:], got["shift"]) < 1e-5
+    _check_grads(got32["grads"], {k: v.cpu() for k, v in got["grads"].items()}, 2e-4)
+
+
+def test_f128_ddim10_encode_sample_psnr_vs_oracle(gd):
+    """ddim5 encode + ddim5 decode (10 decoder passes) at 128x128, B=1: PSNR vs the oracle trajectory > 60 dB on [-1,1] images (stated)."""
+    c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml")
+    dec.set_eval_mode()
+    x0 = _batch(1, 3, 128, seed=3)[0]
+    s = O.Schedules()
+    with torch.no_grad():
+        z = O.encoder_forward(enc_sd, ename, x0)
+        xT_ref = O.shift_ddim_encode_loop(s, "ddim5", dec_sd, dcfg, z, x0)
+        rec_ref = O.shift_ddim_sample_loop(s, "ddim5", dec_sd, dcfg, z, xT_ref)
+        _guard().reset()
+        xT = gd.representation_learning_ddim_encode("ddim5", enc, dec, x0.to(DEV))
+        rec = gd.representation_learning_ddim_sample("ddim5", None, dec, None, xT, enc(x0.to(DEV)))
+    assert _guard().read()[0] == 0
+
+    def psnr(a, b):
+        return 10 * math.log10(4.0 / float(((a.double().cpu() - b.double()) ** 2).mean()))
+    assert psnr(xT, xT_ref) > 60 and psnr(rec, rec_ref) > 60, (psnr(xT, xT_ref), psnr(rec, rec_ref))
+
+
+def test_c64_train_step_full_topology_fp32_and_bf16(gd):
+    c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/celeba64_representation_learning.yml")
+    assert dcfg["base_channel"] == 64 and dcfg["channel_multiplier"] == [1, 2, 4, 8] and c["train_dataset_config"]["image_size"] == 64
+    x0, t, noise = _batch(2, 3, 64, seed=1)
+    _guard().reset()
+    st, got = _run_rl(gd, enc, dec, 2, 64, x0, t, noise)
+    assert _guard().read()[0] == 0
+    z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise)
+    assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
+    assert abs(got["loss"] - loss) < 1e-4 * abs(loss)
+    _check_grads(got["grads"], grads, 1e-3)
+    # BASELINE config #2 runs in bf16 (optimizer_config.enable_amp -> math "bf16": bf16 operands, fp32 accumulate).  The reference has no
+    # bf16 numerics of its own: the stated tolerance is against the fp32-grade path on the same net.
+    del st
+    st16, got16 = _run_rl(gd, enc, dec, 2, 64, x0, t, noise, math="bf16")
+    e = dict(eps=rel_err(got16["eps"], got["eps"]), shift=rel_err(got16["shift"], got["shift"]), z=rel_err(got16["z"], got["z"]),
+             loss=abs(got16["loss"] - got["loss"]) / abs(got["loss"]))
+    gn = max(float((got16["grads"][k].double() - v.double()).norm() / (v.double().norm() + 1e-30)) for k, v in got["grads"].items()
+             if float(v.double().norm()) > 1e-6 * max(float(u.double().norm()) for u in got["grads"].values()))
+    print(f"[bf16 vs fp32-grade, C64 full topology] {e} worst gradient norm error {gn:.3e}")
+    assert e["eps"] < BF16_TOL["out"] and e["shift"] < BF16_TOL["out"] and e["z"] < BF16_TOL["out"] and e["loss"] < BF16_TOL["loss"], e
+    assert gn < BF16_TOL["grad"], gn
+
+
+def test_m32_regular_step_full_topology_vs_oracle(gd):
+    from pdae_amd.model import denoise_fn as denoise_fn_module
+    from pdae_amd.trainer.fused_step import FusedRegularStep
+    c = _yaml("config/mnist_regular.yml")
+    cfg = {k: v for k, v in c["denoise_fn_config"].items() if k not in ("model", "dims")}
+    assert cfg["base_channel"] == 64 and cfg["channel_multiplier"] == [1, 2, 2, 4] and c["train_dataset_config"]["image_size"] == 32
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg), 5)
+    net = getattr(denoise_fn_module, c["denoise_fn_config"]["model"])(device=DEV, **c["denoise_fn_config"])
+    net.load_state_dict(sd)
+    net.train()
+    B = 16                                             # BASELINE.json configs[0]: batch 16
+    x0, t, noise = _batch(B, 1, 32, seed=2)
+    _guard().reset()
+    st = FusedRegularStep(gd, net, None, B, 32, 32)
+    st.x0.copy_(x0.to(DEV).permute(0, 2, 3, 1)); st.t.copy_(t.to(DEV)); st.noise.copy_(noise.to(DEV).permute(0, 2, 3, 1))
+    st.plan.run(0, st.n_bwd)
+    torch.cuda.synchronize()
+    assert _guard().read()[0] == 0
+    for v in sd.values():
+        v.requires_grad_(True)
+    s = O.Schedules()
+    eps = O.unet_forward(sd, cfg, O.q_sample(s, x0, t, noise), t)
+    loss = O.p_loss(noise, eps)
+    loss.backward()
+    assert rel_err(st.eps.permute(0, 3, 1, 2), eps.detach()) < 1e-4
+    assert abs(float(st.loss.item()) - float(loss)) < 1e-4 * abs(float(loss))
+    _check_grads(net.grads(), {k: v.grad for k, v in sd.items()}, 1e-3)
+    assert abs(sum(p.numel() for p in net.P.values()) - 19.4e6) < 0.1e6                                         # 19.4 M

@@ -264,3 +264,33 @@ def test_frozen_prepared_weights_follow_parameter_reloads():
         net.load_state_dict(sd)                                    # same plan, new frozen weights
         eps, shift = net(x, t, z)
     assert rel_err(eps, g["eps"]) < 1e-4 and rel_err(shift, g["shift"]) < 1e-4
+
+
+def test_autograd_bridge_accumulates_like_torch_and_guards_stale_activations():
+    """loss.backward() called for several micro-batches between zero_grad() and step() (runner_config.num_iterations > 1) must
+    SUM the gradients; optimizer.zero_grad() of a torch optimizer (.grad = None) must restart from zero; a backward whose activations were
+    overwritten by a later forward must raise instead of returning a wrong gradient."""
+    from pdae_amd.model.unet import UNet
+    cfg = C.CFG_UNET_B
+    net = load_into(UNet(device=DEV, **cfg), O.synth_state_dict(O.unet_param_shapes(cfg), 3))
+    net.train()
+    g = torch.Generator().manual_seed(0)
+    xs = [torch.randn(2, 1, 16, 16, generator=g).to(DEV) for _ in range(2)]
+    t = torch.tensor([10, 500], device=DEV)
+
+    def grad_of(batches):
+        opt = torch.optim.SGD(net.parameters(), lr=0.0)
+        opt.zero_grad()                                  # set_to_none=True: every .grad becomes None
+        for x in batches:
+            net(x, t).pow(2).mean().backward()
+        assert all(p.grad is not None for p in net.parameters())
+        return net.flat_grad.clone()
+
+    g0, g1 = grad_of(xs[:1]), grad_of(xs[1:])
+    both = grad_of(xs)
+    assert float((both - (g0 + g1)).norm() / both.norm()) < 1e-5
+    assert float((grad_of(xs[:1]) - g0).norm()) == 0.0   # zero_grad really restarted the sum
+    y_old = net(xs[0], t)
+    net(xs[1], t)                                        # overwrites the plan's saved activations
+    with pytest.raises(RuntimeError, match="overwritten"):
+        y_old.sum().backward()

@@ -142,3 +142,37 @@ def test_encoder_ffhq_mlp_metrics():
         assert rel_err(O.mlp_skip_net_forward(sd, C.CFG_MLP, T(g["mlp_z"]), T(g["mlp_t"])), g["mlp_out"]) < TOL
     assert np.allclose(O.ssim(T(g["m_a"]), T(g["m_b"])).numpy(), g["ssim"], atol=1e-6)
     assert np.allclose(O.mse(T(g["m_a"]), T(g["m_b"])).numpy(), g["mse"], rtol=1e-6)
+
+
+def test_f3_front_ends_vs_reference():
+    """The remaining GaussianDiffusion / DDIM front-ends restated in the oracle vs vectors emitted by the reference
+    with its internal noise draws replaced by f3_noise (tests/golden/make_fixtures_f3.py)."""
+    from tests.golden.make_fixtures_cfg import CFG_SHIFT_T, CFG_UNET_SIGMA, F3_T, f3_noise
+    g = load_golden("f3")
+    s = O.Schedules(F3_T)
+    x_t, x_0, eps, vr, t = T(g["a_x_t"]), T(g["a_x_0"]), T(g["a_eps"]), T(g["a_vr"]), T(g["a_t"])
+    assert rel_err(O.q_posterior_mean(s, x_0, x_t, t), g["a_post_mean"]) < 1e-6
+    assert rel_err(O.predicted_x_0(s, x_t, t, eps), g["a_pred_x0"]) < 1e-6
+    assert rel_err(O.noise_p_sample_mean(s, x_t, t, eps), g["a_pred_mean"]) < 1e-6
+    assert rel_err(O.learned_range_to_log_variance(s, vr, t), g["a_logvar"]) < 1e-6
+    n0 = T(f3_noise(0, 0, tuple(x_t.shape)))
+    assert rel_err(O.noise_p_sample(s, x_t, t, eps, n0), g["a_step_fixed"]) < 1e-6
+    assert rel_err(O.noise_p_sample(s, x_t, t, eps, n0, vr), g["a_step_learned"]) < 1e-6
+    xT = T(g["b_x_T"])
+    shp = tuple(xT.shape)
+    sd = O.synth_state_dict(O.unet_param_shapes(CFG_UNET_SIGMA), int(g["seed_unet"]))
+    with torch.no_grad():
+        out = O.regular_ddpm_sample(s, lambda x, tt: O.unet_forward(sd, CFG_UNET_SIGMA, x, tt), xT, lambda i: T(f3_noise(1, i, shp)))
+    assert rel_err(out, g["b_sample"]) < 1e-4
+    dsd = O.synth_state_dict(O.unet_param_shapes(CFG_SHIFT_T, shift=True, latent_dim=int(g["latent"])), int(g["seed_dec"]))
+    z, z2, x0 = T(g["c_z"]), T(g["c_z2"]), T(g["c_x0"])
+    with torch.no_grad():
+        assert rel_err(O.rl_ddpm_sample(s, dsd, CFG_SHIFT_T, z, xT, lambda i: T(f3_noise(2, i, shp))), g["c_ddpm"]) < 1e-4
+        gp, ga = O.rl_gap_measure(s, dsd, CFG_SHIFT_T, z, x0, lambda i: T(f3_noise(3, i, shp, uniform=True)))
+        assert np.allclose(gp, g["c_gap_p"], rtol=1e-4, atol=1e-9) and np.allclose(ga, g["c_gap_a"], rtol=1e-4, atol=1e-9)
+        tl = T(g["c_tl"])
+        a, b = O.rl_two_x_0(s, dsd, CFG_SHIFT_T, z, O.q_sample(s, x0, tl, T(f3_noise(4, 0, shp))), tl)
+        assert rel_err(a, g["c_one_p"]) < 1e-5 and rel_err(b, g["c_one_a"]) < 1e-5
+        assert rel_err(O.shift_ddim_trajectory_interpolation(s, "ddim10", dsd, CFG_SHIFT_T, z, z2, xT, 0.3), g["c_traj"]) < 1e-4
+        zm = O.manipulated_latent(z, T(g["c_cw"]), 3, 0.25, T(g["c_mean"]), T(g["c_std"]))
+        assert rel_err(O.shift_ddim_sample_loop(s, "ddim10", dsd, CFG_SHIFT_T, zm, xT), g["c_man"]) < 1e-4

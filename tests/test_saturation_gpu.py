@@ -1,0 +1,146 @@
+"""GPU: the fp16-window guard of the default "f16x3" arithmetic (include/pdae_hip.h: pdae_set_saturation_counter).
+
+The two-fp16-plane format needs |scaled operand| <= 65504.  These tests
+  * stress a network towards the edge of the window (AdaGN output ~1e3, residual stream ~1e2) and require f16x3 == bf16x6 within 1e-4
+    with the counter at zero,
+  * push it over the edge and require: the counter fires, the optimizer kernel refuses the step on the device (parameters, moments, EMA
+    bit-unchanged), handle_saturation() rewinds the step count and rebuilds in bf16x6, and the recovered step equals a run that used
+    bf16x6 from the start,
+  * check that NaN / Inf inputs are no longer laundered into finite numbers by a convolution."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import rel_err
+from tests.golden import make_fixtures_cfg as C
+from oracle import pdae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CFG = dict(C.CFG_SHIFT_64, dropout=0.0)
+
+
+def _nets(gamma_scale):
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
+    enc_sd = O.synth_state_dict(O.encoder_param_shapes("CELEBA64Encoder", 512), 31)
+    dec_sd = O.synth_state_dict(O.unet_param_shapes(CFG, shift=True, latent_dim=512), 32)
+    for k in dec_sd:                          # GroupNorm affine in front of every second conv: post-AdaGN activations scale with it
+        if k.endswith("out_layers.0.weight") or k.endswith("out_layers.0.bias"):
+            dec_sd[k] = dec_sd[k] * gamma_scale
+    enc = CELEBA64Encoder(device=DEV, latent_dim=512)
+    dec = ShiftUNet(device=DEV, latent_dim=512, **CFG)
+    enc.load_state_dict(enc_sd)
+    dec.load_state_dict(dec_sd)
+    enc.train()
+    dec.set_train_mode()
+    return enc, dec
+
+
+def _data():
+    g = torch.Generator().manual_seed(3)
+    return (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).to(DEV), torch.tensor([50, 700], device=DEV), torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+
+
+@pytest.fixture()
+def clean_math():
+    from pdae_amd import hip as H
+    H.set_default_math(None)
+    H.SaturationGuard.get(DEV).reset()
+    yield H
+    H.set_default_math(None)
+    H.SaturationGuard.get(DEV).reset()
+
+
+def _step(gd, enc, dec, math=None):
+    from pdae_amd.trainer.fused_step import FusedRLStep
+    return FusedRLStep(gd, enc, dec, copy.deepcopy(enc), copy.deepcopy(dec), 2, 64, 64, math=math)
+
+
+def test_large_activations_inside_the_window_match_bf16x6(clean_math):
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    H = clean_math
+    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device(DEV))
+    x0, t, noise = _data()
+    outs = {}
+    for math in ("f16x3", "bf16x6"):
+        enc, dec = _nets(150.0)               # AdaGN outputs up to ~1e3, conv outputs / residual stream ~1e2
+        st = _step(gd, enc, dec, math=math)
+        st.load_batch(x0, t, noise)
+        st.plan.run(0, st.n_bwd)
+        torch.cuda.synchronize()
+        outs[math] = (st.eps.clone(), st.shift.clone(), float(st.loss.item()), dec.flat_grad.clone(), enc.flat_grad.clone())
+    assert H.SaturationGuard.get(DEV).read() == (0, 0)
+    a, b = outs["f16x3"], outs["bf16x6"]
+    assert float(b[1].abs().max()) > 10.0                      # the stress really reaches the output
+    assert rel_err(a[0], b[0]) < 1e-4 and rel_err(a[1], b[1]) < 1e-4 and abs(a[2] - b[2]) < 1e-4 * abs(b[2])
+    for k in (3, 4):
+        assert float((a[k].double() - b[k].double()).norm() / b[k].double().norm()) < 1e-3
+
+
+def test_window_overflow_skips_the_step_and_falls_back_to_bf16x6(clean_math):
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    H = clean_math
+    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device(DEV))
+    x0, t, noise = _data()
+    enc, dec = _nets(5000.0)                  # AdaGN outputs ~2e4: beyond the 3750 forward window
+    st = _step(gd, enc, dec)
+    assert st.math_name == "f16x3"
+    before = [dec.flat_train.clone(), enc.flat_train.clone(), st.ema_dec.flat_train.clone()]
+    st.step(x0, t=t, noise=noise)
+    torch.cuda.synchronize()
+    events, skipped = st.saturation()
+    assert events > 0 and skipped == 1
+    assert torch.equal(dec.flat_train, before[0]) and torch.equal(enc.flat_train, before[1]) and torch.equal(st.ema_dec.flat_train, before[2])
+    assert float(st.m[0].abs().max()) == 0.0 and float(st.v[0].abs().max()) == 0.0
+    assert st.step_count == 1                  # the host has not noticed yet
+    assert st.handle_saturation(log=False) == 1
+    assert st.step_count == 0 and st.math_name == "bf16x6" and H.default_math() == "bf16x6" and st.saturation() == (0, 0)
+    st.step(x0, t=t, noise=noise)
+    torch.cuda.synchronize()
+    assert st.saturation() == (0, 0) and st.step_count == 1 and not torch.equal(dec.flat_train, before[0])
+    # identical to a run that was bf16x6 from the start
+    enc2, dec2 = _nets(5000.0)
+    st2 = _step(gd, enc2, dec2, math="bf16x6")
+    st2.step(x0, t=t, noise=noise)
+    torch.cuda.synchronize()
+    assert torch.equal(dec2.flat_train, dec.flat_train) and torch.equal(enc2.flat_train, enc.flat_train)
+    assert torch.isfinite(dec.flat_train).all()
+
+
+def test_ddim_loop_recovers_from_overflow(clean_math):
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    H = clean_math
+    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device(DEV))
+    enc, dec = _nets(5000.0)
+    dec.set_eval_mode()
+    x0, _, _ = _data()
+    with torch.no_grad():
+        z = enc(x0)
+        out = gd.representation_learning_ddim_encode("ddim5", None, dec, x0, z)       # fires, re-runs in bf16x6
+        assert H.default_math() == "bf16x6" and H.SaturationGuard.get(DEV).read()[0] == 0
+        ref = gd.representation_learning_ddim_encode("ddim5", None, dec, x0, z)
+    assert torch.isfinite(out).all() and torch.equal(out, ref)
+
+
+def test_non_finite_inputs_propagate_through_f16x3_convolutions(clean_math):
+    """fp32 reference semantics: a NaN / Inf activation makes the outputs that depend on it non-finite (it used to come out as -60000)."""
+    H = clean_math
+    N, S, Cc = 2, 16, 64
+    x = torch.randn(N, S, S, Cc, device=DEV)
+    x[0, 5, 7, 3] = float("nan")
+    x[1, 2, 2, 9] = float("inf")
+    w = torch.randn(Cc, 3, 3, Cc, device=DEV) / 24.0
+    c = H.Conv(N, S, S, Cc, 0, Cc, k=3, math=H.MATH_NAMES["f16x3"])
+    nb = c.wprep_bytes(0, force=True)
+    assert nb > 0
+    wp = torch.empty(nb // 4 + 4, device=DEV)
+    y = torch.empty(N, S, S, Cc, device=DEV)
+    H.run(H.op_conv_wprep(c, w, 0, wp))
+    H.run(H.op_conv_fwd(c, x, None, w, None, y, wp=wp))
+    torch.cuda.synchronize()
+    assert not torch.isfinite(y[0, 4:7, 6:9]).any() and not torch.isfinite(y[1, 1:4, 1:4]).any()
+    assert torch.isfinite(y[0, 10:, 10:]).all()
+    assert H.SaturationGuard.get(DEV).read()[0] > 0            # the Inf is outside the window and is counted; NaN travels through the data path

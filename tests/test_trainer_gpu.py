@@ -30,7 +30,7 @@ def test_trainer_runs_saves_and_resumes(tmp_path):
     from pdae_amd.trainer.train_representation_learning import RepresentationLearningTrainer
     cfg_path = _write_cfg(tmp_path)
     run = str(tmp_path / "run")
-    tr = RepresentationLearningTrainer(SimpleNamespace(config_path=cfg_path, run_path=run, resume="", max_steps=4))
+    tr = RepresentationLearningTrainer(SimpleNamespace(config_path=cfg_path, run_path=run, resume="", allow_random_init=True, max_steps=4))
     frozen = tr.decoder.flat_frozen.clone()
     w0 = tr.decoder.flat_train.clone()
     tr.train()
@@ -48,7 +48,7 @@ def test_trainer_runs_saves_and_resumes(tmp_path):
                             {"params": list(tr.decoder.shift_out.parameters())}], lr=1e-4)
     opt.load_state_dict(ck["optimizer"])
     # resume continues from the same weights / moments
-    tr2 = RepresentationLearningTrainer(SimpleNamespace(config_path=cfg_path, run_path=run, resume=os.path.join(run, "checkpoints", "latest.pt"), max_steps=5))
+    tr2 = RepresentationLearningTrainer(SimpleNamespace(config_path=cfg_path, run_path=run, resume=os.path.join(run, "checkpoints", "latest.pt"), allow_random_init=True, max_steps=5))
     assert tr2.step == 4 and torch.equal(tr2.decoder.flat_train, tr.decoder.flat_train) and torch.equal(tr2.fused.m[0], tr.fused.m[0])
     assert torch.equal(tr2.ema_encoder.flat_train, tr.ema_encoder.flat_train)
     tr2.train()
@@ -77,7 +77,7 @@ def test_regular_diffusion_trainer_runs_and_resumes(tmp_path):
     cfg["runner_config"].update(display_steps=2, save_latest_every_steps=3)
     (tmp_path / "cfg.yml").write_text(yaml.dump(cfg))
     run = str(tmp_path / "run")
-    tr = RegularDiffusionTrainer(SimpleNamespace(config_path=str(tmp_path / "cfg.yml"), run_path=run, resume="", max_steps=3))
+    tr = RegularDiffusionTrainer(SimpleNamespace(config_path=str(tmp_path / "cfg.yml"), run_path=run, resume="", allow_random_init=True, max_steps=3))
     w0 = tr.denoise_fn.flat_train.clone()
     tr.train()
     assert tr.step == 3 and not torch.equal(w0, tr.denoise_fn.flat_train)
@@ -105,7 +105,7 @@ def test_latent_diffusion_trainer_runs_and_matches_adamw(tmp_path):
     cfg["runner_config"].update(display_steps=1, save_latest_every_steps=2)
     (tmp_path / "lat.yml").write_text(yaml.dump(cfg))
     run = str(tmp_path / "run_latent")
-    tr = LatentDiffusionTrainer(SimpleNamespace(config_path=str(tmp_path / "lat.yml"), run_path=run, resume="", max_steps=2))
+    tr = LatentDiffusionTrainer(SimpleNamespace(config_path=str(tmp_path / "lat.yml"), run_path=run, resume="", allow_random_init=True, max_steps=2))
     net = tr.latent_denoise_fn
     # reference optimiser on a torch copy of the same parameters, fed the gradients of the fused step
     ref_p = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
@@ -136,7 +136,7 @@ def test_trainer_enable_amp_runs_in_bf16_operand_mode(tmp_path):
     cfg = yaml.safe_load(open(cfg_path))
     cfg["optimizer_config"]["enable_amp"] = True
     open(cfg_path, "w").write(yaml.dump(cfg))
-    tr = RepresentationLearningTrainer(SimpleNamespace(config_path=cfg_path, run_path=str(tmp_path / "run_amp"), resume="", max_steps=2))
+    tr = RepresentationLearningTrainer(SimpleNamespace(config_path=cfg_path, run_path=str(tmp_path / "run_amp"), resume="", allow_random_init=True, max_steps=2))
     convs = [op for op in tr.fused.plan.arr if op.kind == H.OP_CONV_FWD]
     assert convs and all(op.i[13] == H.MATH_NAMES["bf16"] for op in convs)
     tr.train()
