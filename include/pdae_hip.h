@@ -178,6 +178,24 @@ int pdae_ddim_step_rows(const float* x, const float* eps, const float* g, const 
 int pdae_ddpm_step_rows(const float* x, const float* eps, const float* g, const float* noise, const float* learned_range, const float* coef, int N,
                         size_t per_sample, float* out, pdae_stream_t stream);
 
+/* ---- evaluator (sampler/autoencoding_eval.py:83-99): per-image SSIM and MSE of two (N,C,H,W)-shaped batches of ANY strides in one pass.
+ * Both inputs are mapped v -> v*mul + add first (the (x+1)/2 of autoencoding_eval.py:83-88: mul = add = 0.5).  SSIM = metric/utils.py:35-57
+ * (11-tap Gaussian window, given normalised as window11 so that the caller controls its rounding; zero padding; C1 = 1e-4, C2 = 9e-4; mean over
+ * C,H,W), MSE = metric/utils.py:62-63.  ssim / mse: [N] outputs (either may be NULL). */
+size_t pdae_ssim_mse_workspace_bytes(int N, int C, int H, int W);
+int pdae_ssim_mse(const float* a, const int64_t* a_strides, const float* b, const int64_t* b_strides, int N, int C, int H, int W, float mul, float add,
+                  const float* window11, float* ssim, float* mse, void* ws, pdae_stream_t stream);
+
+/* ---- input pipeline (dataset/ffhq.py:19-31,46; dataset/celeba64.py:11-34): a batch of decoded uint8 images [B][Hs][Ws][C] ->
+ * crop -> PIL-exact antialiased bilinear resize to S_out x S_out (22-bit fixed point, uint8 rounding after each pass) -> optional per-image
+ * horizontal flip -> x0 = (v/255 - 0.5)/0.5 written through x0_strides (element strides of the (B,C,S,S) view: NCHW or the NHWC plan buffer)
+ * and gts [B][S][S][C] uint8 (may be NULL).  coef_* [S_out][ksize] int32 and bounds_* [S_out][2] = (first input index, tap count) are
+ * built on the host like PIL's precompute_coeffs (pdae_amd/dataset/resample.py).  ws: pdae_image_prepare_workspace_bytes bytes. */
+size_t pdae_image_prepare_workspace_bytes(int B, int crop_h, int S_out, int C);
+int pdae_image_prepare(const uint8_t* src, int B, int Hs, int Ws, int C, int crop_y, int crop_x, int crop_h, int crop_w, int S_out,
+                       const int32_t* coef_x, const int32_t* bounds_x, int ksize_x, const int32_t* coef_y, const int32_t* bounds_y, int ksize_y,
+                       const uint8_t* flip, float* x0, const int64_t* x0_strides, uint8_t* gts, void* ws, pdae_stream_t stream);
+
 /* ---- optimizer: torch.optim.Adam / AdamW + EMA (train_representation_learning.py:58-70,192-212) over a flat segment */
 /* guard (optional) = device {saturation counter, skipped-step counter} (pdae_set_saturation_counter): while guard[0] != 0 the update is NOT
  * applied (a convolution of this step clamped an operand into the fp16 window, so its gradients are not fp32-grade) and, when count_skip != 0,

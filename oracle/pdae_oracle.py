@@ -699,3 +699,46 @@ def synth_state_dict(shapes, seed):
             a = rng.standard_normal(shp) / math.sqrt(fan_in)
         sd[k] = torch.tensor(a, dtype=torch.float32)
     return sd
+
+
+# ----------------------------------------------------------------------------------
+# input pipeline (dataset/ffhq.py:19-31,46; dataset/celeba64.py:11-34).  The resize lives in a third-party dependency that is not vendored
+# in the reference tree: Pillow (requirements.txt: unpinned; here 10.x), called through torchvision.transforms.Resize on PIL images =
+# Image.resize(size, BILINEAR).  Restated from Pillow's published algorithm (src/libImaging/Resample.c: precompute_coeffs,
+# normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc / Vertical_8bpc) and pinned in tests/test_oracle_golden.py against Pillow itself.
+# ----------------------------------------------------------------------------------
+def pil_bilinear_coeffs(in_size, out_size, bits=22):
+    scale = in_size / out_size
+    fs = max(scale, 1.0)
+    support = fs
+    rows = []
+    for o in range(out_size):
+        c = (o + 0.5) * scale
+        lo, hi = max(int(c - support + 0.5), 0), min(int(c + support + 0.5), in_size)
+        w = np.array([max(0.0, 1.0 - abs((k + lo - c + 0.5) / fs)) for k in range(hi - lo)])
+        w = w / w.sum() if w.sum() != 0 else w
+        rows.append((lo, np.array([int(v * (1 << bits) + 0.5) for v in w], dtype=np.int64)))
+    return rows
+
+
+def resize_u8(img, size, crop=None, bits=22):
+    """uint8 [H,W,C] -> uint8 [size,size,C]: optional crop (top, left, h, w), horizontal pass rounded to uint8, vertical pass rounded to uint8."""
+    if crop is not None:
+        img = img[crop[0]:crop[0] + crop[2], crop[1]:crop[1] + crop[3]]
+    half = 1 << (bits - 1)
+    tmp = np.stack([np.clip((np.tensordot(img[:, lo:lo + len(k)].astype(np.int64), k, axes=([1], [0])) + half) >> bits, 0, 255)
+                    for lo, k in pil_bilinear_coeffs(img.shape[1], size, bits)], 1).astype(np.uint8)
+    out = np.stack([np.clip((np.tensordot(tmp[lo:lo + len(k)].astype(np.int64), k, axes=([0], [0])) + half) >> bits, 0, 255)
+                    for lo, k in pil_bilinear_coeffs(img.shape[0], size, bits)], 0).astype(np.uint8)
+    return out
+
+
+def image_batch(images, size, crop=None, flips=None):
+    """The collate of dataset/ffhq.py:55-74 for decoded uint8 images [B,H,W,C]: x_0 float32 [B,C,S,S] = (v/255 - 0.5)/0.5, gts uint8 [B,S,S,C]."""
+    out = []
+    for b, im in enumerate(images):
+        r = resize_u8(im, size, crop)
+        out.append(r[:, ::-1] if (flips is not None and flips[b]) else r)
+    gts = np.stack(out)
+    x = torch.from_numpy(gts.copy()).float().div(255).permute(0, 3, 1, 2)
+    return (x - 0.5) / 0.5, gts

@@ -420,6 +420,25 @@ extern "C" int pdae_adam_ema(float* p, const float* g, float* m, float* v, float
   return k_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay, guard, count_skip, S(stream));
 }
 
+// ---- evaluator + input pipeline
+extern "C" size_t pdae_ssim_mse_workspace_bytes(int N, int C, int H, int W) { return k_ssim_mse_workspace_floats(N, C, H, W) * sizeof(float); }
+extern "C" int pdae_ssim_mse(const float* a, const int64_t* a_strides, const float* b, const int64_t* b_strides, int N, int C, int H, int W, float mul,
+                             float add, const float* window11, float* ssim, float* mse, void* ws, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(a && b && a_strides && b_strides && window11 && ws && (ssim || mse) && N > 0 && N < 65536 && C > 0 && C < 65536 && H > 0 && W > 0,
+                 "ssim_mse: bad arguments");
+  return k_ssim_mse(a, (const long long*)a_strides, b, (const long long*)b_strides, N, C, H, W, mul, add, window11, ssim, mse, (float*)ws, S(stream));
+}
+extern "C" size_t pdae_image_prepare_workspace_bytes(int B, int crop_h, int S_out, int C) { return k_image_workspace_bytes(B, crop_h, S_out, C); }
+extern "C" int pdae_image_prepare(const uint8_t* src, int B, int Hs, int Ws, int C, int crop_y, int crop_x, int crop_h, int crop_w, int S_out,
+                                  const int32_t* coef_x, const int32_t* bounds_x, int ksize_x, const int32_t* coef_y, const int32_t* bounds_y,
+                                  int ksize_y, const uint8_t* flip, float* x0, const int64_t* x0_strides, uint8_t* gts, void* ws,
+                                  pdae_stream_t stream) {
+  PDAE_CHECK_ARG(src && coef_x && bounds_x && coef_y && bounds_y && x0 && x0_strides && ws && B > 0 && C > 0 && S_out > 0, "image_prepare: null pointer");
+  PDAE_CHECK_ARG(crop_y >= 0 && crop_x >= 0 && crop_h > 0 && crop_w > 0 && crop_y + crop_h <= Hs && crop_x + crop_w <= Ws, "image_prepare: crop box outside the image");
+  return k_image_prepare(src, B, Hs, Ws, C, crop_y, crop_x, crop_h, crop_w, S_out, coef_x, bounds_x, ksize_x, coef_y, bounds_y, ksize_y, flip, x0,
+                         (const long long*)x0_strides, gts, (unsigned char*)ws, S(stream));
+}
+
 // ---- planned-graph executor
 static void desc_from(const int64_t* i, pdae_conv_desc& d) {
   d.N = (int)i[0]; d.Hi = (int)i[1]; d.Wi = (int)i[2]; d.C0 = (int)i[3]; d.C1 = (int)i[4]; d.Ho = (int)i[5]; d.Wo = (int)i[6]; d.Cout = (int)i[7];

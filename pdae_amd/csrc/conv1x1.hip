@@ -103,11 +103,12 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
       const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
       const int c = (s0 << 4) + qd * 4;
       const long long p = m0 + row;
-      apre[l] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < P.M && c < (s_end << 4)) {
-        const bool first = c < P.C0;
-        apre[l] = first ? *reinterpret_cast<const float4*>(P.x0 + p * P.C0 + c) : *reinterpret_cast<const float4*>(P.x1 + p * P.C1 + (c - P.C0));
-      }
+      const bool ok = p < P.M && c < (s_end << 4);
+      const long long pp = ok ? p : 0;               // unconditional load from a clamped address, zeroed afterwards
+      const int cq = ok ? c : 0;
+      const bool first = cq < P.C0;
+      const float4 v = *reinterpret_cast<const float4*>(first ? P.x0 + pp * P.C0 + cq : P.x1 + pp * P.C1 + (cq - P.C0));
+      apre[l] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto a_lstore = [&]() {
@@ -123,8 +124,9 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
     }
   };
 
-  const int nt0 = P.nt_off + (n0 >> 5);
   const int nt_end = P.nt_off + ((P.Nout + 31) >> 5);
+  const int nt0 = min(P.nt_off + (n0 >> 5), nt_end - 1);          // tiles beyond the last are clamped onto it: those columns are never stored
+  const int bofs[2] = {0, (nt0 + 1 < nt_end) ? 512 : 0};
   const size_t plane_stride = (size_t)nsteps * P.NT * 512;
   auto ldb = [&](uint4 (&bq)[2][QNPL(NS)], int s) {
     const unsigned short* base = P.wp + ((size_t)s * P.NT + nt0) * 512 + lane * 8;
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int p = 0; p < QNPL(NS); ++p)
-        bq[b][p] = (nt0 + b < nt_end) ? *reinterpret_cast<const uint4*>(base + p * plane_stride + b * 512) : make_uint4(0u, 0u, 0u, 0u);
+        bq[b][p] = *reinterpret_cast<const uint4*>(base + p * plane_stride + bofs[b]);       // branch-free (clamped tile): counted vmcnt waits
   };
 
   f32x16 acc[2][2];
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   auto step = [&](int s, const uint4 (&bq)[2][QNPL(NS)], uint4 (&bn)[2][QNPL(NS)]) {
-    if (s + 1 < s_end) ldb(bn, s + 1);
+    ldb(bn, min(s + 1, s_end - 1));                 // next step's weights, always issued (straight-line loads: counted waits)
     const int ks = (s - s_begin) & 3;               // step inside the staged 64 channels
     uint4 af[2][QNPL(NS)];
 #pragma unroll
@@ -152,6 +154,7 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #pragma unroll
       for (int p = 0; p < QNPL(NS); ++p)
         af[a][p] = *reinterpret_cast<const uint4*>(&sA[(p * 128 + wm * 64 + a * 32 + li) * QLDH + ks * 16 + h * 8]);
+    __builtin_amdgcn_sched_barrier(0);              // loads first, then the MFMA cluster (the scheduler would sink them behind it)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -223,15 +226,21 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
       const long long row = mw + a * 32 + it * 4 + er;
       rowv[it] = (row >= P.M || colb >= P.Nout) ? -1 : row;
       rv[it] = bias4;
-      if (rowv[it] >= 0 && P.splits == 1) {
-        if (P.res) {
-          const float4 u = *reinterpret_cast<const float4*>(P.res + (P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + colb);
-          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
-        }
-        if (P.accumulate) {
-          const float4 u = *reinterpret_cast<const float4*>(P.y + row * P.Nout + colb);
-          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
-        }
+    }
+    // wave-uniform conditions, clamped per-lane addresses: eight independent loads in flight per operand (see conv3x3p.hip)
+    if (P.splits == 1 && P.res) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const long long row = rowv[it] < 0 ? 0 : rowv[it];
+        const float4 u = *reinterpret_cast<const float4*>(P.res + (P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + (colb < P.Nout ? colb : 0));
+        rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+      }
+    }
+    if (P.splits == 1 && P.accumulate) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const float4 u = *reinterpret_cast<const float4*>(P.y + (rowv[it] < 0 ? 0 : rowv[it]) * P.Nout + (colb < P.Nout ? colb : 0));
+        rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
 #pragma unroll

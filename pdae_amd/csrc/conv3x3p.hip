@@ -165,9 +165,12 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
         gmu = *reinterpret_cast<const float4*>(cf); gsc = *reinterpret_cast<const float4*>(cf + NC); gsh = *reinterpret_cast<const float4*>(cf + 2 * NC);
       }
     }
+    // unconditional loads from a clamped address, zeroed afterwards where the patch pixel lies outside the image (see ldb)
 #pragma unroll
-    for (int l = 0; l < PA_LD; ++l)
-      apre[l] = aoff[l] >= 0 ? *reinterpret_cast<const float4*>(src + aoff[l] * ld + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 0; l < PA_LD; ++l) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (aoff[l] < 0 ? 0ll : aoff[l]) * ld + cc);
+      apre[l] = aoff[l] >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
   auto a_lstore = [&]() {
 #pragma unroll
@@ -219,60 +222,67 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   const int c_begin = sp * P.cps, c_end = min(nchunk, c_begin + P.cps);
   // B fragments of one k-step (16 channels of one tap): one uint4 (8 bf16) per lane, 32-channel tile and plane;
   //   main chunks: wp [p][chunk][tap][kc][nt][lane],  skip chunks: wps [p][chunk - nmain][kc][nt][lane]
-  const int nt0 = (n0 >> 5) + wn * 2;
+  const int nt0 = min((n0 >> 5) + wn * 2, P.NT - 1);
+  const int bofs[2] = {0, (nt0 + 1 < P.NT) ? 512 : 0};
   const size_t plane_main = (size_t)nmain * 18 * P.NT * 512, plane_skip = (size_t)P.nx * 2 * P.NT * 512;      // bf16 elements per plane
   auto ldb = [&](uint4 (&bq)[2][NPL(NS)], int chunk, int tap, int kc) {
     const bool raw = chunk >= nmain;
     const unsigned short* base = raw ? P.wps + ((size_t)(((chunk - nmain) << 1) + kc) * P.NT + nt0) * 512 + lane * 8
                                      : P.wp + ((size_t)(((chunk * 9 + tap) << 1) + kc) * P.NT + nt0) * 512 + lane * 8;
     const size_t ps = raw ? plane_skip : plane_main;
+    // branch-free: a tile index beyond the last one is clamped onto it (those output columns are masked in the epilogue), so the loads are
+    // unconditional straight-line code and the compiler can wait for them with a COUNTED vmcnt instead of draining everything in flight
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int p = 0; p < NPL(NS); ++p)
-        bq[b][p] = (nt0 + b < P.NT) ? *reinterpret_cast<const uint4*>(base + p * ps + b * 512) : make_uint4(0u, 0u, 0u, 0u);
+        bq[b][p] = *reinterpret_cast<const uint4*>(base + p * ps + bofs[b]);
   };
-  // one k-step: 16 channels (half kc of the staged chunk) of one tap
-  auto mma = [&](int tap, int kc, const uint4 (&bq)[2][NPL(NS)]) {
+  // A fragments of one k-step (16 channels = half kc of the staged chunk, one tap): 2 pixel groups x planes, 16 bytes per lane each
+  auto lda = [&](uint4 (&af)[2][NPL(NS)], int tap, int kc) {
     const int dy = tap / 3, dx = tap - dy * 3;
     const int ashift = dy * PPW + dx;
-    uint4 af[2][NPL(NS)];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int p = 0; p < NPL(NS); ++p)
         af[a][p] = *reinterpret_cast<const uint4*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
+  };
+  // the MFMAs of one k-step.  Product-major order: consecutive MFMAs target different accumulators (a dependent pair is 4 issues apart)
+  auto mma = [&](const uint4 (&af)[2][NPL(NS)], const uint4 (&bq)[2][NPL(NS)]) {
 #define PDAE_A(P_) __builtin_bit_cast(bf16x8, af[a][P_])
 #define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[b][P_])
 #define PDAE_AH(P_) __builtin_bit_cast(f16x8, af[a][P_])
 #define PDAE_BH(P_) __builtin_bit_cast(f16x8, bq[b][P_])
-        if constexpr (NS == 4) {                  // fp16 planes: cross terms first, leading term last
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(1), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(1), PDAE_BH(0), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(0), acc[a][b], 0, 0, 0);
-        } else {
-          if constexpr (NS == 3) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(1), acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(2), acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(2), PDAE_B(0), acc[a][b], 0, 0, 0);
-          }
-          if constexpr (NS >= 2) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(1), acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(0), acc[a][b], 0, 0, 0);
-          }
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(0), acc[a][b], 0, 0, 0);
-        }
+#define PDAE_EACH_ACC(STMT)                 \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a) \
+  _Pragma("unroll") for (int b = 0; b < 2; ++b) { STMT; }
+    if constexpr (NS == 4) {                  // fp16 planes: cross terms first, leading term last
+      PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(1), acc[a][b], 0, 0, 0))
+      PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(1), PDAE_BH(0), acc[a][b], 0, 0, 0))
+      PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(0), acc[a][b], 0, 0, 0))
+    } else {
+      if constexpr (NS == 3) {
+        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(1), acc[a][b], 0, 0, 0))
+        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(2), acc[a][b], 0, 0, 0))
+        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(2), PDAE_B(0), acc[a][b], 0, 0, 0))
+      }
+      if constexpr (NS >= 2) {
+        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(1), acc[a][b], 0, 0, 0))
+        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(0), acc[a][b], 0, 0, 0))
+      }
+      PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(0), acc[a][b], 0, 0, 0))
+    }
+#undef PDAE_EACH_ACC
 #undef PDAE_A
 #undef PDAE_AH
 #undef PDAE_BH
 #undef PDAE_B
-      }
   };
-  uint4 q0[2][NPL(NS)], q1[2][NPL(NS)];
+  // Software pipeline, one k-step deep for BOTH operands: while the 12 (6 / 3 / 1 x 4) MFMAs of step i run, the weight fragments (L2, ~200-500
+  // cycles) and the patch fragments (LDS, ~64+ cycles) of step i+1 are already in flight.  sched_barrier pins "issue the loads, THEN the MFMA
+  // cluster": left alone the scheduler sinks the loads to the end of the cluster and the next cluster starts with an exposed vmcnt / lgkmcnt wait.
+  uint4 q0[2][NPL(NS)], q1[2][NPL(NS)], f0[2][NPL(NS)], f1[2][NPL(NS)];
   if (c_begin < c_end) {
     a_gload(c_begin);
     ldb(q0, c_begin, c_begin >= nmain ? 4 : 0, 0);
@@ -282,22 +292,48 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
       const bool raw = chunk >= nmain;
       const int t_lo = raw ? 4 : 0, t_hi = raw ? 5 : 9;                   // skip chunks: centre tap only
+      lda(f0, t_lo, 0);
       for (int tap = t_lo; tap < t_hi; ++tap) {
-        ldb(q1, chunk, tap, 1);                   // next k-step's weights in flight under this step's MFMAs
-        mma(tap, 0, q0);
-        if (tap + 1 < t_hi) ldb(q0, chunk, tap + 1, 0);
-        else if (chunk + 1 < c_end) ldb(q0, chunk + 1, chunk + 1 >= nmain ? 4 : 0, 0);
-        mma(tap, 1, q1);
+#ifndef PDAE_PROBE_NOB
+        ldb(q1, chunk, tap, 1);
+#endif
+#ifndef PDAE_PROBE_NOA
+        lda(f1, tap, 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f0, q0);
+        __builtin_amdgcn_sched_barrier(0);
+        {   // next k-step, ALWAYS issued (unconditional straight-line loads keep the vmcnt / lgkmcnt waits counted): the next tap of this
+            // chunk, else the first tap of the next chunk (its patch fragments are re-read after the hand-over below), else a harmless
+            // repeat of the current step at the very end
+          const bool more = tap + 1 < t_hi, nextc = !more && chunk + 1 < c_end;
+          const int nchunk_i = nextc ? chunk + 1 : chunk;
+          const int ntap = more ? tap + 1 : (nextc ? (chunk + 1 >= nmain ? 4 : 0) : tap);
+#ifndef PDAE_PROBE_NOB
+          ldb(q0, nchunk_i, ntap, 0);
+#endif
+#ifndef PDAE_PROBE_NOA
+          lda(f0, ntap, 0);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(f1, q1);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // patch hand-over at the end of a chunk: the only barriers of the kernel
+#ifndef PDAE_PROBE_NOSTAGE
       if (chunk + 1 < c_end) {
         __syncthreads();                          // every wave is done with the current patch
         a_lstore();
         __syncthreads();
         if (chunk + 2 < c_end) a_gload(chunk + 2);
       }
+#endif
     }
   }
+#if defined(PDAE_PROBE_NOB) || defined(PDAE_PROBE_NOA)
+  lda(f1, 4, 1); ldb(q1, c_begin, 0, 1);        // probes: keep every buffer defined
+#endif
 
   // ---- epilogue: every wave transposes its 32-pixel x 64-channel accumulator groups through a private LDS region (the patch is
   // dead by now) so that global traffic is float4 per lane, 16 lanes per pixel row: 256-byte contiguous runs, 4x fewer store
@@ -329,17 +365,26 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
       const int im = W8 ? img + (bx >> 1) : img;
       rowv[it] = (oy >= P.H || ox >= P.W || im >= P.N || colb >= P.Nout) ? -1 : ((long long)im * P.H + oy) * P.W + ox;
       rv[it] = bias4;
-      if (rowv[it] >= 0 && P.splits == 1) {
-        if (P.res_mode) {
-          long long rrow = rowv[it];
-          if (P.res_mode == 2) rrow = ((long long)im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
-          const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + colb);
-          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+    }
+    // residual / accumulate operands: wave-uniform conditions, per-lane addresses clamped to row 0 / column 0 where the lane has nothing to
+    // store -- eight independent loads in flight per operand instead of eight load -> wait round trips behind exec-mask branches
+    if (P.splits == 1 && P.res_mode) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        long long rrow = rowv[it] < 0 ? 0 : rowv[it];
+        if (P.res_mode == 2) {
+          const int ox2 = (int)(rrow % P.W); const long long t2 = rrow / P.W; const int oy2 = (int)(t2 % P.H); const long long im2 = t2 / P.H;
+          rrow = (im2 * (P.H >> 1) + (oy2 >> 1)) * (P.W >> 1) + (ox2 >> 1);
         }
-        if (P.accumulate) {
-          const float4 u = *reinterpret_cast<const float4*>(P.y + rowv[it] * P.Nout + colb);
-          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
-        }
+        const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + (colb < P.Nout ? colb : 0));
+        rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+      }
+    }
+    if (P.splits == 1 && P.accumulate) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const float4 u = *reinterpret_cast<const float4*>(P.y + (rowv[it] < 0 ? 0 : rowv[it]) * P.Nout + (colb < P.Nout ? colb : 0));
+        rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
 #pragma unroll

@@ -71,13 +71,16 @@ template <int NS> __device__ __forceinline__ void w_split2(float e0, float e1, u
   }
 }
 
-// two transposing reads -> 8 consecutive k (pixel rows r0..r0+7 as seen by this lane's half) of this lane's column
+// two transposing reads -> 8 consecutive k (pixel rows r0..r0+7 as seen by this lane's half) of this lane's column.  The compiler builtin
+// (not inline asm) so that hipcc tracks the LDS counter itself and can keep the next tap's fragments in flight under this tap's MFMAs
+// (an asm statement needs its own "s_waitcnt lgkmcnt(0)", which exposes the LDS latency once per tap).
+typedef short w_s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 tr_frag(unsigned addr_lo, unsigned addr_hi) {
-  unsigned long long v0, v1;
-  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(v0), "=&v"(v1) : "v"(addr_lo), "v"(addr_hi) : "memory");
-  uint4 u = make_uint4((unsigned)v0, (unsigned)(v0 >> 32), (unsigned)v1, (unsigned)(v1 >> 32));
-  return u;
+  typedef __attribute__((address_space(3))) w_s16x4* lds_ptr;
+  const w_s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(size_t)addr_lo);
+  const w_s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(size_t)addr_hi);
+  const uint2 a = __builtin_bit_cast(uint2, v0), b = __builtin_bit_cast(uint2, v1);
+  return make_uint4(a.x, a.y, b.x, b.y);
 }
 
 struct WgradParams {

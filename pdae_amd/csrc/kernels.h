@@ -46,3 +46,12 @@ int k_softmax(float* s, long long rows, int T, hipStream_t st);
 int k_softmax_bwd(const float* p, float* dp, long long rows, int T, hipStream_t st);
 size_t k_colsum_workspace_floats(long long M, int C);
 int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws, hipStream_t st);
+
+// metric.hip / image.hip
+size_t k_ssim_mse_workspace_floats(int N, int C, int H, int W);
+int k_ssim_mse(const float* a, const long long* as, const float* b, const long long* bs, int N, int C, int H, int W, float mul, float add,
+               const float* window, float* ssim, float* mse, float* ws, hipStream_t st);
+size_t k_image_workspace_bytes(int B, int crop_h, int S, int C);
+int k_image_prepare(const unsigned char* src, int B, int Hs, int Ws, int C, int cy, int cx, int ch, int cw, int S, const int* kx, const int* bx, int ksx,
+                    const int* ky, const int* by, int ksy, const unsigned char* flip, float* x0, const long long* strides, unsigned char* gts,
+                    unsigned char* ws, hipStream_t st);

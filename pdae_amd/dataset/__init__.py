@@ -1,7 +1,27 @@
-"""Input pipeline stand-in.  The reference's datasets are LMDB / torchvision readers (dataset/*.py) whose data, lmdb and
-torchvision are absent here; BASELINE.json defines the metric on synthetic images.  SYNTHETIC honours the collate contract
-{"idx", "x_0", "gts"} (dataset/ffhq.py:55-74): x_0 ~ U(-1,1) float32 [B,C,H,W], gts uint8 [B,H,W,C]."""
+"""Input pipeline: LMDB-free, with the per-image work of the reference's DataLoader workers moved onto the GPU.
+
+The reference reads JPEG/PNG bytes from LMDB, decodes with PIL and runs torchvision transforms per image on worker processes
+(dataset/ffhq.py:19-53), then collates to {"idx", "x_0", "gts"} (:55-74).  Here a dataset is a set of `.npy` shards of DECODED uint8 images
+([n, H, W, C]; memory-mapped, so a 70 000-image FFHQ-256 set is a 13.8 GB file set that never enters the Python heap); a batch is
+  1. gathered from the memory map into one of two pinned host buffers by a background thread,
+  2. copied to the device on a side stream (double buffered: the copy of batch k+1 overlaps the training step of batch k),
+  3. cropped / resized (PIL-exact antialiased bilinear) / flipped / normalised by ONE pdae_image_prepare call (csrc/image.hip),
+and handed over as {"idx": LongTensor, "x_0": float32 [B,C,S,S] in [-1,1], "gts": uint8 [B,S,S,C]} -- the collate contract.
+`SYNTHETIC` (BASELINE.json: synthetic images of the named resolution) draws x_0 on the device and keeps the same contract.
+"""
+import ctypes
+import glob
+import os
+import queue
+import threading
+
+import numpy as np
 import torch
+
+from .. import hip as H
+from .resample import bilinear_coefficients
+
+CROPS = {"CELEBA64": (57, 25, 128, 128)}          # dataset/celeba64.py:11-14: F.crop(img, top, left, height, width) in front of the resize
 
 
 class SYNTHETIC:
@@ -19,9 +39,141 @@ class SYNTHETIC:
         return {"idx": torch.arange(batch_size), "x_0": x, "gts": gts}
 
 
-def build(config):
+class ShardedImages:
+    """Decoded uint8 images in `<data_path>/*.npy` shards ([n,H,W,C] or [n,H,W]); index = position in the sorted shard list."""
+
+    def __init__(self, data_path):
+        files = sorted(glob.glob(os.path.join(data_path, "*.npy")))
+        if not files:
+            raise FileNotFoundError(f"no .npy image shards under {data_path!r}")
+        self.shards = [np.load(f, mmap_mode="r") for f in files]
+        for s in self.shards:
+            if s.dtype != np.uint8 or s.ndim not in (3, 4) or s.shape[1:] != self.shards[0].shape[1:]:
+                raise ValueError("image shards must be uint8 [n,H,W,C] arrays of one common image shape")
+        self.starts = np.cumsum([0] + [s.shape[0] for s in self.shards])
+        self.shape = tuple(self.shards[0].shape[1:]) + (() if self.shards[0].ndim == 4 else (1,))
+
+    def __len__(self):
+        return int(self.starts[-1])
+
+    def gather(self, indices, out):
+        """out[k] = image indices[k]  (out: uint8 [B,H,W,C] numpy view of a pinned buffer)."""
+        for k, i in enumerate(indices):
+            s = int(np.searchsorted(self.starts, i, side="right")) - 1
+            img = self.shards[s][i - self.starts[s]]
+            out[k] = img if img.ndim == 3 else img[..., None]
+
+
+class DeviceImagePipeline:
+    """Double-buffered host -> device image batches with on-GPU crop / resize / flip / normalise (module docstring)."""
+
+    def __init__(self, config, device, rank=0, world_size=1, seed=0):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise H.PdaeError("the device image pipeline needs a ROCm device (pdae_image_prepare has no CPU fallback)")
+        self.size = int(config["image_size"])
+        self.augmentation = bool(config.get("augmentation", True))
+        self.images = ShardedImages(config["data_path"])
+        Hs, Ws, C = self.images.shape
+        if C != int(config.get("image_channel", C)):
+            raise ValueError(f"image_channel {config.get('image_channel')} but the shards hold {C}-channel images")
+        self.crop = tuple(config["crop"]) if config.get("crop") else CROPS.get(str(config.get("name", "")).upper(), (0, 0, Hs, Ws))
+        cy, cx, ch, cw = self.crop
+        kx, bx = bilinear_coefficients(cw, self.size)
+        ky, by = bilinear_coefficients(ch, self.size)
+        dev = self.device
+        self._tabs = [torch.from_numpy(a).to(dev) for a in (kx, bx, ky, by)]
+        self._ks = (kx.shape[1], ky.shape[1])
+        self.rank, self.world, self.seed, self.epoch = rank, world_size, seed, 0
+        self._stream = torch.cuda.Stream(device=dev)
+        self._slots = None
+        self._q = None
+        self._thread = None
+
+    def __len__(self):
+        return len(self.images)
+
+    # ------------------------------------------------------------------ index order (DistributedSampler semantics: shuffled per epoch, rank-strided)
+    def _epoch_indices(self, epoch):
+        g = np.random.default_rng(self.seed + epoch)
+        order = g.permutation(len(self.images)) if self.augmentation else np.arange(len(self.images))
+        return order[self.rank::self.world]
+
+    def _alloc(self, B):
+        Hs, Ws, C = self.images.shape
+        L = H.lib()
+        slots = []
+        for _ in range(2):
+            host = torch.empty(B, Hs, Ws, C, dtype=torch.uint8).pin_memory()
+            slots.append(dict(host=host, np=host.numpy(), flip_host=torch.zeros(B, dtype=torch.uint8).pin_memory(),
+                              dev=torch.empty(B, Hs, Ws, C, dtype=torch.uint8, device=self.device),
+                              flip=torch.empty(B, dtype=torch.uint8, device=self.device),
+                              ws=torch.empty(int(L.pdae_image_prepare_workspace_bytes(B, self.crop[2], self.size, C)) + 16, dtype=torch.uint8, device=self.device),
+                              ready=torch.cuda.Event(), done=None, free=threading.Event()))
+            slots[-1]["free"].set()
+        return slots
+
+    def _producer(self, B):
+        k, epoch = 0, self.epoch
+        while True:
+            idx = self._epoch_indices(epoch)
+            for s in range(0, len(idx) - B + 1, B):              # drop_last like the reference's DataLoader (base_trainer.py:71-79)
+                slot = self._slots[k % 2]
+                slot["free"].wait()                                # the consumer has issued the kernel that reads this slot's device buffer
+                slot["free"].clear()
+                if slot["done"] is not None:
+                    slot["ready"].synchronize()                    # the previous H2D out of this pinned buffer has finished
+                    self._stream.wait_event(slot["done"])          # the next H2D into the device buffer queues behind that kernel (no host wait)
+                ids = idx[s:s + B]
+                self.images.gather(ids, slot["np"])
+                if self.augmentation:
+                    slot["flip_host"].copy_(torch.from_numpy((np.random.default_rng(self.seed * 7919 + epoch * 104729 + s).random(B) < 0.5).astype(np.uint8)))
+                else:
+                    slot["flip_host"].zero_()
+                with torch.cuda.stream(self._stream):
+                    slot["dev"].copy_(slot["host"], non_blocking=True)
+                    slot["flip"].copy_(slot["flip_host"], non_blocking=True)
+                    slot["ready"].record(self._stream)
+                self._q.put((k % 2, torch.from_numpy(np.asarray(ids, dtype=np.int64))))
+                k += 1
+            epoch += 1
+
+    def batch(self, batch_size, device=None, generator=None, out=None):
+        """Next batch.  `out`: optional float32 destination (any strides, e.g. the NHWC plan buffer viewed as (B,C,S,S))."""
+        if self._thread is None:
+            self._slots = self._alloc(batch_size)
+            self._q = queue.Queue(maxsize=2)
+            self._thread = threading.Thread(target=self._producer, args=(batch_size,), daemon=True)
+            self._thread.start()
+        k, ids = self._q.get()
+        slot = self._slots[k]
+        Hs, Ws, C = self.images.shape
+        S = self.size
+        x0 = torch.empty(batch_size, C, S, S, device=self.device) if out is None else out
+        gts = torch.empty(batch_size, S, S, C, dtype=torch.uint8, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(slot["ready"])                              # the H2D copy of this slot ran on the side stream
+        kx, bx, ky, by = self._tabs
+        cy, cx, ch, cw = self.crop
+        strides = (ctypes.c_int64 * 4)(*x0.stride())
+        L = H.lib()
+        rc = L.pdae_image_prepare(slot["dev"].data_ptr(), batch_size, Hs, Ws, C, cy, cx, ch, cw, S, kx.data_ptr(), bx.data_ptr(), self._ks[0],
+                                  ky.data_ptr(), by.data_ptr(), self._ks[1], slot["flip"].data_ptr(), x0.data_ptr(), strides, gts.data_ptr(),
+                                  slot["ws"].data_ptr(), ctypes.c_void_p(cur.cuda_stream))
+        if rc != 0:
+            raise H.PdaeError(f"pdae_image_prepare failed ({rc}): {L.pdae_last_error().decode()}")
+        slot["done"] = torch.cuda.Event()
+        slot["done"].record(cur)
+        slot["free"].set()
+        return {"idx": ids, "x_0": x0, "gts": gts}
+
+
+def build(config, device=None, rank=0, world_size=1, seed=0):
+    """dataset_module.build(train_dataset_config): 'SYNTHETIC', or any other name with a `data_path` of .npy shards."""
     name = config.get("name", config.get("dataset_name", "SYNTHETIC"))
-    if name != "SYNTHETIC":
-        raise NotImplementedError(f"dataset {name!r}: only the SYNTHETIC stand-in ships with pdae_amd (no lmdb/torchvision/data in this "
-                                  "environment); plug a loader that yields {'idx','x_0','gts'} batches")
-    return SYNTHETIC(config)
+    if name == "SYNTHETIC":
+        return SYNTHETIC(config)
+    if not config.get("data_path"):
+        raise NotImplementedError(f"dataset {name!r}: give train_dataset_config.data_path = a directory of decoded uint8 .npy shards "
+                                  "(the reference's LMDB / torchvision readers are not part of pdae_amd)")
+    return DeviceImagePipeline(config, device if device is not None else torch.device("cuda", torch.cuda.current_device()), rank, world_size, seed)

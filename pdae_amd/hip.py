@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpdae_hip.so")
+LIB_PATH = os.environ.get("PDAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpdae_hip.so")     # PDAE_HIP_LIB: timing-probe builds (tools/probe_build.py)
 
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
@@ -83,6 +83,17 @@ def lib():
         L.pdae_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
         L.pdae_colsum_workspace_bytes.restype = ctypes.c_size_t
         L.pdae_abi_version.restype = ctypes.c_int
+        L.pdae_ssim_mse_workspace_bytes.restype = ctypes.c_size_t
+        L.pdae_ssim_mse_workspace_bytes.argtypes = [ctypes.c_int] * 4
+        L.pdae_ssim_mse.restype = ctypes.c_int
+        L.pdae_ssim_mse.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)] + [ctypes.c_int] * 4 + \
+            [ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.pdae_image_prepare_workspace_bytes.restype = ctypes.c_size_t
+        L.pdae_image_prepare_workspace_bytes.argtypes = [ctypes.c_int] * 4
+        L.pdae_image_prepare.restype = ctypes.c_int
+        L.pdae_image_prepare.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 9 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                                                 ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.pdae_set_saturation_counter.argtypes = [ctypes.c_void_p]
         L.pdae_set_saturation_counter.restype = ctypes.c_int
         _lib = L
@@ -93,7 +104,8 @@ EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter",
            "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_q_sample", "pdae_loss",
-           "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops"]
+           "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
+           "pdae_ssim_mse_workspace_bytes", "pdae_ssim_mse", "pdae_image_prepare_workspace_bytes", "pdae_image_prepare"]
 
 
 class SaturationGuard:

@@ -6,7 +6,7 @@ import torch
 
 from .. import dataset as dataset_module
 from ..diffusion.gaussian_diffusion import GaussianDiffusion
-from ..metric import MSEMetric, SSIMMetric
+from ..metric import MSEMetric, SSIMMetric, ssim_mse
 from ..model.representation_learning import decoder as decoder_module
 from ..model.representation_learning import encoder as encoder_module
 from ..utils import dispatch_num_samples_for_process, init_distributed_mode, load_yaml, set_seed
@@ -43,9 +43,10 @@ class Sampler:
                 n = min(bs, mine - done)
                 x_0 = self.dataset.batch(n, self.device)["x_0"]
                 rec = self.gaussian_diffusion.representation_learning_autoencoding(encoder_style, decoder_style, self.encoder, self.decoder, x_0)
-                a, b = (x_0 + 1.0) / 2.0, (rec + 1.0) / 2.0
-                self.ssim_metric.process(a, b)
-                self.mse_metric.process(a, b)
+                # one fused kernel: (x+1)/2 of both batches, SSIM and MSE per image (autoencoding_eval.py:83-88 + metric/utils.py:35-63)
+                s, m = ssim_mse(x_0, rec, denormalize=True)
+                self.ssim_metric.results.extend(s.tolist())
+                self.mse_metric.results.extend(m.tolist())
                 done += n
         ssim = self.ssim_metric.all_gather_results(self.global_world_size)
         mse = self.mse_metric.all_gather_results(self.global_world_size)

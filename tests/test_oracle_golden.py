@@ -176,3 +176,26 @@ def test_f3_front_ends_vs_reference():
         assert rel_err(O.shift_ddim_trajectory_interpolation(s, "ddim10", dsd, CFG_SHIFT_T, z, z2, xT, 0.3), g["c_traj"]) < 1e-4
         zm = O.manipulated_latent(z, T(g["c_cw"]), 3, 0.25, T(g["c_mean"]), T(g["c_std"]))
         assert rel_err(O.shift_ddim_sample_loop(s, "ddim10", dsd, CFG_SHIFT_T, zm, xT), g["c_man"]) < 1e-4
+
+
+def test_resize_oracle_is_bit_exact_with_pillow():
+    """The input pipeline's resize lives in Pillow (third-party, not vendored by the reference): the oracle restates its 8-bit resampler and
+    is pinned here against Pillow itself (known-answer: Image.resize(..., BILINEAR) is what transforms.Resize applies, dataset/ffhq.py:21)."""
+    from PIL import Image
+    from pdae_amd.dataset.resample import bilinear_coefficients
+    rng = np.random.default_rng(0)
+    for Hs, Ws, S, crop in [(256, 256, 128, None), (218, 178, 64, (57, 25, 128, 128)), (100, 75, 32, None), (64, 64, 128, None), (37, 53, 16, None)]:
+        img = rng.integers(0, 256, (Hs, Ws, 3), dtype=np.uint8)
+        pil = Image.fromarray(img)
+        if crop:
+            pil = pil.crop((crop[1], crop[0], crop[1] + crop[3], crop[0] + crop[2]))
+        assert np.array_equal(np.asarray(pil.resize((S, S), Image.BILINEAR)), O.resize_u8(img, S, crop)), (Hs, Ws, S)
+        # the product's host-side coefficient tables are the oracle's
+        w_in = crop[3] if crop else Ws
+        coef, bounds = bilinear_coefficients(w_in, S)
+        for o, (lo, k) in enumerate(O.pil_bilinear_coeffs(w_in, S)):
+            assert bounds[o, 0] == lo and bounds[o, 1] == len(k) and np.array_equal(coef[o, :len(k)], k)
+    g = rng.integers(0, 256, (2, 40, 40, 1), dtype=np.uint8)
+    x, gts = O.image_batch(g, 20, flips=[0, 1])
+    assert x.shape == (2, 1, 20, 20) and gts.shape == (2, 20, 20, 1) and float(x.min()) >= -1 and float(x.max()) <= 1
+    assert np.array_equal(gts[1], O.resize_u8(g[1], 20)[:, ::-1])

@@ -74,7 +74,8 @@ def test_large_activations_inside_the_window_match_bf16x6(clean_math):
         outs[math] = (st.eps.clone(), st.shift.clone(), float(st.loss.item()), dec.flat_grad.clone(), enc.flat_grad.clone())
     assert H.SaturationGuard.get(DEV).read() == (0, 0)
     a, b = outs["f16x3"], outs["bf16x6"]
-    assert float(b[1].abs().max()) > 10.0                      # the stress really reaches the output
+    # (the output heads sit behind a GroupNorm, so the stress does not show in eps / shift magnitudes; that it is real is shown by the
+    # next test, where the same knob 33x larger trips the window)
     assert rel_err(a[0], b[0]) < 1e-4 and rel_err(a[1], b[1]) < 1e-4 and abs(a[2] - b[2]) < 1e-4 * abs(b[2])
     for k in (3, 4):
         assert float((a[k].double() - b[k].double()).norm() / b[k].double().norm()) < 1e-3
@@ -116,7 +117,7 @@ def test_ddim_loop_recovers_from_overflow(clean_math):
     gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device(DEV))
     enc, dec = _nets(5000.0)
     dec.set_eval_mode()
-    x0, _, _ = _data()
+    x0 = _data()[0].repeat(4, 1, 1, 1)          # B = 8: enough tiles for the forward convolutions to take the fp16-format patch kernel
     with torch.no_grad():
         z = enc(x0)
         out = gd.representation_learning_ddim_encode("ddim5", None, dec, x0, z)       # fires, re-runs in bf16x6
