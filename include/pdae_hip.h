@@ -110,6 +110,13 @@ int pdae_gemm(int transA, int transB, int M, int N, int K, float alpha, const fl
               int64_t ldb, int64_t sBo, int64_t sBi, float* C, int64_t ldc, int64_t sCo, int64_t sCi, int batch_outer, int batch_inner,
               const float* bias, int accumulate, pdae_stream_t stream);
 
+/* A family of small linear layers in ONE launch: y_i[M][n_out_i] = x_i[M][K] W_i[n_out_i][K]^T + bias_i (M <= 32, exact fp32 FMA).  Every
+ * ResBlock's emb_layers / emb_z_layers Linear (model/module.py:287-293, 371-380) reads SiLU(emb) / SiLU(shift_emb), which exist before the
+ * first block: one call per network pass instead of one launch per block.  items and first_feature are DEVICE arrays; first_feature[i] is
+ * the position of item i's first output feature in the concatenated feature list, first_feature[n_items] == total_features. */
+typedef struct pdae_linear_item { const float* x; const float* w; const float* bias; float* y; int32_t n_out; int32_t reserved; } pdae_linear_item;
+int pdae_linear_group(const pdae_linear_item* items, const int32_t* first_feature, int n_items, int total_features, int M, int K, pdae_stream_t stream);
+
 /* ---- GroupNorm(32,C) + AdaGN + SiLU (+Dropout, +AvgPool2d) : module.py:56-63,241,257-263,279-284,293-294,379-381 */
 size_t pdae_gn_workspace_bytes(int N, int C);
 int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, void* ws,
@@ -211,7 +218,7 @@ enum {
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
   PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
-  PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS
+  PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP
 };
 typedef struct pdae_op {
   int32_t kind;

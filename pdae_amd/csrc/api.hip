@@ -297,6 +297,13 @@ extern "C" int pdae_gemm(int transA, int transB, int M, int N, int K, float alph
   return igemm_dense(transA, transB, P, batch_outer * batch_inner, S(stream));
 }
 
+extern "C" int pdae_linear_group(const pdae_linear_item* items, const int32_t* first_feature, int n_items, int total_features, int M, int K,
+                                 pdae_stream_t stream) {
+  PDAE_CHECK_ARG(items && first_feature && n_items > 0 && total_features > 0 && M > 0 && M <= 32 && K > 0 && (K & 7) == 0,
+                 "linear_group: bad arguments (M <= 32, K %% 8 == 0)");
+  return skinny_group_launch(items, first_feature, n_items, total_features, M, K, S(stream));
+}
+
 // ---- GroupNorm family
 extern "C" size_t pdae_gn_workspace_bytes(int N, int C) { return k_gn_workspace_floats(N, C) * sizeof(float); }
 extern "C" int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, void* ws,
@@ -492,6 +499,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_AXPBY_ROWS: return pdae_axpby_rows(F(0), F(1), F(2), F(3), (int)i[0], (size_t)i[1], FM(4), st);
     case PDAE_OP_DDIM_STEP_ROWS: return pdae_ddim_step_rows(F(0), F(1), F(2), F(3), (int)i[0], (size_t)i[1], (int)i[2], FM(4), st);
     case PDAE_OP_DDPM_STEP_ROWS: return pdae_ddpm_step_rows(F(0), F(1), F(2), F(3), F(4), F(5), (int)i[0], (size_t)i[1], FM(6), st);
+    case PDAE_OP_LINEAR_GROUP: return pdae_linear_group((const pdae_linear_item*)p[0], (const int32_t*)p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], st);
     case PDAE_OP_ADAM_EMA:
       return pdae_adam_ema(FM(0), F(1), FM(2), FM(3), FM(4), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (int)i[1],
                            (float)f[5], (float)f[6], (float)f[7], (float)f[8], (unsigned int*)p[5], (int)i[2], st);

@@ -1,7 +1,7 @@
 // 3x3 / stride-1 / pad-1 convolution (forward and data-gradient) for gfx950 on the bf16 MFMA pipe with split fp32
 // operands -- the "patch" kernel.
 //
-// Block = 512 threads (8 waves as 4(M) x 2(N)), output tile = 16x16 pixels x 128 output channels.
+// Block = 256 threads (4 waves, each 128 pixels x 32 output channels), output tile = 8x16 pixels x 128 output channels (PTH 16: 8 waves, 16x16 pixels).
 // For every 32-channel chunk of the input the 18x18-pixel halo patch is staged in LDS ONCE (as NS bf16 planes, see
 // igemm.hip) and all 9 taps read their shifted A fragments straight out of it, so the input crosses L2->CU ~1.3x
 // instead of 9x.  The weights are pre-split into bf16 planes in MFMA-FRAGMENT ORDER by conv3x3p_wprep (one 1 KB
@@ -36,7 +36,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define PBN 128
 #define PSLOT(row, slot) ((row) * PLDH + ((slot) << 3))       // bf16 offset of 16-byte k-slot `slot` of `row`
 #define PPLANE(rows) ((rows) * PLDH)
-#define EPW 68                  // floats per row of the epilogue transpose tile (64 + 4 pad)
+#define EPW 36                  // floats per row of the epilogue transpose tile (32 + 4 pad)
 
 __device__ __forceinline__ float p_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 __device__ __forceinline__ unsigned p_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
@@ -98,8 +98,17 @@ __device__ __forceinline__ float p_pow2_scale(float amax) {
 }
 __device__ __forceinline__ float p_silu(float v) { return v / (1.0f + expf(-v)); }
 
+// issue pattern of one k-step: one LDS / vector-memory load of the NEXT step behind each MFMA of this one (measured +2..4 % over "all loads,
+// then the 12 MFMAs"; -DPDAE_P3_CLUSTERED restores that form for tools/probe_build.py)
+#define PDAE_ILV_PATTERN                                                                                   \
+  _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);                                                     \
+    if (i_ < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    else if (i_ < 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                   \
+  }
 template <int NS, int PTH, bool W8, bool GN = false>
-__global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P) {
+__global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams P) {      // 2 waves per SIMD: two 8x16 blocks (or one 16x16 block) per CU
   static_assert(!(GN && W8), "fused GroupNorm input is not built for the image-pair geometry");
   constexpr int PTHREADS = PTH * 32;                      // 512 | 256
   constexpr int PNPIX = (PTH + 2) * PPW;                  // 324 | 180
@@ -109,7 +118,10 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   unsigned short* sA = smem;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
-  const int wm = wv >> 1, wn = wv & 1;           // 4 x 2 waves; wave tile = 64 pixels x 64 channels
+  // wave tile = 128 pixels x 32 output channels: the 4 waves (PTH 8) / 2 x 4 waves (PTH 16) that share a pixel set each own ONE 32-channel
+  // weight tile, so no two waves of a block load the same B fragment (the 64 x 64 wave tile made pairs of waves fetch identical fragments:
+  // probe timing put ~20 % of the kernel on the weight loads through the vector-memory path; A fragments come from LDS, which has headroom)
+  const int wm = wv >> 2, wn = wv & 3;
 
   // block -> (image, tile_y, tile_x, n-tile); n-tile fastest so the blocks sharing a patch are co-scheduled
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -202,30 +214,27 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
     }
   };
 
-  // MFMA row i of 32-row group g = wm*2+a <-> pixel (by*8 + i/4, bx*4 + i%4), (bx, by) = (g & 3, g >> 2): with the 20-pixel
+  // MFMA row i of 32-row group g = wm*4+a <-> pixel (by*8 + i/4, bx*4 + i%4), (bx, by) = (g & 3, g >> 2): with the 20-pixel
   // pitch and 80-byte rows the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte slots for all 9 tap shifts
-  int apix[2];
+  int apix[4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int g = wm * 2 + a, bx = g & 3;
+  for (int a = 0; a < 4; ++a) {
+    const int g = wm * 4 + a, bx = g & 3;
     apix[a] = ((g >> 2) * 8 + (li >> 2)) * PPW + (W8 ? (bx >> 1) * 10 + (bx & 1) * 4 : bx * 4) + (li & 3);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
   const int c_begin = sp * P.cps, c_end = min(nchunk, c_begin + P.cps);
   // B fragments of one k-step (16 channels of one tap): one uint4 (8 bf16) per lane, 32-channel tile and plane;
   //   main chunks: wp [p][chunk][tap][kc][nt][lane],  skip chunks: wps [p][chunk - nmain][kc][nt][lane]
-  const int nt0 = min((n0 >> 5) + wn * 2, P.NT - 1);
-  const int bofs[2] = {0, (nt0 + 1 < P.NT) ? 512 : 0};
+  const int nt0 = min((n0 >> 5) + wn, P.NT - 1);
   const size_t plane_main = (size_t)nmain * 18 * P.NT * 512, plane_skip = (size_t)P.nx * 2 * P.NT * 512;      // bf16 elements per plane
-  auto ldb = [&](uint4 (&bq)[2][NPL(NS)], int chunk, int tap, int kc) {
+  auto ldb = [&](uint4 (&bq)[NPL(NS)], int chunk, int tap, int kc) {
     const bool raw = chunk >= nmain;
     const unsigned short* base = raw ? P.wps + ((size_t)(((chunk - nmain) << 1) + kc) * P.NT + nt0) * 512 + lane * 8
                                      : P.wp + ((size_t)(((chunk * 9 + tap) << 1) + kc) * P.NT + nt0) * 512 + lane * 8;
@@ -233,45 +242,40 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
     // branch-free: a tile index beyond the last one is clamped onto it (those output columns are masked in the epilogue), so the loads are
     // unconditional straight-line code and the compiler can wait for them with a COUNTED vmcnt instead of draining everything in flight
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int p = 0; p < NPL(NS); ++p)
-        bq[b][p] = *reinterpret_cast<const uint4*>(base + p * ps + bofs[b]);
+    for (int p = 0; p < NPL(NS); ++p) bq[p] = *reinterpret_cast<const uint4*>(base + p * ps);
   };
   // A fragments of one k-step (16 channels = half kc of the staged chunk, one tap): 2 pixel groups x planes, 16 bytes per lane each
-  auto lda = [&](uint4 (&af)[2][NPL(NS)], int tap, int kc) {
+  auto lda = [&](uint4 (&af)[4][NPL(NS)], int tap, int kc) {
     const int dy = tap / 3, dx = tap - dy * 3;
     const int ashift = dy * PPW + dx;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int p = 0; p < NPL(NS); ++p)
         af[a][p] = *reinterpret_cast<const uint4*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
   };
   // the MFMAs of one k-step.  Product-major order: consecutive MFMAs target different accumulators (a dependent pair is 4 issues apart)
-  auto mma = [&](const uint4 (&af)[2][NPL(NS)], const uint4 (&bq)[2][NPL(NS)]) {
+  auto mma = [&](const uint4 (&af)[4][NPL(NS)], const uint4 (&bq)[NPL(NS)]) {
 #define PDAE_A(P_) __builtin_bit_cast(bf16x8, af[a][P_])
-#define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[b][P_])
+#define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[P_])
 #define PDAE_AH(P_) __builtin_bit_cast(f16x8, af[a][P_])
-#define PDAE_BH(P_) __builtin_bit_cast(f16x8, bq[b][P_])
-#define PDAE_EACH_ACC(STMT)                 \
-  _Pragma("unroll") for (int a = 0; a < 2; ++a) \
-  _Pragma("unroll") for (int b = 0; b < 2; ++b) { STMT; }
+#define PDAE_BH(P_) __builtin_bit_cast(f16x8, bq[P_])
+#define PDAE_EACH_ACC(STMT) _Pragma("unroll") for (int a = 0; a < 4; ++a) { STMT; }
     if constexpr (NS == 4) {                  // fp16 planes: cross terms first, leading term last
-      PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(1), acc[a][b], 0, 0, 0))
-      PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(1), PDAE_BH(0), acc[a][b], 0, 0, 0))
-      PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(0), acc[a][b], 0, 0, 0))
+      PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(1), acc[a], 0, 0, 0))
+      PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(1), PDAE_BH(0), acc[a], 0, 0, 0))
+      PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(0), acc[a], 0, 0, 0))
     } else {
       if constexpr (NS == 3) {
-        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(1), acc[a][b], 0, 0, 0))
-        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(2), acc[a][b], 0, 0, 0))
-        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(2), PDAE_B(0), acc[a][b], 0, 0, 0))
+        PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(1), acc[a], 0, 0, 0))
+        PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(2), acc[a], 0, 0, 0))
+        PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(2), PDAE_B(0), acc[a], 0, 0, 0))
       }
       if constexpr (NS >= 2) {
-        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(1), acc[a][b], 0, 0, 0))
-        PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(0), acc[a][b], 0, 0, 0))
+        PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(1), acc[a], 0, 0, 0))
+        PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(0), acc[a], 0, 0, 0))
       }
-      PDAE_EACH_ACC(acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(0), acc[a][b], 0, 0, 0))
+      PDAE_EACH_ACC(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(0), acc[a], 0, 0, 0))
     }
 #undef PDAE_EACH_ACC
 #undef PDAE_A
@@ -282,7 +286,7 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   // Software pipeline, one k-step deep for BOTH operands: while the 12 (6 / 3 / 1 x 4) MFMAs of step i run, the weight fragments (L2, ~200-500
   // cycles) and the patch fragments (LDS, ~64+ cycles) of step i+1 are already in flight.  sched_barrier pins "issue the loads, THEN the MFMA
   // cluster": left alone the scheduler sinks the loads to the end of the cluster and the next cluster starts with an exposed vmcnt / lgkmcnt wait.
-  uint4 q0[2][NPL(NS)], q1[2][NPL(NS)], f0[2][NPL(NS)], f1[2][NPL(NS)];
+  uint4 q0[NPL(NS)], q1[NPL(NS)], f0[4][NPL(NS)], f1[4][NPL(NS)];
   if (c_begin < c_end) {
     a_gload(c_begin);
     ldb(q0, c_begin, c_begin >= nmain ? 4 : 0, 0);
@@ -300,8 +304,13 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
 #ifndef PDAE_PROBE_NOA
         lda(f1, tap, 1);
 #endif
+#ifndef PDAE_P3_CLUSTERED
+        mma(f0, q0);
+        PDAE_ILV_PATTERN
+#else
         __builtin_amdgcn_sched_barrier(0);
         mma(f0, q0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         {   // next k-step, ALWAYS issued (unconditional straight-line loads keep the vmcnt / lgkmcnt waits counted): the next tap of this
             // chunk, else the first tap of the next chunk (its patch fragments are re-read after the hand-over below), else a harmless
@@ -316,12 +325,18 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
           lda(f0, ntap, 0);
 #endif
         }
+#ifndef PDAE_P3_CLUSTERED
+        mma(f1, q1);
+        PDAE_ILV_PATTERN
+#else
         __builtin_amdgcn_sched_barrier(0);
         mma(f1, q1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       // patch hand-over at the end of a chunk: the only barriers of the kernel
 #ifndef PDAE_PROBE_NOSTAGE
+      // (a second LDS patch buffer filled in the middle of the chunk -- one barrier per chunk -- was measured: no gain, 2x LDS, +30 VGPRs)
       if (chunk + 1 < c_end) {
         __syncthreads();                          // every wave is done with the current patch
         a_lstore();
@@ -335,31 +350,32 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
   lda(f1, 4, 1); ldb(q1, c_begin, 0, 1);        // probes: keep every buffer defined
 #endif
 
-  // ---- epilogue: every wave transposes its 32-pixel x 64-channel accumulator groups through a private LDS region (the patch is
-  // dead by now) so that global traffic is float4 per lane, 16 lanes per pixel row: 256-byte contiguous runs, 4x fewer store
-  // instructions than storing the MFMA layout directly (the dword-per-lane form is store-issue bound)
+  // ---- epilogue: every wave transposes its four 32-pixel x 32-channel accumulator groups through a private LDS region (the patch is
+  // dead by now) so that global traffic is float4 per lane, 8 lanes per pixel row: 128-byte contiguous runs (one cache line), 4x fewer
+  // store instructions than storing the MFMA layout directly (the dword-per-lane form is store-issue bound)
   const long long Mtot = (long long)P.N * P.H * P.W;
   const float oscale = NS == 4 ? P.woscale / ascale : 1.0f;      // exact: powers of two
   if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
   __syncthreads();                                        // all waves are done reading the patch
   float* tw = reinterpret_cast<float*>(smem) + wv * (32 * EPW);
-  const int er = lane >> 4, ec = (lane & 15) * 4;         // read side: row within a group of 4, first of 4 channels
-  const int colb = n0 + wn * 64 + ec;
+  const int er = lane >> 3, ec = (lane & 7) * 4;          // read side: row within a group of 8, first of 4 channels
+  const int colb = n0 + wn * 32 + ec;
+  const int colc = colb < P.Nout ? colb : 0;              // clamped column for the operand loads of lanes that store nothing
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (P.splits == 1 && colb < P.Nout) {          // Nout % 4 == 0: the four columns are valid together
     if (P.bias) bias4 = *reinterpret_cast<const float4*>(P.bias + colb);
     if (P.bias_x) { const float4 u = *reinterpret_cast<const float4*>(P.bias_x + colb); bias4.x += u.x; bias4.y += u.y; bias4.z += u.z; bias4.w += u.w; }
   }
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int g = wm * 2 + a, bx = g & 3;
-    // destination rows of the 8 float4 this lane stores, and the residual / accumulate operands: all loads are issued up front
-    // so that their latency runs under the LDS transposition instead of serialising the 8 stores
-    long long rowv[8];
-    float4 rv[8];
+  for (int a = 0; a < 4; ++a) {
+    const int g = wm * 4 + a, bx = g & 3;
+    // destination rows of the 4 float4 this lane stores, and the residual / accumulate operands: all loads are issued up front
+    // so that their latency runs under the LDS transposition instead of serialising the stores
+    long long rowv[4];
+    float4 rv[4];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int i = it * 4 + er;
+    for (int it = 0; it < 4; ++it) {
+      const int i = it * 8 + er;
       const int oy = y0 + (g >> 2) * 8 + (i >> 2);
       const int ox = W8 ? (bx & 1) * 4 + (i & 3) : x0 + bx * 4 + (i & 3);
       const int im = W8 ? img + (bx >> 1) : img;
@@ -367,33 +383,31 @@ __global__ void __launch_bounds__(PTH * 32) conv3x3p_kernel(const PatchParams P)
       rv[it] = bias4;
     }
     // residual / accumulate operands: wave-uniform conditions, per-lane addresses clamped to row 0 / column 0 where the lane has nothing to
-    // store -- eight independent loads in flight per operand instead of eight load -> wait round trips behind exec-mask branches
+    // store -- independent loads in flight instead of load -> wait round trips behind exec-mask branches
     if (P.splits == 1 && P.res_mode) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < 4; ++it) {
         long long rrow = rowv[it] < 0 ? 0 : rowv[it];
         if (P.res_mode == 2) {
           const int ox2 = (int)(rrow % P.W); const long long t2 = rrow / P.W; const int oy2 = (int)(t2 % P.H); const long long im2 = t2 / P.H;
           rrow = (im2 * (P.H >> 1) + (oy2 >> 1)) * (P.W >> 1) + (ox2 >> 1);
         }
-        const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + (colb < P.Nout ? colb : 0));
+        const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + colc);
         rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
     if (P.splits == 1 && P.accumulate) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const float4 u = *reinterpret_cast<const float4*>(P.y + (rowv[it] < 0 ? 0 : rowv[it]) * P.Nout + (colb < P.Nout ? colb : 0));
+      for (int it = 0; it < 4; ++it) {
+        const float4 u = *reinterpret_cast<const float4*>(P.y + (rowv[it] < 0 ? 0 : rowv[it]) * P.Nout + colc);
         rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + li] = NS == 4 ? acc[a][r] * oscale : acc[a][r];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + b * 32 + li] = NS == 4 ? acc[a][b][r] * oscale : acc[a][b][r];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * EPW + ec]);
+    for (int it = 0; it < 4; ++it) {
+      float4 v = *reinterpret_cast<const float4*>(&tw[(it * 8 + er) * EPW + ec]);
       if (rowv[it] < 0) continue;
       if (P.splits > 1) { *reinterpret_cast<float4*>(P.slab + ((long long)sp * Mtot + rowv[it]) * P.Nout + colb) = v; continue; }
       v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
@@ -432,7 +446,7 @@ __global__ void __launch_bounds__(256) conv3x3p_reduce_kernel(const PatchParams 
 template <int NS, int PTH, bool W8, bool GN = false> static int launch_ns(const PatchParams& P, hipStream_t s) {
   constexpr int NPIX = (PTH + 2) * PPW;
   size_t smem = (size_t)(NPL(NS) * PPLANE(NPIX)) * sizeof(unsigned short);
-  const size_t epi = (size_t)(PTH / 2) * 32 * EPW * sizeof(float);        // one 32 x 68 fp32 tile per wave
+  const size_t epi = (size_t)(PTH / 2) * 32 * EPW * sizeof(float);        // one 32 x 36 fp32 tile per wave
   if (smem < epi) smem = epi;
   static bool attr_set = false;
   if (!attr_set) {

@@ -108,7 +108,11 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
   const int a = wv >> 1, kh = wv & 1;        // output-channel tile, k-chunk parity
   const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
 
-  int bid = blockIdx.x;
+  // XCD-aware bijective block order (block b runs on XCD b % 8, each XCD has its own L2): consecutive LOGICAL ids share an XCD, and the
+  // ci_chunk index runs fastest, so the C/32 blocks that stream the same dY tiles (and the Cout/128 blocks that stream the same X patches)
+  // hit in one L2 instead of fetching the tensor once per XCD
+  const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
   const int ci_chunk = bid % P.ci_chunks; bid /= P.ci_chunks;
   const int co_tile = bid % P.co_tiles; const int split = bid / P.co_tiles;
   const int ci0 = ci_chunk * 32, co0 = co_tile * 128;

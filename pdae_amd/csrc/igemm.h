@@ -77,6 +77,7 @@ int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, l
                    const float* amax = nullptr);
 
 // skinny.hip: M <= 32 linear layers (one wave per output feature)
+int skinny_group_launch(const void* items, const int* first, int n_items, int total, int M, int K, hipStream_t s);
 bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch);
 int skinny_launch(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, const float* bias, int M, int N, int K,
                   int accumulate, hipStream_t s);

@@ -12,18 +12,15 @@
 
 #define SK_M 32
 
-__global__ void __launch_bounds__(256) skinny_nt_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
-                                                        float* __restrict__ C, long long ldc, const float* __restrict__ bias, int M, int N, int K,
-                                                        int accumulate) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
+// one wave: feature n of C = A B^T (+ bias); Brow = B + n * ldb
+__device__ __forceinline__ void skinny_feature(const float* __restrict__ A, long long lda, const float* __restrict__ Brow, float* __restrict__ C,
+                                               long long ldc, const float* __restrict__ bias, int n, int M, int K, int accumulate, int lane) {
   float acc[SK_M];
 #pragma unroll
   for (int m = 0; m < SK_M; ++m) acc[m] = 0.f;
   for (int k0 = lane * 8; k0 < K; k0 += 512) {
-    const float4 b0 = *reinterpret_cast<const float4*>(B + (long long)n * ldb + k0);
-    const float4 b1 = *reinterpret_cast<const float4*>(B + (long long)n * ldb + k0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(Brow + k0);
+    const float4 b1 = *reinterpret_cast<const float4*>(Brow + k0 + 4);
 #pragma unroll
     for (int m = 0; m < SK_M; ++m) {
       if (m < M) {
@@ -56,6 +53,35 @@ __global__ void __launch_bounds__(256) skinny_nt_kernel(const float* __restrict_
     float* dst = C + m * ldc + n;
     *dst = accumulate ? *dst + v : v;
   }
+}
+
+__global__ void __launch_bounds__(256) skinny_nt_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
+                                                        float* __restrict__ C, long long ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                        int accumulate) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  skinny_feature(A, lda, B + (long long)n * ldb, C, ldc, bias, n, M, K, accumulate, threadIdx.x & 63);
+}
+
+// A whole family of linear layers in ONE launch: y_i[M][n_i] = x_i[M][K] W_i[n_i][K]^T + b_i for i < n_items (every ResBlock's
+// emb_layers / emb_z_layers Linear of a network pass: they all read SiLU(emb) / SiLU(shift_emb), which exist before the first block runs --
+// the reference issues them one by one inside each block, model/module.py:287-293,371-380).  items / first are DEVICE arrays; first[i] = index
+// of item i's first feature in the concatenated feature list (first[n_items] = total).  One wave per feature, located by binary search.
+struct LinearItem { const float* x; const float* w; const float* bias; float* y; int n_out; int pad; };
+__global__ void __launch_bounds__(256) skinny_group_kernel(const LinearItem* __restrict__ items, const int* __restrict__ first, int n_items, int total,
+                                                           int M, int K) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= total) return;
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (first[mid] <= f) lo = mid; else hi = mid - 1; }
+  const LinearItem it = items[lo];
+  const int n = f - first[lo];
+  skinny_feature(it.x, K, it.w + (long long)n * K, it.y, it.n_out, it.bias, n, M, K, 0, threadIdx.x & 63);
+}
+
+int skinny_group_launch(const void* items, const int* first, int n_items, int total, int M, int K, hipStream_t s) {
+  hipLaunchKernelGGL(skinny_group_kernel, dim3((total + 3) / 4), dim3(256), 0, s, (const LinearItem*)items, first, n_items, total, M, K);
+  return pdae_launch_status("linear_group");
 }
 
 bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch) {

@@ -155,6 +155,7 @@ class Builder:
         self.math = H.MATH_NAMES[H.default_math()] if math is None else (H.MATH_NAMES[math] if isinstance(math, str) else int(math))
         self.P = params
         self.Gr = grads or {}
+        self._emb = {}            # weight-name prefix -> (y, ctx) of linears already computed by prefetch_emb
         self.save = save          # keep activations for backward (else buffers are recycled)
         self.drop_p = drop_p
         self.drop_layers = 0
@@ -238,7 +239,7 @@ class Builder:
             self.p.need_ws(wsb)
             # the bias gradient rides along: the 3x3 kernel sums dY while staging it, the other paths run the column sum themselves
             ride = self.fuse_db
-            am = (amax if amax is not None else self.dy_amax(c, dy)) if c.KH == 3 else None   # generic 1x1 wgrad: no fp16 format
+            am = ((amax if (amax is not None and self.amax_ok(c)) else self.dy_amax(c, dy))) if c.KH == 3 else None   # generic 1x1 wgrad: no fp16 format
             self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am), ws_slot=4,
                         wsb_slot=len(c.fields()) + 1)
             if am is not None:
@@ -256,7 +257,7 @@ class Builder:
         w = self.P[cx.wname + ".weight"]
         dx = out if out is not None else self.p.buf(c.N, c.Hl, c.Wl, ci_cnt)
         whole = ci_off == 0 and ci_cnt == c.Cin
-        am = (amax if amax is not None else self.dy_amax(c, dy)) if (whole or c.KH == 1) else None
+        am = (amax if (amax is not None and self.amax_ok(c)) else self.dy_amax(c, dy)) if (whole or c.KH == 1) else None
         wp_t = self._wprep(c, w, 1, f16_grad=am is not None) if (whole or (c.KH == 1 and ci_off % 32 == 0 and ci_cnt % 4 == 0)) else None
         if wp_t is None:
             am = None
@@ -273,6 +274,35 @@ class Builder:
         y = self.p.buf(Nb, out)
         self.p.emit(H.op_gemm(0, 1, Nb, out, K, x, K, w, K, y, out, bias=b))
         return y, NS(x=x, wname=wname, Nb=Nb, K=K, out=out)
+
+    def linear_group(self, jobs):
+        """jobs = [(x [Nb,K], weight-name prefix)]: every  y = x W^T + b  in ONE launch (pdae_linear_group).  Returns [(y, ctx)] with the same
+        ctx objects linear() produces, so linear_bwd works unchanged.  Falls back to single launches when the shapes do not fit the kernel."""
+        if not jobs:
+            return []
+        Nb, K = jobs[0][0].shape
+        fits = Nb <= 32 and K % 8 == 0 and all(x.shape == (Nb, K) for x, _ in jobs) and os.environ.get("PDAE_GROUP_LINEAR", "1") != "0"
+        if not fits:
+            return [self.linear(x, w) for x, w in jobs]
+        out, items = [], []
+        for x, wname in jobs:
+            w, b = self.P[wname + ".weight"], self.P[wname + ".bias"]
+            assert w.numel() == w.shape[0] * K, (wname, tuple(w.shape), K)
+            y = self.p.buf(Nb, w.shape[0])
+            items.append((x, w, b, y))
+            out.append((y, NS(x=x, wname=wname, Nb=Nb, K=K, out=w.shape[0])))
+        it, first, total = H.linear_group_tables(items, self.p.device)
+        self.p.live.extend([it, first])                  # the device tables live as long as the plan
+        self.p.emit(H.op_linear_group(it, first, len(items), total, Nb, K))
+        return out
+
+    def prefetch_emb(self, ea, prefixes, eza=None, z_prefixes=()):
+        """All emb_layers (input SiLU(emb)) and emb_z_layers (input SiLU(shift_emb)) Linear layers of the listed ResBlocks in one launch;
+        resblock() picks its (scale, shift) vectors up from here."""
+        jobs = [(ea, p + ".emb_layers.1") for p in prefixes] + [(eza, p + ".emb_z_layers.1") for p in z_prefixes]
+        res = self.linear_group(jobs)
+        for (x, wname), r in zip(jobs, res):
+            self._emb[wname] = r
 
     def linear_bwd(self, lx, dy, dx=None, dx_acc=0):
         """dW = dy^T x, db = colsum(dy), optionally dx (+)= dy W."""
@@ -422,10 +452,10 @@ class Builder:
             h1, c1 = self.conv(g1.y, None, pre + ".in_layers.2", 3, up=up)
             if not self.save:
                 pl.free(g1.y)
-        ss, l_ss = self.linear(ea, pre + ".emb_layers.1")
+        ss, l_ss = self._emb.pop(pre + ".emb_layers.1", None) or self.linear(ea, pre + ".emb_layers.1")
         zss, l_zss = (None, None)
         if eza is not None:
-            zss, l_zss = self.linear(eza, pre + ".emb_z_layers.1")
+            zss, l_zss = self._emb.pop(pre + ".emb_z_layers.1", None) or self.linear(eza, pre + ".emb_z_layers.1")
         cs = g2 = c2 = out = None
         skip = (x0, x1, pre + ".skip_connection") if has_skip else None
         res, res_mode = None, 0
@@ -462,22 +492,24 @@ class Builder:
             pl.free(g1.xpool)
         return out, NS(pre=pre, g1=g1, c1=c1, l_ss=l_ss, l_zss=l_zss, g2=g2, c2=c2, cs=cs, up=up, down=down, has_skip=has_skip, h1=h1)
 
-    def resblock_bwd(self, r, dout, need_dx0=True, need_dx1=False, d_ea=None, d_eza=None):
-        """Returns (dx0, dx1).  d_ea / d_eza: accumulators [N,E] for d SiLU(emb) / d SiLU(shift_emb) (or None)."""
+    def resblock_bwd(self, r, dout, need_dx0=True, need_dx1=False, d_ea=None, d_eza=None, dout_amax=None, out_amax=False):
+        """Returns (dx0, dx1, amax0).  d_ea / d_eza: accumulators [N,E] for d SiLU(emb) / d SiLU(shift_emb) (or None).
+        dout_amax: device scalar max|dout| when the producer of dout already knows it (saves the separate pdae_amax pass);
+        out_amax: also return max|dx0| -- it falls out of the final GroupNorm-backward apply pass -- for the consumer of dx0."""
         pl = self.p
         g1, g2 = r.g1, r.g2
         C0, C1 = g1.C0, g1.C1
         # conv2
-        self.conv_bwd_params(r.c2, dout)
-        d_a2 = self.conv_dgrad(r.c2, dout)
+        self.conv_bwd_params(r.c2, dout, amax=dout_amax)
+        d_a2 = self.conv_dgrad(r.c2, dout, amax=dout_amax)
         # channel-changing skip: 1x1 conv over the raw (concat) input
         dx0 = dx1 = None
         if r.has_skip:
             self.conv_bwd_params(r.cs, dout)
             if need_dx0:
-                dx0 = self.conv_dgrad(r.cs, dout, ci_off=0, ci_cnt=C0)
+                dx0 = self.conv_dgrad(r.cs, dout, ci_off=0, ci_cnt=C0, amax=dout_amax)
             if need_dx1:
-                dx1 = self.conv_dgrad(r.cs, dout, ci_off=C0, ci_cnt=C1)
+                dx1 = self.conv_dgrad(r.cs, dout, ci_off=C0, ci_cnt=C1, amax=dout_amax)
         # AdaGN + SiLU (+dropout)
         dh1 = pl.buf(*r.h1.shape)
         am1 = pl.buf(4) if self.amax_ok(r.c1.c) else None      # max|dh1| falls out of the GroupNorm-backward apply pass
@@ -498,11 +530,14 @@ class Builder:
                 dx0 = pl.buf(g1.N, g1.H, g1.W, C0)
             if need_dx1 and dx1 is None:
                 dx1 = pl.buf(g1.N, g1.H, g1.W, C1)
+            am0 = pl.buf(4) if (out_amax and need_dx0 and self.f16_grads) else None
             self.gn_bwd(g1, d_a1, bmode, add=None if r.has_skip else dout, dx0=dx0 if need_dx0 else None, acc0=int(r.has_skip),
-                        dx1=dx1 if need_dx1 else None, acc1=int(r.has_skip))
+                        dx1=dx1 if need_dx1 else None, acc1=int(r.has_skip), dx0_amax=am0)
             pl.free(d_a1)
+        else:
+            am0 = None
         pl.free(dh1, am1)
-        return dx0, dx1
+        return dx0, dx1, am0
 
     # ------------------------------------------------------------------ AttentionBlock
     def attention(self, pre, x, heads, new_order):
@@ -534,12 +569,13 @@ class Builder:
         return out, NS(pre=pre, gx=gx, cq=cq, cp=cp, qkv=qkv, Pm=Pm, o=o, N=N, T=T, C=C, heads=heads, ch=ch, offs=(oq, ok, ov, hs), scale2=scale2,
                        shape=(N, Hh, W, C))
 
-    def attention_bwd(self, a, dout, need_dx=True):
+    def attention_bwd(self, a, dout, need_dx=True, dout_amax=None, out_amax=False):
+        """Returns (dx, amax of dx or None); dout_amax / out_amax as in resblock_bwd."""
         pl = self.p
         N, T, C, heads, ch = a.N, a.T, a.C, a.heads, a.ch
         oq, ok, ov, hs = a.offs
         self.conv_bwd_params(a.cp, dout)
-        d_o = self.conv_dgrad(a.cp, dout)                          # [N,H,W,C]
+        d_o = self.conv_dgrad(a.cp, dout, amax=dout_amax)          # [N,H,W,C]
         dqkv = pl.buf(*a.qkv.shape)
         dP = pl.buf(N * heads, T, T)
         qp, kp, vp = a.qkv.data_ptr() + 4 * oq, a.qkv.data_ptr() + 4 * ok, a.qkv.data_ptr() + 4 * ov
@@ -557,13 +593,14 @@ class Builder:
         pl.emit(H.op_gemm(1, 0, T, ch, T, dP, T, qp, 3 * C, dkp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
         pl.free(d_o, dP)
         self.conv_bwd_params(a.cq, dqkv)
-        dx = None
+        dx = am = None
         trainable_norm = (a.pre + ".norm.weight") in self.Gr
         if need_dx or trainable_norm:
             d_xn = self.conv_dgrad(a.cq, dqkv)
             if need_dx:
                 dx = pl.buf(*a.shape)
-            self.gn_bwd(a.gx, d_xn, 0, add=dout, dx0=dx)
+                am = pl.buf(4) if (out_amax and self.f16_grads) else None
+            self.gn_bwd(a.gx, d_xn, 0, add=dout, dx0=dx, dx0_amax=am)
             pl.free(d_xn)
         pl.free(dqkv)
-        return dx
+        return dx, am

@@ -230,6 +230,13 @@ def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shif
     if shift:
         semb, l_lab = B.linear(z, "label_emb")
         eza = B.silu(semb)
+    # every ResBlock's emb_layers / emb_z_layers Linear in one launch (they only depend on the embeddings computed above)
+    def res_prefixes(pre, blocks):
+        return [f"{pre}.{i}.{j}" if isinstance(blocks[0], list) else f"{pre}.{j}" for i, layers in enumerate(blocks if isinstance(blocks[0], list) else [blocks])
+                for j, (kind, d) in enumerate(layers) if kind == "res"]
+    plain = res_prefixes("input_blocks", inputs) + res_prefixes("middle_block", middle) + res_prefixes("output_blocks", outputs)
+    shifted = (res_prefixes("shift_middle_block", middle) + res_prefixes("shift_output_blocks", outputs)) if shift else []
+    B.prefetch_emb(ea, plain + shifted, eza, shifted)
     hs, in_ctx = [], []
     h = x
     for i, layers in enumerate(inputs):
@@ -277,36 +284,43 @@ def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shif
 
 
 # ---------------------------------------------------------------------------------- backward graphs
-def _block_backward(B, ctxs, dout, d_ea, d_eza, need_dx0_first=True, need_dx1_first=False):
-    """Backward through one TimestepSequential.  Returns (dx0, dx1) of the block's first layer."""
+def _block_backward(B, ctxs, dout, d_ea, d_eza, need_dx0_first=True, need_dx1_first=False, dout_amax=None, out_amax=False):
+    """Backward through one TimestepSequential.  Returns (dx0, dx1, amax of dx0 or None) of the block's first layer.
+    dout_amax: device scalar max|dout| from the producer of dout; out_amax: the caller hands dx0 UNMODIFIED to the next backward stage and
+    wants its abs-max (it falls out of the last GroupNorm-backward pass: no separate pdae_amax launch)."""
     pl = B.p
     dx1 = None
+    am = dout_amax
     for j in range(len(ctxs) - 1, -1, -1):
         kind, c = ctxs[j]
         first = j == 0
         need0 = (not first) or need_dx0_first
+        want = (not first) or out_amax                   # inside the block dx0 always flows straight into the next layer
         if kind == "res":
-            dx0, d1 = B.resblock_bwd(c, dout, need_dx0=need0, need_dx1=first and need_dx1_first, d_ea=d_ea, d_eza=d_eza)
+            dx0, d1, am_next = B.resblock_bwd(c, dout, need_dx0=need0, need_dx1=first and need_dx1_first, d_ea=d_ea, d_eza=d_eza, dout_amax=am, out_amax=want)
             if first:
                 dx1 = d1
         elif kind == "attn":
-            dx0 = B.attention_bwd(c, dout, need_dx=need0)
+            dx0, am_next = B.attention_bwd(c, dout, need_dx=need0, dout_amax=am, out_amax=want)
         else:
             B.conv_bwd_params(c, dout)
             dx0 = B.conv_dgrad(c, dout) if need0 else None
-        pl.free(dout)
-        dout = dx0
-    return dout, dx1
+            am_next = None
+        pl.free(dout, am)
+        dout, am = dx0, am_next
+    return dout, dx1, am
 
 
 def _head_backward(B, hd, dy):
+    """Returns (dh, max|dh| device scalar or None)."""
     pl = B.p
     B.conv_bwd_params(hd.c, dy)
     d_a = B.conv_dgrad(hd.c, dy)
     dh = pl.buf(hd.g.N, hd.g.H, hd.g.W, hd.g.C0)
-    B.gn_bwd(hd.g, d_a, 0, dx0=dh)
+    am = pl.buf(4) if B.f16_grads else None
+    B.gn_bwd(hd.g, d_a, 0, dx0=dh, dx0_amax=am)
     pl.free(d_a)
-    return dh
+    return dh, am
 
 
 def shift_backward(B, fx, d_shift, mark=None):
@@ -317,12 +331,13 @@ def shift_backward(B, fx, d_shift, mark=None):
     mark = mark or (lambda prefix: None)
     N, E = fx.semb.shape
     d_eza = pl.buf(N, E, zero=True)
-    dh = _head_backward(B, fx.shead, d_shift)
+    dh, am = _head_backward(B, fx.shead, d_shift)
     mark("shift_out.")
     for i in range(len(fx.sout_ctx) - 1, -1, -1):
-        dh, _ = _block_backward(B, fx.sout_ctx[i], dh, None, d_eza)
+        dh, _, am = _block_backward(B, fx.sout_ctx[i], dh, None, d_eza, dout_amax=am, out_amax=True)
         mark(f"shift_output_blocks.{i}.")
-    _block_backward(B, fx.smid_ctx, dh, None, d_eza, need_dx0_first=False)
+    _, _, am = _block_backward(B, fx.smid_ctx, dh, None, d_eza, need_dx0_first=False, dout_amax=am)
+    pl.free(am)
     mark("shift_middle_block.")
     d_semb = pl.buf(N, E)
     pl.emit(H.op_silu_bwd(fx.semb, d_eza, d_semb, N * E))
@@ -339,18 +354,20 @@ def unet_backward(B, fx, d_eps):
     t = fx.tctx
     N, E = t.emb.shape
     d_ea = pl.buf(N, E, zero=True)
-    dh = _head_backward(B, fx.head, d_eps)
+    dh, am = _head_backward(B, fx.head, d_eps)
     n_in = len(fx.in_ctx)
     d_skip = [None] * n_in
     for i in range(len(fx.out_ctx) - 1, -1, -1):
-        dh, dx1 = _block_backward(B, fx.out_ctx[i], dh, d_ea, None, need_dx1_first=True)
+        dh, dx1, am = _block_backward(B, fx.out_ctx[i], dh, d_ea, None, need_dx1_first=True, dout_amax=am, out_amax=True)
         d_skip[n_in - 1 - i] = dx1
-    dh, _ = _block_backward(B, fx.mid_ctx, dh, d_ea, None)
+    dh, _, am = _block_backward(B, fx.mid_ctx, dh, d_ea, None, dout_amax=am)
+    pl.free(am)
     for k in range(n_in - 1, -1, -1):
         g = d_skip[k]
-        pl.emit(H.op_axpby(dh, g, dh.numel(), 1.0, 1.0))
+        pl.emit(H.op_axpby(dh, g, dh.numel(), 1.0, 1.0))         # the skip gradient joins: the sum's abs-max is not known, pdae_amax runs
         pl.free(dh)
-        dh, _ = _block_backward(B, fx.in_ctx[k], g, d_ea, None, need_dx0_first=(k > 0))
+        dh, _, am = _block_backward(B, fx.in_ctx[k], g, d_ea, None, need_dx0_first=(k > 0))
+        pl.free(am)
     # time embedding MLP (+ class embedding table)
     d_emb = pl.buf(N, E)
     pl.emit(H.op_silu_bwd(t.emb, d_ea, d_emb, N * E))
@@ -412,7 +429,7 @@ def encoder_backward(B, ex, dz):
             dprev = pl.buf(c.N, c.H, c.W, c.C0)
             B.gn_bwd(c, dh, 0, dx0=dprev)
         elif kind == "attn":
-            dprev = B.attention_bwd(c, dh, need_dx=True)
+            dprev, _ = B.attention_bwd(c, dh, need_dx=True)
         else:
             B.conv_bwd_params(c, dh)
             dprev = B.conv_dgrad(c, dh) if j > 0 else None

@@ -1,7 +1,7 @@
 """Times a few 3x3 launches (B=32) under the product library and the probe variants (tools/probe_build.py)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if len(sys.argv) > 1 and sys.argv[1] == "child":
+if os.environ.get("P3_CHILD"):
     sys.path.insert(0, ROOT)
     import torch
     from pdae_amd import hip as H
@@ -21,10 +21,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         H.run(H.op_conv_wprep(c, w, 0, wp))
         ms = t(H.op_conv_fwd(c, x, None, w, None, y, wp=wp))
         out.append(f"{C}->{Cout}@{S}: {ms:.3f} ms {2.0*N*S*S*Cout*9*C/ms/1e9:6.1f} TF")
-    print(os.environ.get("PDAE_HIP_LIB", "product").split("/")[-2], " | ".join(out), flush=True)
+    print((os.environ.get("PDAE_HIP_LIB") or "x/product/x").split("/")[-2], " | ".join(out), flush=True)
 else:
-    for v in ["", "nob", "noa", "nostage", "mfma"]:
+    for v in (sys.argv[1:] or ["", "nob", "noa", "nostage", "mfma", "ilv"]):
         env = dict(os.environ)
         if v:
             env["PDAE_HIP_LIB"] = os.path.join(ROOT, "pdae_amd", "lib", "probe_" + v, "libpdae_hip.so")
-        subprocess.call([sys.executable, os.path.abspath(__file__), "child"], env=env)
+        env["P3_CHILD"] = "1"
+        subprocess.call([sys.executable, os.path.abspath(__file__)], env=env)

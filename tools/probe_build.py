@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pdae_amd.build import CSRC, LIBDIR, SOURCES, HIPCC, FLAGS
 VARIANTS = {"nob": ["-DPDAE_PROBE_NOB"], "noa": ["-DPDAE_PROBE_NOA"], "nostage": ["-DPDAE_PROBE_NOSTAGE"],
-            "mfma": ["-DPDAE_PROBE_NOB", "-DPDAE_PROBE_NOA", "-DPDAE_PROBE_NOSTAGE"]}
+            "mfma": ["-DPDAE_PROBE_NOB", "-DPDAE_PROBE_NOA", "-DPDAE_PROBE_NOSTAGE"], "clustered": ["-DPDAE_P3_CLUSTERED"]}
 for name, defs in VARIANTS.items():
     d = os.path.join(LIBDIR, "probe_" + name)
     os.makedirs(d, exist_ok=True)
