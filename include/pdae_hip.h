@@ -185,6 +185,18 @@ int pdae_ddim_step_rows(const float* x, const float* eps, const float* g, const 
 int pdae_ddpm_step_rows(const float* x, const float* eps, const float* g, const float* noise, const float* learned_range, const float* coef, int N,
                         size_t per_sample, float* out, pdae_stream_t stream);
 
+/* ---- fused attention core of AttentionBlock (module.py:422-428, QKVAttentionLegacy :431-457 / QKVAttention :460-488) and its backward.
+ * qkv [N][T][3C] (T = H*W pixels, the output of the qkv 1x1 convolution in NHWC), out [N][T][C]; new_order = use_new_attention_order
+ * ([q(all heads)|k|v] channel blocks instead of per-head [q|k|v]).  softmax(q k^T / sqrt(ch)) v per (image, head) in ONE launch: the
+ * T x T probabilities never leave the CU.  lse [N*heads][T] (log-sum-exp of the scaled scores; NULL when no backward follows) is all the
+ * backward needs besides qkv / out: it recomputes the probabilities.  ws of pdae_attn_bwd: N*heads*T floats.  Exact fp32 (f32 MFMA).
+ * Supported: T in {64,128,192,256}, head width C/heads a multiple of 32 (pdae_attn_fused_ok); other shapes: the strided-batched pdae_gemm +
+ * pdae_softmax composition. */
+int pdae_attn_fused_ok(int T, int C, int heads);
+int pdae_attn_fwd(const float* qkv, int N, int T, int C, int heads, int new_order, float* out, float* lse, pdae_stream_t stream);
+int pdae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* d_out, int N, int T, int C, int heads, int new_order, float* dqkv,
+                  void* ws, pdae_stream_t stream);
+
 /* ---- evaluator (sampler/autoencoding_eval.py:83-99): per-image SSIM and MSE of two (N,C,H,W)-shaped batches of ANY strides in one pass.
  * Both inputs are mapped v -> v*mul + add first (the (x+1)/2 of autoencoding_eval.py:83-88: mul = add = 0.5).  SSIM = metric/utils.py:35-57
  * (11-tap Gaussian window, given normalised as window11 so that the caller controls its rounding; zero padding; C1 = 1e-4, C2 = 9e-4; mean over
@@ -218,7 +230,8 @@ enum {
   PDAE_OP_GN_BWD, PDAE_OP_TEMB, PDAE_OP_SILU, PDAE_OP_SILU_BWD, PDAE_OP_AXPBY, PDAE_OP_EMBEDDING, PDAE_OP_EMBEDDING_BWD, PDAE_OP_TO_NHWC,
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
   PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
-  PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP
+  PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP,
+  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD
 };
 typedef struct pdae_op {
   int32_t kind;

@@ -427,6 +427,20 @@ extern "C" int pdae_adam_ema(float* p, const float* g, float* m, float* v, float
   return k_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay, guard, count_skip, S(stream));
 }
 
+// ---- fused attention core
+extern "C" int pdae_attn_fused_ok(int T, int C, int heads) { return (heads > 0 && C % heads == 0 && attn_fused_ok(T, C / heads, C, heads)) ? 1 : 0; }
+extern "C" int pdae_attn_fwd(const float* qkv, int N, int T, int C, int heads, int new_order, float* out, float* lse, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(qkv && out && N > 0 && N < 65536 && heads > 0 && heads < 65536, "attn_fwd: bad arguments");
+  PDAE_CHECK_ARG(pdae_attn_fused_ok(T, C, heads), "attn_fwd: shape not supported by the fused kernel (T in {64,128,192,256}, head width %% 32 == 0): T=%d C=%d heads=%d", T, C, heads);
+  return k_attn_fwd(qkv, N, T, C, heads, new_order, out, lse, S(stream));
+}
+extern "C" int pdae_attn_bwd(const float* qkv, const float* out, const float* lse, const float* d_out, int N, int T, int C, int heads, int new_order,
+                             float* dqkv, void* ws, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(qkv && out && lse && d_out && dqkv && ws && N > 0 && N < 65536 && heads > 0 && heads < 65536, "attn_bwd: bad arguments");
+  PDAE_CHECK_ARG(pdae_attn_fused_ok(T, C, heads), "attn_bwd: shape not supported by the fused kernel: T=%d C=%d heads=%d", T, C, heads);
+  return k_attn_bwd(qkv, out, lse, d_out, N, T, C, heads, new_order, dqkv, (float*)ws, S(stream));
+}
+
 // ---- evaluator + input pipeline
 extern "C" size_t pdae_ssim_mse_workspace_bytes(int N, int C, int H, int W) { return k_ssim_mse_workspace_floats(N, C, H, W) * sizeof(float); }
 extern "C" int pdae_ssim_mse(const float* a, const int64_t* a_strides, const float* b, const int64_t* b_strides, int N, int C, int H, int W, float mul,
@@ -499,6 +513,8 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_AXPBY_ROWS: return pdae_axpby_rows(F(0), F(1), F(2), F(3), (int)i[0], (size_t)i[1], FM(4), st);
     case PDAE_OP_DDIM_STEP_ROWS: return pdae_ddim_step_rows(F(0), F(1), F(2), F(3), (int)i[0], (size_t)i[1], (int)i[2], FM(4), st);
     case PDAE_OP_DDPM_STEP_ROWS: return pdae_ddpm_step_rows(F(0), F(1), F(2), F(3), F(4), F(5), (int)i[0], (size_t)i[1], FM(6), st);
+    case PDAE_OP_ATTN_FWD: return pdae_attn_fwd(F(0), (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], FM(1), FM(2), st);
+    case PDAE_OP_ATTN_BWD: return pdae_attn_bwd(F(0), F(1), F(2), F(3), (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], FM(4), p[5], st);
     case PDAE_OP_LINEAR_GROUP: return pdae_linear_group((const pdae_linear_item*)p[0], (const int32_t*)p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], st);
     case PDAE_OP_ADAM_EMA:
       return pdae_adam_ema(FM(0), F(1), FM(2), FM(3), FM(4), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (int)i[1],

@@ -55,3 +55,9 @@ size_t k_image_workspace_bytes(int B, int crop_h, int S, int C);
 int k_image_prepare(const unsigned char* src, int B, int Hs, int Ws, int C, int cy, int cx, int ch, int cw, int S, const int* kx, const int* bx, int ksx,
                     const int* ky, const int* by, int ksy, const unsigned char* flip, float* x0, const long long* strides, unsigned char* gts,
                     unsigned char* ws, hipStream_t st);
+
+// attention.hip
+bool attn_fused_ok(int T, int ch, int C, int heads);
+int k_attn_fwd(const float* qkv, int N, int T, int C, int heads, int new_order, float* out, float* lse, hipStream_t st);
+int k_attn_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, int N, int T, int C, int heads, int new_order, float* dqkv,
+               float* dvec, hipStream_t st);

@@ -149,6 +149,7 @@ class Builder:
         self.fuse_db = os.environ.get("PDAE_FUSE_DB", "1") != "0"      # bias gradients ride in the weight-gradient launch
         self.fuse_skip = os.environ.get("PDAE_FUSE_SKIP", "1") != "0"  # ResBlock skip_connection rides in conv2's K loop (conv_skip)
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
+        self.fuse_attn = os.environ.get("PDAE_FUSE_ATTN", "1") != "0"  # QK^T -> softmax -> PV (and its backward) as one kernel (pdae_attn_fwd / _bwd)
         self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
         self._frozen_wp = {}
         self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
@@ -555,19 +556,26 @@ class Builder:
         else:               # per head [q k v]
             oq, ok, ov, hs = 0, ch, 2 * ch, 3 * ch
         scale2 = 1.0 / math.sqrt(ch)          # (ch^-1/4)^2 : q and k are each scaled by ch^-1/4 (module.py:451-453)
-        Pm = pl.buf(N * heads, T, T)
         o = pl.buf(N, Hh, W, C)
-        qp, kp, vp = qkv.data_ptr() + 4 * oq, qkv.data_ptr() + 4 * ok, qkv.data_ptr() + 4 * ov
-        pl.emit(H.op_gemm(0, 1, T, T, ch, qp, 3 * C, kp, 3 * C, Pm, T, alpha=scale2, batch_outer=N, batch_inner=heads,
-                                     sA=(T * 3 * C, hs), sB=(T * 3 * C, hs), sC=(heads * T * T, T * T)))
-        pl.emit(H.op_softmax(Pm, N * heads * T, T))
-        pl.emit(H.op_gemm(0, 0, T, ch, T, Pm, T, vp, 3 * C, o, C, batch_outer=N, batch_inner=heads,
-                                     sA=(heads * T * T, T * T), sB=(T * 3 * C, hs), sC=(T * C, ch)))
+        fused = self.fuse_attn and H.attn_fused_ok(T, C, heads)
+        Pm = lse = None
+        if fused:
+            # QK^T -> softmax -> PV in one launch, probabilities never written (pdae_attn_fwd); only the row log-sum-exp is kept for backward
+            lse = pl.buf(N * heads, T) if self.save else None
+            pl.emit(H.op_attn_fwd(qkv, N, T, C, heads, new_order, o, lse))
+        else:
+            Pm = pl.buf(N * heads, T, T)
+            qp, kp, vp = qkv.data_ptr() + 4 * oq, qkv.data_ptr() + 4 * ok, qkv.data_ptr() + 4 * ov
+            pl.emit(H.op_gemm(0, 1, T, T, ch, qp, 3 * C, kp, 3 * C, Pm, T, alpha=scale2, batch_outer=N, batch_inner=heads,
+                              sA=(T * 3 * C, hs), sB=(T * 3 * C, hs), sC=(heads * T * T, T * T)))
+            pl.emit(H.op_softmax(Pm, N * heads * T, T))
+            pl.emit(H.op_gemm(0, 0, T, ch, T, Pm, T, vp, 3 * C, o, C, batch_outer=N, batch_inner=heads,
+                              sA=(heads * T * T, T * T), sB=(T * 3 * C, hs), sC=(T * C, ch)))
         out, cp = self.conv(o, None, pre + ".proj_out", 1, res=x, res_mode=1)
         if not self.save:
             pl.free(qkv, Pm, o)
-        return out, NS(pre=pre, gx=gx, cq=cq, cp=cp, qkv=qkv, Pm=Pm, o=o, N=N, T=T, C=C, heads=heads, ch=ch, offs=(oq, ok, ov, hs), scale2=scale2,
-                       shape=(N, Hh, W, C))
+        return out, NS(pre=pre, gx=gx, cq=cq, cp=cp, qkv=qkv, Pm=Pm, lse=lse, o=o, N=N, T=T, C=C, heads=heads, ch=ch, offs=(oq, ok, ov, hs), scale2=scale2,
+                       shape=(N, Hh, W, C), new_order=bool(new_order))
 
     def attention_bwd(self, a, dout, need_dx=True, dout_amax=None, out_amax=False):
         """Returns (dx, amax of dx or None); dout_amax / out_amax as in resblock_bwd."""
@@ -577,6 +585,11 @@ class Builder:
         self.conv_bwd_params(a.cp, dout)
         d_o = self.conv_dgrad(a.cp, dout, amax=dout_amax)          # [N,H,W,C]
         dqkv = pl.buf(*a.qkv.shape)
+        if a.lse is not None:                                      # fused backward: probabilities recomputed from q, k and the saved log-sum-exp
+            wsd = pl.buf(N * heads, T)
+            pl.emit(H.op_attn_bwd(a.qkv, a.o, a.lse, d_o, N, T, C, heads, a.new_order, dqkv, wsd))
+            pl.free(d_o, wsd)
+            return self._attention_bwd_tail(a, dout, dqkv, need_dx, out_amax)
         dP = pl.buf(N * heads, T, T)
         qp, kp, vp = a.qkv.data_ptr() + 4 * oq, a.qkv.data_ptr() + 4 * ok, a.qkv.data_ptr() + 4 * ov
         dqp, dkp, dvp = dqkv.data_ptr() + 4 * oq, dqkv.data_ptr() + 4 * ok, dqkv.data_ptr() + 4 * ov
@@ -592,6 +605,10 @@ class Builder:
         pl.emit(H.op_gemm(0, 0, T, ch, T, dP, T, kp, 3 * C, dqp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
         pl.emit(H.op_gemm(1, 0, T, ch, T, dP, T, qp, 3 * C, dkp, 3 * C, alpha=a.scale2, batch_outer=N, batch_inner=heads, sA=bA, sB=bQ, sC=bQ))
         pl.free(d_o, dP)
+        return self._attention_bwd_tail(a, dout, dqkv, need_dx, out_amax)
+
+    def _attention_bwd_tail(self, a, dout, dqkv, need_dx, out_amax):
+        pl = self.p
         self.conv_bwd_params(a.cq, dqkv)
         dx = am = None
         trainable_norm = (a.pre + ".norm.weight") in self.Gr

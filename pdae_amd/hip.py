@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PDAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpdae
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
  OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX,
- OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP) = range(1, 39)
+ OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD) = range(1, 41)
 
 
 class PdaeOp(ctypes.Structure):
@@ -103,7 +103,7 @@ def lib():
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
            "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
-           "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_group", "pdae_q_sample", "pdae_loss",
+           "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
            "pdae_ssim_mse_workspace_bytes", "pdae_ssim_mse", "pdae_image_prepare_workspace_bytes", "pdae_image_prepare"]
 
@@ -305,6 +305,18 @@ def linear_group_tables(items, device):
 
 def op_linear_group(items_t, first_t, n_items, total, M, K):
     return make_op(OP_LINEAR_GROUP, [items_t, first_t], [n_items, total, M, K])
+
+
+def attn_fused_ok(T, C, heads):
+    return bool(lib().pdae_attn_fused_ok(int(T), int(C), int(heads)))
+
+
+def op_attn_fwd(qkv, N, T, C, heads, new_order, out, lse=None):
+    return make_op(OP_ATTN_FWD, [qkv, out, lse], [N, T, C, heads, int(new_order)])
+
+
+def op_attn_bwd(qkv, out, lse, d_out, N, T, C, heads, new_order, dqkv, ws):
+    return make_op(OP_ATTN_BWD, [qkv, out, lse, d_out, dqkv, ws], [N, T, C, heads, int(new_order)])
 
 
 def op_gn_stats(x0, C0, x1, C1, N, HW, G, eps, mean, rstd, ws):
