@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--bucket-mb", type=float, default=0, help="gradient bucket size of the data-parallel all-reduce; 0 = sweep 16/48/96 MB in the "
                                                              "warm-up phase and keep the fastest")
+    ap.add_argument("--native-rccl", action="store_true", help="gradient exchange through the library's own RCCL communicator on HIP streams "
+                                                              "(pdae_allreduce_bucket) instead of torch.distributed.all_reduce")
     ap.add_argument("--dry", action="store_true", help="plumbing check without a GPU: gloo backend, a small network on CPU tensors, kernels "
                                                       "replaced by a no-op recorder (exercises launcher, process group, buckets, JSON)")
     ap.add_argument("--math", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16", "f16x3"],
@@ -204,6 +206,7 @@ def main():
         dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["NCCL_DEBUG"] = os.environ.get("PDAE_NCCL_DEBUG", "WARN")      # RCCL's version banner goes to stdout: keep it to the one JSON line
         if dry:
             dist.init_process_group(backend="gloo")
         else:
@@ -241,7 +244,7 @@ def main():
     log("building the fused step plan")
     st = FusedRLStep(gd, enc, dec, ema_enc, ema_dec, B, size, size, lr=float(oc["lr"]), betas=eval(oc["adam_betas"]), eps=float(oc["adam_eps"]),
                      weight_decay=float(oc["weight_decay"]), ema_decay=float(rc["ema_decay"]), ema_every=int(rc["ema_every"]),
-                     num_iterations=int(rc["num_iterations"]), bucket_mb=args.bucket_mb or 48)
+                     num_iterations=int(rc["num_iterations"]), bucket_mb=args.bucket_mb or 48, native_comm=bool(args.native_rccl) and not dry)
     if dry:
         st.plan.run = lambda first=0, last=None, stream=None: None          # no kernels: launcher / process-group / bucket plumbing only
     log(f"plan: {st.plan.n} ops, {st.plan.bytes_alloc / 2**30:.1f} GiB of activations/workspaces")
@@ -253,7 +256,8 @@ def main():
     if world > 1:
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
-        comm = {"backend": dist.get_backend(), "rccl_ranks": int(ones.item()), "grad_bytes_per_step": int(4 * (dec.flat_grad.numel() + enc.flat_grad.numel()))}
+        comm = {"backend": dist.get_backend(), "exchange": "pdae_allreduce_bucket (own RCCL communicator, side stream)" if st.ncomm is not None else "torch.distributed.all_reduce (async)",
+                "rccl_ranks": int(ones.item()), "grad_bytes_per_step": int(4 * (dec.flat_grad.numel() + enc.flat_grad.numel()))}
         sweep = {}
         for mb in ([args.bucket_mb] if args.bucket_mb else [16, 48, 96]):
             st.buckets = st._make_buckets(st._marks, mb)

@@ -223,6 +223,18 @@ int pdae_adam_ema(float* p, const float* g, float* m, float* v, float* ema, size
                   float weight_decay, int decoupled, float step_size, float inv_sqrt_bc2, float grad_scale, float ema_decay,
                   unsigned int* guard, int count_skip, pdae_stream_t stream);
 
+/* ---- data-parallel gradient exchange: DistributedDataParallel's bucketed all-reduce (train_representation_learning.py:29,39) as plain calls.
+ * One process per GPU.  Rank 0 obtains the 128-byte id (pdae_comm_unique_id) and hands it to the other ranks over the host's control channel;
+ * every rank then calls pdae_comm_init (collective) with the device it will use current.  pdae_allreduce_bucket(comm, buf, count, dtype, op,
+ * stream) reduces `count` elements IN PLACE across the ranks on `stream` (dtype 0 = float32, 1 = int32; op 0 = sum, 1 = max), stream-ordered
+ * like any kernel: enqueue it on a side stream behind an event of the compute stream as soon as a gradient bucket is final, and make the
+ * optimizer wait on an event recorded after the last bucket.  RCCL is dlopen'ed on first use (librccl_path may be NULL: a copy already
+ * mapped into the process -- e.g. PyTorch's -- is preferred, then the system's). */
+int pdae_comm_unique_id(const char* librccl_path, void* id128);
+int pdae_comm_init(const char* librccl_path, const void* id128, int nranks, int rank, void** comm);
+int pdae_allreduce_bucket(void* comm, void* buf, size_t count, int dtype, int op, pdae_stream_t stream);
+int pdae_comm_destroy(void* comm);
+
 /* ---- planned-graph executor: a network pass is a static array of ops, issued back-to-back on one stream
  * with a single host call (replaces the per-module Python dispatch of TimestepSequential, module.py:131-140). */
 enum {

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpdae_hip.so")
-SOURCES = ["api.hip", "igemm.hip", "conv3x3p.hip", "conv3x3w.hip", "conv1x1.hip", "convhead.hip", "skinny.hip", "norm.hip", "mlp.hip", "elementwise.hip", "metric.hip", "image.hip", "attention.hip"]
+SOURCES = ["api.hip", "igemm.hip", "conv3x3p.hip", "conv3x3w.hip", "conv1x1.hip", "convhead.hip", "skinny.hip", "norm.hip", "mlp.hip", "elementwise.hip", "metric.hip", "image.hip", "attention.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
@@ -42,7 +42,7 @@ def build_library(force=False, verbose=True):
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
     if force or procs or _newer(objs, LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

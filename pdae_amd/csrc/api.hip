@@ -427,6 +427,21 @@ extern "C" int pdae_adam_ema(float* p, const float* g, float* m, float* v, float
   return k_adam_ema(p, g, m, v, ema, n, lr, b1, b2, eps, wd, decoupled, step_size, inv_sqrt_bc2, grad_scale, ema_decay, guard, count_skip, S(stream));
 }
 
+// ---- data-parallel gradient exchange (RCCL bound at run time, comm.hip)
+extern "C" int pdae_comm_unique_id(const char* librccl_path, void* id128) {
+  PDAE_CHECK_ARG(id128, "comm_unique_id: null pointer");
+  return k_comm_unique_id(librccl_path, id128);
+}
+extern "C" int pdae_comm_init(const char* librccl_path, const void* id128, int nranks, int rank, void** comm) {
+  PDAE_CHECK_ARG(id128 && comm && nranks > 0 && rank >= 0 && rank < nranks, "comm_init: bad arguments");
+  return k_comm_init(librccl_path, id128, nranks, rank, comm);
+}
+extern "C" int pdae_allreduce_bucket(void* comm, void* buf, size_t count, int dtype, int op, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(comm && buf && count > 0 && (dtype == 0 || dtype == 1) && (op == 0 || op == 1), "allreduce_bucket: bad arguments");
+  return k_allreduce(comm, buf, count, dtype, op, S(stream));
+}
+extern "C" int pdae_comm_destroy(void* comm) { return k_comm_destroy(comm); }
+
 // ---- fused attention core
 extern "C" int pdae_attn_fused_ok(int T, int C, int heads) { return (heads > 0 && C % heads == 0 && attn_fused_ok(T, C / heads, C, heads)) ? 1 : 0; }
 extern "C" int pdae_attn_fwd(const float* qkv, int N, int T, int C, int heads, int new_order, float* out, float* lse, pdae_stream_t stream) {

@@ -61,3 +61,9 @@ bool attn_fused_ok(int T, int ch, int C, int heads);
 int k_attn_fwd(const float* qkv, int N, int T, int C, int heads, int new_order, float* out, float* lse, hipStream_t st);
 int k_attn_bwd(const float* qkv, const float* o, const float* lse, const float* d_o, int N, int T, int C, int heads, int new_order, float* dqkv,
                float* dvec, hipStream_t st);
+
+// comm.hip
+int k_comm_unique_id(const char* librccl_path, void* id128);
+int k_comm_init(const char* librccl_path, const void* id128, int nranks, int rank, void** comm);
+int k_allreduce(void* comm, void* buf, size_t count, int dtype, int op, hipStream_t st);
+int k_comm_destroy(void* comm);

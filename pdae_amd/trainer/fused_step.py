@@ -19,6 +19,7 @@ with one static op list over pre-allocated buffers:
 FusedRegularStep (config #1) and FusedLatentStep (config #5) are the same driver around other graphs.
 """
 import math
+import os
 import random
 import sys
 import time
@@ -36,7 +37,7 @@ class _FusedStep:
     self.n_bwd, self.loss and self._marks) and `_load(*inputs)` (copies one micro-batch into the plan's input buffers)."""
 
     def _init_driver(self, nets, emas, lr, betas, eps, weight_decay, decoupled, ema_decay, ema_every, num_iterations, process_group,
-                     bucket_mb, math):
+                     bucket_mb, math, native_comm=None):
         self.flat_nets = list(nets)
         self.emas = list(emas)
         self.lr, self.b1, self.b2, self.adam_eps, self.wd, self.decoupled = lr, betas[0], betas[1], eps, weight_decay, int(decoupled)
@@ -51,6 +52,14 @@ class _FusedStep:
         self.m = [torch.zeros_like(n.flat_train) for n in self.flat_nets]
         self.v = [torch.zeros_like(n.flat_train) for n in self.flat_nets]
         self.comm_events = None                         # set by enable_comm_timing()
+        # gradient exchange: torch.distributed (ProcessGroupNCCL = RCCL) by default; native_comm / PDAE_NATIVE_RCCL=1 selects the library's own
+        # RCCL communicator driven with HIP streams and events (pdae_amd/comm.py, include/pdae_hip.h: pdae_allreduce_bucket)
+        if native_comm is None:
+            native_comm = os.environ.get("PDAE_NATIVE_RCCL", "0") == "1"
+        self.ncomm = None
+        if native_comm and self.flat_nets[0].device.type == "cuda":
+            from ..comm import NativeComm
+            self.ncomm = NativeComm(self.flat_nets[0].device, group=process_group) if self.world > 1 else NativeComm(self.flat_nets[0].device, 0, 1)
         self.rebuild(math)
 
     # ------------------------------------------------------------------ plan (re)construction
@@ -125,7 +134,7 @@ class _FusedStep:
         if p.drop_ops:
             p.set_dropout(random.getrandbits(31), self.step_count * self.num_iterations + self.micro)   # host RNG: no device sync
         last = self.micro == self.num_iterations - 1
-        if last and self.world > 1:
+        if last and (self.world > 1 or self.ncomm is not None):
             self.backward_with_allreduce(p.run)
         else:
             p.run(0, self.n_bwd)
@@ -143,17 +152,26 @@ class _FusedStep:
         The saturation word travels with the last bucket (MAX) so that every rank takes the same skip decision."""
         works, cur = [], 0
         ev = self.comm_events
+        nc = self.ncomm
         if ev is not None:
             ev["t0"].record()
         for op_idx, view in self.buckets:
             run(cur, op_idx)
             cur = op_idx
-            works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            if nc is not None:
+                nc.all_reduce(view)                      # side stream, behind an event of the compute stream
+            else:
+                works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         run(cur, self.n_bwd)
         if ev is not None:
             ev["bwd_done"].record()
         if self.guard is not None and self.math_name == "f16x3":
-            works.append(dist.all_reduce(self.guard.t[0:1], op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
+            if nc is not None:
+                nc.all_reduce(self.guard.t[0:1], op="max")
+            else:
+                works.append(dist.all_reduce(self.guard.t[0:1], op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
+        if nc is not None:
+            nc.wait()
         for w in works:
             w.wait()
         if ev is not None:
@@ -194,11 +212,11 @@ class _FusedStep:
 class FusedRLStep(_FusedStep):
     def __init__(self, gaussian_diffusion, encoder, decoder, ema_encoder, ema_decoder, batch, height, width, lr=1e-4, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=0.0, decoupled=False, ema_decay=0.9999, ema_every=1, num_iterations=1, process_group=None,
-                 bucket_mb=48, math=None):
+                 bucket_mb=48, math=None, native_comm=None):
         self.gd, self.enc, self.dec, self.ema_enc, self.ema_dec = gaussian_diffusion, encoder, decoder, ema_encoder, ema_decoder
         self.N, self.Hh, self.W = batch, height, width
         self._init_driver([decoder, encoder], [ema_decoder, ema_encoder], lr, betas, eps, weight_decay, decoupled, ema_decay, ema_every,
-                          num_iterations, process_group, bucket_mb, math)
+                          num_iterations, process_group, bucket_mb, math, native_comm)
 
     def _build(self, math):
         gd, encoder, decoder = self.gd, self.enc, self.dec

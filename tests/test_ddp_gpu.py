@@ -101,3 +101,38 @@ def test_two_rank_step_equals_single_process_on_concatenated_batch(monkeypatch):
     for got, ref in ((dec0.flat_train, dec.flat_train), (enc0.flat_train, enc.flat_train), (st0.ema_dec.flat_train, st.ema_dec.flat_train)):
         diff = (got - ref).abs()
         assert float(diff.max()) < 1e-4 and float((diff > 2e-6).float().mean()) < 1e-3 and float(diff.mean()) < 1e-7
+
+
+def test_native_rccl_communicator_single_rank():
+    """The library's own RCCL communicator (pdae_comm_init / pdae_allreduce_bucket, RCCL dlopen'ed) driven through the fused step's bucket
+    path on a side stream: with one rank the all-reduce is the identity, so the step must equal the plain step bit for bit -- what this pins
+    is symbol binding, communicator creation, stream / event ordering and that every bucket goes through the C ABI."""
+    from pdae_amd.trainer import fused_step as FS
+    x0, t, noise = _data(2)
+    enc_a, dec_a, st_a = _build(2)
+    set_calls = []
+    import pdae_amd.comm as comm_mod
+    orig = comm_mod.NativeComm.all_reduce
+
+    def counting(self, view, op="sum"):
+        set_calls.append((view.data_ptr(), view.numel(), op))
+        return orig(self, view, op)
+
+    comm_mod.NativeComm.all_reduce = counting
+    try:
+        enc_b, dec_b = _build(2)[:2]
+        from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+        st_b = FS.FusedRLStep(GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, dec_b.device), enc_b, dec_b, copy.deepcopy(enc_b),
+                              copy.deepcopy(dec_b), 2, 64, 64, bucket_mb=1, native_comm=True)
+        assert st_b.ncomm is not None and st_b.ncomm.world == 1
+        for _ in range(2):
+            la = float(st_a.step(x0, t=t, noise=noise).item())
+            lb = float(st_b.step(x0, t=t, noise=noise).item())
+            assert la == lb
+        torch.cuda.synchronize()
+    finally:
+        comm_mod.NativeComm.all_reduce = orig
+    assert torch.equal(dec_a.flat_train, dec_b.flat_train) and torch.equal(enc_a.flat_train, enc_b.flat_train)
+    floats = [c for c in set_calls if c[2] == "sum"]
+    assert len(floats) == 2 * len(st_b.buckets) and sum(n for _, n, _ in floats) == 2 * (dec_b.flat_grad.numel() + enc_b.flat_grad.numel())
+    st_b.ncomm.close()
