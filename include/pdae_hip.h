@@ -123,8 +123,11 @@ int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int H
                   pdae_stream_t stream);
 /* coef[3][N][C] = (mu, a, b) such that v = a*(x-mu)+b equals (1+zs)*((GN(x))*(1+s)+sh)+zsh; ss/zss = [N][2C] (scale|shift) or NULL */
 /* pdae_gn_stats followed by pdae_gn_coef with the finalize and the coefficient fold in ONE launch (two launches instead of three) */
+/* ticket (pdae_gn_stats_coef, pdae_gn_bwd; optional): N + 1 uint32 words, ZEROED ONCE by the caller and owned by one stream.  With it the
+ * partial-sum kernel's last block per sample runs the finalize stage itself (agent-scope release / acquire hand-off), i.e. statistics +
+ * coefficients are ONE launch and the backward's reduce + finalize + parameter-gradient stages are ONE launch; the words return to zero. */
 int pdae_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma, const float* beta,
-                       const float* ss, const float* zss, float* mean, float* rstd, float* coef, void* ws, pdae_stream_t stream);
+                       const float* ss, const float* zss, float* mean, float* rstd, float* coef, void* ws, uint32_t* ticket, pdae_stream_t stream);
 int pdae_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss,
                  const float* zss, float* coef, pdae_stream_t stream);
 /* y = act(v) * dropmask; act: 0 identity, 1 SiLU.  mode 0: same size; mode 1: y (and xpool = raw x) are 2x2 average pooled. */
@@ -135,7 +138,7 @@ int pdae_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H
 int pdae_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
                 const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p,
                 uint64_t seed, uint64_t offset, const float* add, float* dx0, int acc0, float* dx1, int acc1, float* dgamma, float* dbeta,
-                int acc_param, float* dss, float* dzss, void* ws, float* dx0_amax, pdae_stream_t stream);
+                int acc_param, float* dss, float* dzss, void* ws, float* dx0_amax, uint32_t* ticket, pdae_stream_t stream);
 /* dx0_amax (optional): device scalar that receives max|dx0| -- the dy_amax of the convolution whose output gradient dx0 is (saves the
  * separate pdae_amax pass over it). */
 

@@ -313,9 +313,9 @@ extern "C" int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, i
 }
 extern "C" int pdae_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma,
                                   const float* beta, const float* ss, const float* zss, float* mean, float* rstd, float* coef, void* ws,
-                                  pdae_stream_t stream) {
+                                  uint32_t* ticket, pdae_stream_t stream) {
   PDAE_CHECK_ARG(x0 && gamma && beta && mean && rstd && coef && ws && (C1 == 0 || x1) && (C0 + C1) % G == 0, "gn_stats_coef: bad arguments");
-  return k_gn_stats_coef(x0, C0, x1, C1, N, HW, G, eps, gamma, beta, ss, zss, mean, rstd, coef, (float*)ws, S(stream));
+  return k_gn_stats_coef(x0, C0, x1, C1, N, HW, G, eps, gamma, beta, ss, zss, mean, rstd, coef, (float*)ws, S(stream), ticket);
 }
 extern "C" int pdae_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss,
                             const float* zss, float* coef, pdae_stream_t stream) {
@@ -330,12 +330,13 @@ extern "C" int pdae_gn_apply(const float* x0, int C0, const float* x1, int C1, i
 extern "C" int pdae_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
                            const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode,
                            float drop_p, uint64_t seed, uint64_t offset, const float* add, float* dx0, int acc0, float* dx1, int acc1,
-                           float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, void* ws, float* dx0_amax, pdae_stream_t stream) {
+                           float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, void* ws, float* dx0_amax, uint32_t* ticket,
+                           pdae_stream_t stream) {
   PDAE_CHECK_ARG(x0 && coef && rstd && gamma && beta && dA && ws && (C1 == 0 || x1), "gn_bwd: null pointer");
   PDAE_CHECK_ARG(mode >= 0 && mode <= 2 && (mode != 1 || ((H % 2) == 0 && (W % 2) == 0)), "gn_bwd: bad mode");
   PDAE_CHECK_ARG((!dss || ss) && (!dzss || zss) && (!dgamma || dbeta), "gn_bwd: gradient requested for an absent input");
   return k_gn_bwd(x0, C0, x1, C1, N, H, W, G, coef, rstd, gamma, beta, ss, zss, dA, act, mode, drop_p, seed, offset, add, dx0, acc0, dx1, acc1,
-                  dgamma, dbeta, acc_param, dss, dzss, (float*)ws, S(stream), dx0_amax);
+                  dgamma, dbeta, acc_param, dss, dzss, (float*)ws, S(stream), dx0_amax, ticket);
 }
 
 // ---- elementwise
@@ -496,7 +497,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_GN_STATS: return pdae_gn_stats(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], FM(2), FM(3), p[4], st);
     case PDAE_OP_GN_STATS_COEF:
       return pdae_gn_stats_coef(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(2), F(3), F(4), F(5), FM(6), FM(7),
-                                FM(8), p[9], st);
+                                FM(8), p[9], (uint32_t*)p[10], st);
     case PDAE_OP_GN_COEF: return pdae_gn_coef((int)i[0], (int)i[1], (int)i[2], F(0), F(1), F(2), F(3), F(4), F(5), FM(6), st);
     case PDAE_OP_GN_APPLY:
       return pdae_gn_apply(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], F(2), (int)i[5], (int)i[6], FM(3), FM(4), (float)f[0],
@@ -504,7 +505,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_GN_BWD:
       return pdae_gn_bwd(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], F(2), F(3), F(4), F(5), F(6), F(7), F(8),
                          (int)i[6], (int)i[7], (float)f[0], (uint64_t)i[11], (uint64_t)i[12], F(9), FM(10), (int)i[8], FM(11), (int)i[9], FM(12),
-                         FM(13), (int)i[10], FM(14), FM(15), p[16], FM(17), st);
+                         FM(13), (int)i[10], FM(14), FM(15), p[16], FM(17), (uint32_t*)p[18], st);
     case PDAE_OP_TEMB: return pdae_timestep_embedding((const int64_t*)p[0], F(1), (int)i[0], (int)i[1], FM(2), st);
     case PDAE_OP_MLP_MODLN_FWD:
       return pdae_mlp_modln_fwd(F(0), F(1), F(2), F(3), (int)i[0], (int)i[1], (int)i[2], (int)i[3], (float)f[0], FM(4), FM(5), FM(6), st);

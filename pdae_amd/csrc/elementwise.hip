@@ -408,6 +408,10 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restri
 }
 size_t k_colsum_workspace_floats(long long M, int C) { return (size_t)COLSUM_MAXB * C; }
 int k_colsum(const float* x, long long M, int C, float* out, int acc, float* ws, hipStream_t st) {
+  if (M <= 512) {            // few rows (split-K partials of the fused bias gradient, M = batch linears): the final stage alone, one launch
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, x, (int)M, C, out, acc);
+    return pdae_launch_status("colsum");
+  }
   long long want = (M * C + 16383) / 16384;          // >= 16K elements per block
   int nb = (int)(want < 1 ? 1 : (want > COLSUM_MAXB ? COLSUM_MAXB : want));
   int rows_per = cdiv(M, nb); nb = cdiv(M, rows_per);

@@ -51,10 +51,34 @@ __device__ __forceinline__ float4 drop_mask(unsigned long long seed, unsigned lo
 }
 
 // ----------------------------------------------------------------------------------------------
+// "last block finishes the job": kernels that write per-block partials take a ticket per sample; the block that draws the last ticket of its
+// sample runs the finalize stage itself instead of a second launch (a dependent launch costs 1.5-2 us of boundary plus a ~10 us tail for a
+// few hundred flops).  Hand-off protocol of the CDNA programming guide (G16): plain stores -> __syncthreads() -> one lane: agent-scope
+// release fence, explicit vmcnt(0), relaxed agent atomic; the last arriver: agent-scope acquire fence -> __syncthreads() -> plain loads.
+// The ticket word is reset by the last arriver, so a zero-initialised array stays valid across launches (launches on one stream are serial).
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool last_block_of(unsigned* ticket, unsigned count) {
+  __shared__ int is_last;
+  __syncthreads();                                       // every partial of this block has been stored (barrier waits for vmcnt)
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == count - 1;
+    if (is_last) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
+  __syncthreads();
+  return is_last != 0;
+}
+
+// ----------------------------------------------------------------------------------------------
 // statistics: per (n, chunk) block, threads = channel quads x pixel lanes; shifted sums (shift =
 // first element of the group) keep E[x^2]-E[x]^2 benign; finalize combines chunks in double.
 // ----------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_stats_partial_kernel(Src2 s, int HW, int C, int G, int chunk, float* __restrict__ part) {
+__device__ __forceinline__ void gn_stats_partial_body(const Src2& s, int HW, int C, int G, int chunk, float* __restrict__ part) {
   __shared__ float red[2 * 1024];            // [PL][C] x {s1,s2} with PL*C <= 1024
   const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
   const int NQ = C >> 2, PL = 256 / NQ, cg = C / G;
@@ -90,6 +114,9 @@ __global__ void __launch_bounds__(256) gn_stats_partial_kernel(Src2 s, int HW, i
     float* o = part + (((size_t)n * S + sidx) * G + t) * 2;
     o[0] = a; o[1] = b;
   }
+}
+__global__ void __launch_bounds__(256) gn_stats_partial_kernel(Src2 s, int HW, int C, int G, int chunk, float* __restrict__ part) {
+  gn_stats_partial_body(s, HW, C, G, chunk, part);
 }
 
 // one wave per (n, group): lanes over the S <= 64 partials, butterfly-reduced in double
@@ -130,12 +157,12 @@ __global__ void gn_coef_kernel(int N, int C, int G, const float* __restrict__ me
 
 // statistics finalize + coefficient fold in one launch: block = sample n; waves reduce the per-chunk partials of their groups
 // (double butterfly), then all threads write the per-(n,c) coefficients
-__global__ void __launch_bounds__(256) gn_finalize_coef_kernel(Src2 s, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               const float* __restrict__ ss, const float* __restrict__ zss,
-                                                               float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ coef) {
+__device__ __forceinline__ void gn_finalize_coef_body(const Src2& s, int n, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ ss,
+                                                      const float* __restrict__ zss, float* __restrict__ mean, float* __restrict__ rstd,
+                                                      float* __restrict__ coef) {
   __shared__ float smean[64], srstd[64];
-  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, cg = C / G;
+  const int t = threadIdx.x, lane = t & 63, cg = C / G;
   for (int g = t >> 6; g < G; g += 4) {
     double a = 0.0, b = 0.0;
     for (int k = lane; k < S; k += 64) { const float* o = part + (((size_t)n * S + k) * G + g) * 2; a += o[0]; b += o[1]; }
@@ -160,6 +187,24 @@ __global__ void __launch_bounds__(256) gn_finalize_coef_kernel(Src2 s, int N, in
     coef[(size_t)N * C + i] = k;
     coef[(size_t)2 * N * C + i] = b;
   }
+}
+
+__global__ void __launch_bounds__(256) gn_finalize_coef_kernel(Src2 s, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ ss, const float* __restrict__ zss,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ coef) {
+  gn_finalize_coef_body(s, blockIdx.x, N, HW, C, G, S, eps, part, gamma, beta, ss, zss, mean, rstd, coef);
+}
+
+// statistics + finalize + coefficient fold in ONE launch: the partial-sum kernel, whose last block per sample finishes that sample
+__global__ void __launch_bounds__(256) gn_stats_coef_fused_kernel(Src2 s, int N, int HW, int C, int G, int chunk, float eps, float* __restrict__ part,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ ss, const float* __restrict__ zss,
+                                                                  float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ coef,
+                                                                  unsigned* __restrict__ ticket) {
+  gn_stats_partial_body(s, HW, C, G, chunk, part);
+  if (last_block_of(ticket + blockIdx.y, gridDim.x))
+    gn_finalize_coef_body(s, blockIdx.y, N, HW, C, G, gridDim.x, eps, part, gamma, beta, ss, zss, mean, rstd, coef);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -265,9 +310,9 @@ __device__ __forceinline__ float4 compute_dv(float4 da, float4 xm, float4 a, flo
   return da;
 }
 
-__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(Src2 s, int H, int W, int C, int chunk, const float* __restrict__ coef, int N,
-                                                            const float* __restrict__ dA, int act, int mode, float drop_p,
-                                                            unsigned long long seed, unsigned long long offset, float* __restrict__ part) {
+__device__ __forceinline__ void gn_bwd_reduce_body(const Src2& s, int H, int W, int C, int chunk, const float* __restrict__ coef, int N,
+                                                   const float* __restrict__ dA, int act, int mode, float drop_p,
+                                                   unsigned long long seed, unsigned long long offset, float* __restrict__ part) {
   __shared__ float red[2 * 1024];
   const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x, HW = H * W;
   const int NQ = C >> 2, PL = 256 / NQ;
@@ -309,17 +354,22 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(Src2 s, int H, int W
     o[0] = u; o[1] = v;
   }
 }
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(Src2 s, int H, int W, int C, int chunk, const float* __restrict__ coef, int N,
+                                                            const float* __restrict__ dA, int act, int mode, float drop_p,
+                                                            unsigned long long seed, unsigned long long offset, float* __restrict__ part) {
+  gn_bwd_reduce_body(s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
+}
 
 // one block per sample n.  Writes d(scale,shift) pairs, the per-(n,c) [c1,c2] apply coefficients and
 // the per-(n,c) gamma/beta contributions (summed over n by gn_bwd_param_kernel).
-__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(int N, int HW, int C, int G, int S, const float* __restrict__ part,
-                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, const float* __restrict__ ss,
-                                                              const float* __restrict__ zss, float* __restrict__ dss,
-                                                              float* __restrict__ dzss, float* __restrict__ c12, float* __restrict__ pgb,
-                                                              unsigned* __restrict__ amax0) {
+__device__ __forceinline__ void gn_bwd_finalize_body(int n, int N, int HW, int C, int G, int S, const float* __restrict__ part,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ ss,
+                                                     const float* __restrict__ zss, float* __restrict__ dss,
+                                                     float* __restrict__ dzss, float* __restrict__ c12, float* __restrict__ pgb,
+                                                     unsigned* __restrict__ amax0) {
   __shared__ float g1[1024], g2[1024], m1[64], m2[64];
-  const int n = blockIdx.x, cg = C / G, t = threadIdx.x;
+  const int cg = C / G, t = threadIdx.x;
   if (amax0 && n == 0 && t == 0) *amax0 = 0u;      // the apply kernel (next launch on this stream) accumulates max|dx0| into it
   for (int c = t; c < C; c += 256) {
     float S0 = 0.f, S1 = 0.f;
@@ -350,14 +400,45 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(int N, int HW, int
     c12[((size_t)n * C + c) * 2 + 1] = r * r * m2[g];
   }
 }
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(int N, int HW, int C, int G, int S, const float* __restrict__ part,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ ss,
+                                                              const float* __restrict__ zss, float* __restrict__ dss,
+                                                              float* __restrict__ dzss, float* __restrict__ c12, float* __restrict__ pgb,
+                                                              unsigned* __restrict__ amax0) {
+  gn_bwd_finalize_body(blockIdx.x, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, amax0);
+}
 
-__global__ void gn_bwd_param_kernel(int N, int C, const float* __restrict__ pgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__device__ __forceinline__ void gn_bwd_param_one(int c, int N, int C, const float* __restrict__ pgb, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                 int accumulate) {
   float a = 0.f, b = 0.f;
   for (int n = 0; n < N; ++n) { a += pgb[((size_t)n * C + c) * 2]; b += pgb[((size_t)n * C + c) * 2 + 1]; }
   if (accumulate) { a += dgamma[c]; b += dbeta[c]; }
   dgamma[c] = a; dbeta[c] = b;
+}
+__global__ void gn_bwd_param_kernel(int N, int C, const float* __restrict__ pgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) gn_bwd_param_one(c, N, C, pgb, dgamma, dbeta, accumulate);
+}
+
+// reduce + finalize + parameter gradients in ONE launch: the last block of each sample finalizes it, the last finalizer sums the
+// per-sample gamma / beta contributions (ticket[0..N) per sample, ticket[N] across samples; see last_block_of)
+__global__ void __launch_bounds__(256) gn_bwd_reduce_fused_kernel(Src2 s, int H, int W, int C, int G, int chunk, const float* __restrict__ coef, int N,
+                                                                  const float* __restrict__ dA, int act, int mode, float drop_p,
+                                                                  unsigned long long seed, unsigned long long offset, float* __restrict__ part,
+                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const float* __restrict__ ss,
+                                                                  const float* __restrict__ zss, float* __restrict__ dss, float* __restrict__ dzss,
+                                                                  float* __restrict__ c12, float* __restrict__ pgb, unsigned* __restrict__ amax0,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_param,
+                                                                  unsigned* __restrict__ ticket) {
+  gn_bwd_reduce_body(s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
+  const int n = blockIdx.y;
+  if (!last_block_of(ticket + n, gridDim.x)) return;
+  gn_bwd_finalize_body(n, N, H * W, C, G, gridDim.x, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, amax0);
+  if (dgamma == nullptr) return;
+  if (!last_block_of(ticket + N, (unsigned)N)) return;
+  for (int c = threadIdx.x; c < C; c += 256) gn_bwd_param_one(c, N, C, pgb, dgamma, dbeta, acc_param);
 }
 
 // dx = a*dv - c1 - (x-mu)*c2 (+ add, resampled like dA); split into the two concat sources.  Streaming form as gn_apply_stream.
@@ -463,12 +544,16 @@ int k_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, 
 }
 
 int k_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma, const float* beta,
-                    const float* ss, const float* zss, float* mean, float* rstd, float* coef, float* ws, hipStream_t st) {
+                    const float* ss, const float* zss, float* mean, float* rstd, float* coef, float* ws, hipStream_t st, unsigned* ticket) {
   if (int e = check_c(C0, C1, G)) return e;
   const int C = C0 + C1;
   Src2 s{x0, x1, C0, C1};
   int S = stats_chunks(HW, C), chunk = cdiv(HW, S);
   S = cdiv(HW, chunk);
+  if (ticket) {
+    hipLaunchKernelGGL(gn_stats_coef_fused_kernel, dim3(S, N), dim3(256), 0, st, s, N, HW, C, G, chunk, eps, ws, gamma, beta, ss, zss, mean, rstd, coef, ticket);
+    return pdae_launch_status("gn_stats_coef");
+  }
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, N), dim3(256), 0, st, s, HW, C, G, chunk, ws);
   hipLaunchKernelGGL(gn_finalize_coef_kernel, dim3(N), dim3(256), 0, st, s, N, HW, C, G, S, eps, ws, gamma, beta, ss, zss, mean, rstd, coef);
   return pdae_launch_status("gn_stats_coef");
@@ -503,7 +588,7 @@ int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, i
 int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
              const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p,
              unsigned long long seed, unsigned long long offset, const float* add, float* dx0, int acc0, float* dx1, int acc1,
-             float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, float* ws, hipStream_t st, float* dx0_amax) {
+             float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, float* ws, hipStream_t st, float* dx0_amax, unsigned* ticket) {
   if (int e = check_c(C0, C1, G)) return e;
   const int C = C0 + C1, HW = H * W;
   unsigned* am = (dx0 && dx0_amax) ? reinterpret_cast<unsigned*>(dx0_amax) : nullptr;
@@ -513,10 +598,15 @@ int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int
   float* part = ws;                                   // [N][S][C][2]
   float* c12 = ws + (size_t)N * 64 * C * 2;           // [N][C][2]
   float* pgb = c12 + (size_t)N * C * 2;               // [N][C][2]
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am);
-  if (dgamma)
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, N, C, pgb, dgamma, dbeta, acc_param);
+  if (ticket) {
+    hipLaunchKernelGGL(gn_bwd_reduce_fused_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, G, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part,
+                       rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am, dgamma, dbeta, acc_param, ticket);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am);
+    if (dgamma)
+      hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, N, C, pgb, dgamma, dbeta, acc_param);
+  }
   if (dx0 || dx1) {
     int Sa = stream_chunks(HW, C), chunk_a = cdiv(HW, Sa);
     Sa = cdiv(HW, chunk_a);

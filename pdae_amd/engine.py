@@ -39,6 +39,19 @@ class Plan:
         self.init_arr = None
         self.watch = []         # modules whose _frozen_version gates a re-run of the init ops
         self.seen = None
+        self._tickets = None    # zeroed uint32 words for the "last block finishes" GroupNorm kernels (one stream runs a plan: shared by all its ops)
+
+    def tickets(self, n):
+        """>= n + 1 zero-initialised ticket words (pdae_gn_stats_coef / pdae_gn_bwd) with PDAE_GN_TICKETS=1, else None (default).
+        The single-launch "last block finalizes" forms are correct (tests) but SLOWER on this path: every block's agent-scope release fence
+        writes back the XCD's L2, which is full of the producer's freshly written activations -- measured 80.2 vs 76.5 ms per FFHQ-128 step on
+        one box.  Kept as an opt-in for hosts whose tensors are small enough to sit clean in L2."""
+        if os.environ.get("PDAE_GN_TICKETS", "0") != "1":
+            return None
+        if self._tickets is None or self._tickets.numel() < n + 1:
+            self._tickets = torch.zeros(max(n + 1, 257), dtype=torch.int32, device=self.device)
+            self.live.append(self._tickets)
+        return self._tickets
 
     # ---- memory
     def buf(self, *shape, dtype=torch.float32, zero=False):
@@ -385,7 +398,7 @@ class Builder:
         gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]
         pl.need_ws(H.gn_ws_bytes(N, C))
         mean, rstd, coef = pl.buf(N * GROUPS), pl.buf(N * GROUPS), pl.buf(3, N, C)
-        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None), ws_slot=9)
+        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None, ticket=pl.tickets(N)), ws_slot=9)
         wp = self._wprep(c, w, 0, gn=True)
         y = pl.buf(N, c.Ho, c.Wo, c.Cout)
         if sp is not None:
@@ -409,7 +422,7 @@ class Builder:
         Ho, Wo = (Hh // 2, W // 2) if mode == 1 else (Hh, W)
         y = pl.buf(N, Ho, Wo, C)
         xpool = pl.buf(N, Ho, Wo, C) if (mode == 1 and want_xpool) else None
-        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None), ws_slot=9)
+        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None, ticket=pl.tickets(N)), ws_slot=9)
         dp = self.drop_p if dropout else 0.0
         layer = 0
         if dp > 0:
@@ -435,7 +448,7 @@ class Builder:
         pl.need_ws(H.gn_ws_bytes(g.N, C))
         idx = pl.emit(H.op_gn_bwd(g.x0, g.C0, g.x1, g.C1, g.N, g.H, g.W, GROUPS, g.coef, g.rstd, gamma, beta, g.ss, g.zss, dA, g.act,
                                   bmode, None, add=add, dx0=dx0, acc0=acc0, dx1=dx1, acc1=acc1, dgamma=dgamma, dbeta=dbeta, acc_param=self.acc, dss=dss,
-                                  dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0, dx0_amax=dx0_amax), ws_slot=16)
+                                  dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0, dx0_amax=dx0_amax, ticket=pl.tickets(g.N)), ws_slot=16)
         if g.drop_p > 0:
             pl.drop_ops.append((idx, 11, 12))
         return dss, dzss

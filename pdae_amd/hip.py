@@ -323,8 +323,8 @@ def op_gn_stats(x0, C0, x1, C1, N, HW, G, eps, mean, rstd, ws):
     return make_op(OP_GN_STATS, [x0, x1, mean, rstd, ws], [C0, C1, N, HW, G], [eps])
 
 
-def op_gn_stats_coef(x0, C0, x1, C1, N, HW, G, eps, gamma, beta, ss, zss, mean, rstd, coef, ws):
-    return make_op(OP_GN_STATS_COEF, [x0, x1, gamma, beta, ss, zss, mean, rstd, coef, ws], [C0, C1, N, HW, G], [eps])
+def op_gn_stats_coef(x0, C0, x1, C1, N, HW, G, eps, gamma, beta, ss, zss, mean, rstd, coef, ws, ticket=None):
+    return make_op(OP_GN_STATS_COEF, [x0, x1, gamma, beta, ss, zss, mean, rstd, coef, ws, ticket], [C0, C1, N, HW, G], [eps])
 
 
 def op_gn_coef(N, C, G, mean, rstd, gamma, beta, ss, zss, coef):
@@ -336,8 +336,8 @@ def op_gn_apply(x0, C0, x1, C1, N, H, W, coef, act, mode, y, xpool=None, drop_p=
 
 
 def op_gn_bwd(x0, C0, x1, C1, N, H, W, G, coef, rstd, gamma, beta, ss, zss, dA, act, mode, ws, add=None, dx0=None, acc0=0,
-              dx1=None, acc1=0, dgamma=None, dbeta=None, acc_param=0, dss=None, dzss=None, drop_p=0.0, seed=0, offset=0, dx0_amax=None):
-    return make_op(OP_GN_BWD, [x0, x1, coef, rstd, gamma, beta, ss, zss, dA, add, dx0, dx1, dgamma, dbeta, dss, dzss, ws, dx0_amax],
+              dx1=None, acc1=0, dgamma=None, dbeta=None, acc_param=0, dss=None, dzss=None, drop_p=0.0, seed=0, offset=0, dx0_amax=None, ticket=None):
+    return make_op(OP_GN_BWD, [x0, x1, coef, rstd, gamma, beta, ss, zss, dA, add, dx0, dx1, dgamma, dbeta, dss, dzss, ws, dx0_amax, ticket],
                    [C0, C1, N, H, W, G, act, mode, acc0, acc1, acc_param, seed, offset], [drop_p])
 
 

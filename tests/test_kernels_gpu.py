@@ -225,6 +225,24 @@ def test_groupnorm_family(H, case):
     H.run(H.op_gn_bwd(x0, C0, x1, C1, N, Hh, W, G, coef, rstd, f32(gamma), f32(beta), f32(ss), f32(zss), nhwc(dA).cuda(), act, mode, wsp,
                       add=None if add is None else nhwc(add).cuda(), dx0=dx0, dx1=dx1, dgamma=dg, dbeta=db, dss=dss, dzss=dzss, dx0_amax=am))
     assert float(am[0]) == float(dx0.abs().max())
+    # single-launch forms ("the last block of a sample finalizes it", ticket words): same arithmetic in the same order -> bit-identical, and the
+    # tickets return to zero so that the same words serve every later launch (three rounds)
+    tick = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        mean3, rstd3, coef3 = torch.zeros_like(mean), torch.zeros_like(rstd), torch.zeros_like(coef)
+        H.run(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, G, 1e-5, f32(gamma), f32(beta), f32(ss), f32(zss), mean3, rstd3, coef3, wsp, ticket=tick))
+        assert torch.equal(mean, mean3) and torch.equal(rstd, rstd3) and torch.equal(coef, coef3)
+        t_dx0, t_dg, t_db = torch.zeros_like(dx0), torch.zeros_like(dg), torch.zeros_like(db)
+        t_dx1 = torch.zeros_like(dx1) if C1 else None
+        t_dss = torch.zeros_like(dss) if use_ss else None
+        t_dzss = torch.zeros_like(dzss) if use_zss else None
+        am2 = torch.full((4,), 7.0, device="cuda")
+        H.run(H.op_gn_bwd(x0, C0, x1, C1, N, Hh, W, G, coef, rstd, f32(gamma), f32(beta), f32(ss), f32(zss), nhwc(dA).cuda(), act, mode, wsp,
+                          add=None if add is None else nhwc(add).cuda(), dx0=t_dx0, dx1=t_dx1, dgamma=t_dg, dbeta=t_db, dss=t_dss, dzss=t_dzss,
+                          dx0_amax=am2, ticket=tick))
+        assert torch.equal(t_dx0, dx0) and torch.equal(t_dg, dg) and torch.equal(t_db, db) and float(am2[0]) == float(am[0])
+        assert (not C1 or torch.equal(t_dx1, dx1)) and (not use_ss or torch.equal(t_dss, dss)) and (not use_zss or torch.equal(t_dzss, dzss))
+        assert int(tick.abs().sum()) == 0
     dx = torch.cat([dx0, dx1], -1) if C1 else dx0
     assert rel_err(nchw(dx), x.grad) < 2e-5
     assert rel_err(dg, gamma.grad) < 2e-5 and rel_err(db, beta.grad) < 2e-5
