@@ -336,3 +336,222 @@ int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (e) return e;
   return igemm_splitk_reduce(ws, dw, (long long)Cout * 9 * C, P.splits * 2, accumulate, s);
 }
+
+
+// =============================================================================================================================
+// 1x1 weight gradient:  dW[co][ci] = sum over pixels p of dY[p][co] * X[p][ci],  X = [x0 | x1] (the concat of a skip convolution is never
+// materialised).  Same fragment machinery as above -- pixel-major tiles in LDS, transposing reads -- but with one tap the arithmetic intensity
+// is set by how many input channels a block covers per staged dY tile: a block owns 128 output x 128 input channels (4 chunks), wave (a, cj) =
+// output channels a*32..+31 x input chunks 2cj, 2cj+1, and walks all eight 16-pixel k-chunks of a 128-pixel tile itself, so there is no
+// k-parity split and one slab per pixel split.  (The generic implicit-GEMM kernel ran these launches at 35-85 TFLOP/s in 6-product arithmetic.)
+// Replaces the weight gradient of the ResBlock skip_connection (module.py:276) and the attention qkv / proj_out convolutions (:412,420).
+// =============================================================================================================================
+struct Wgrad1Params {
+  const float* x0; const float* x1; int C0, C1, C;      // X rows of M pixels, C = C0 + C1
+  long long M;                                          // pixels
+  const float* dy; int Cout;
+  float* ws;                                            // slabs [splits][Cout][C]
+  int ntiles, tiles_per_split, splits, co_tiles, ci_blocks;
+  const float* dy_amax; float* db_part; unsigned int* sat;
+};
+
+template <int NS>
+__global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  constexpr int SPL = WTPIX * WSY;                        // one plane of one operand: 128 pixels x (128 channels + 8 pad)
+  unsigned short* sX = smem;                              // [NPL][128][WSY]
+  unsigned short* sY = smem + WNPL(NS) * SPL;             // [NPL][128][WSY]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int a = wv & 3, cj = wv >> 2;
+  const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;      // XCD-aware order, ci block fastest (see conv3x3w_kernel)
+  const int ci_blk = bid % P.ci_blocks; bid /= P.ci_blocks;
+  const int co_tile = bid % P.co_tiles; const int split = bid / P.co_tiles;
+  const int ci0 = ci_blk * 128, co0 = co_tile * 128;
+  const int C = P.C, Cout = P.Cout;
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const unsigned lane_off = (unsigned)(((h * 8 + (i16 >> 2)) * WSY + g16 * 16 + (i16 & 3) * 4) * 2);      // bytes; + channel-tile offset below
+  const unsigned sY_base = (unsigned)(WNPL(NS) * SPL * 2);
+
+  float4 xpre[8], ypre[8];
+  float sat_hit = 0.f;
+  const bool want_db = P.db_part != nullptr && ci_blk == 0;
+  float4* bred = reinterpret_cast<float4*>(smem + 2 * WNPL(NS) * SPL);
+  const float yscale = NS == 4 ? w_pow2_scale(*P.dy_amax) : 1.0f;
+  if (want_db) bred[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto gload = [&](int tile) {
+    const long long m0 = (long long)tile * WTPIX;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const int idx = t + WTHREADS * l, pix = idx >> 5, c4 = idx & 31;
+      const long long m = m0 + pix;
+      const bool inm = m < P.M;
+      const long long mm = inm ? m : 0;                   // unconditional loads from clamped addresses, zeroed afterwards
+      const int ci = ci0 + c4 * 4, co = co0 + c4 * 4;
+      const bool okx = inm && ci < C, oky = inm && co < Cout;
+      const int cic = okx ? ci : 0;
+      const float4 vx = *reinterpret_cast<const float4*>(cic < P.C0 ? P.x0 + mm * P.C0 + cic : P.x1 + mm * P.C1 + (cic - P.C0));
+      const float4 vy = *reinterpret_cast<const float4*>(P.dy + mm * Cout + (oky ? co : 0));
+      xpre[l] = okx ? vx : make_float4(0.f, 0.f, 0.f, 0.f);
+      ypre[l] = oky ? vy : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&]() {
+    if (want_db) {
+      float4 b4 = bred[t];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) { b4.x += ypre[l].x; b4.y += ypre[l].y; b4.z += ypre[l].z; b4.w += ypre[l].w; }
+      bred[t] = b4;
+    }
+#pragma unroll
+    for (int l = 0; l < 8; ++l) {
+      const int idx = t + WTHREADS * l, pix = idx >> 5, c4 = idx & 31;
+      if constexpr (NS == 4) {
+        pdae_f16_scale4(xpre[l], WXSCALE, sat_hit);
+        ypre[l].x *= yscale; ypre[l].y *= yscale; ypre[l].z *= yscale; ypre[l].w *= yscale;
+      }
+      unsigned u[WNPL(NS)], v[WNPL(NS)];
+      w_split2<NS>(xpre[l].x, xpre[l].y, u); w_split2<NS>(xpre[l].z, xpre[l].w, v);
+#pragma unroll
+      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sX[(p * WTPIX + pix) * WSY + c4 * 4]) = make_uint2(u[p], v[p]);
+      w_split2<NS>(ypre[l].x, ypre[l].y, u); w_split2<NS>(ypre[l].z, ypre[l].w, v);
+#pragma unroll
+      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + c4 * 4]) = make_uint2(u[p], v[p]);
+    }
+  };
+
+  const int t_beg = split * P.tiles_per_split, t_end = min(P.ntiles, t_beg + P.tiles_per_split);
+  if (t_beg < t_end) gload(t_beg);
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (tile + 1 < t_end) gload(tile + 1);
+#pragma unroll 2
+    for (int kc = 0; kc < 8; ++kc) {                      // 16 pixels per k-chunk
+      uint4 af[WNPL(NS)], bfr[2][WNPL(NS)];
+#pragma unroll
+      for (int p = 0; p < WNPL(NS); ++p) {
+        const unsigned ad = sY_base + lane_off + (unsigned)(((p * WTPIX + kc * 16) * WSY + a * 32) * 2);
+        af[p] = tr_frag(ad, ad + 4 * WSY * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned bd = lane_off + (unsigned)(((p * WTPIX + kc * 16) * WSY + (cj * 2 + j) * 32) * 2);
+          bfr[j][p] = tr_frag(bd, bd + 4 * WSY * 2);
+        }
+      }
+#define WA(P_) __builtin_bit_cast(bf16x8, af[P_])
+#define WB(P_) __builtin_bit_cast(bf16x8, bfr[j][P_])
+#define WAH(P_) __builtin_bit_cast(f16x8, af[P_])
+#define WBH(P_) __builtin_bit_cast(f16x8, bfr[j][P_])
+#define W1_EACH(STMT) _Pragma("unroll") for (int j = 0; j < 2; ++j) { STMT; }
+      if constexpr (NS == 4) {
+        W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(0), WBH(1), acc[j], 0, 0, 0))
+        W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(1), WBH(0), acc[j], 0, 0, 0))
+        W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(0), WBH(0), acc[j], 0, 0, 0))
+      } else {
+        if constexpr (NS == 3) {
+          W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(1), WB(1), acc[j], 0, 0, 0))
+          W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(2), acc[j], 0, 0, 0))
+          W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(2), WB(0), acc[j], 0, 0, 0))
+        }
+        if constexpr (NS >= 2) {
+          W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(1), acc[j], 0, 0, 0))
+          W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(1), WB(0), acc[j], 0, 0, 0))
+        }
+        W1_EACH(acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(0), acc[j], 0, 0, 0))
+      }
+#undef W1_EACH
+#undef WA
+#undef WB
+#undef WAH
+#undef WBH
+    }
+  }
+  if (P.db_part != nullptr) {                   // bias gradient: 16 threads share each channel quad -> LDS -> fixed-order sum
+    __syncthreads();
+    if (want_db && t < 32) {
+      float4 s4 = bred[t];
+      for (int k = 1; k < 16; ++k) { const float4 u = bred[t + 32 * k]; s4.x += u.x; s4.y += u.y; s4.z += u.z; s4.w += u.w; }
+      const int co = co0 + t * 4;
+      if (co < Cout) *reinterpret_cast<float4*>(P.db_part + (size_t)split * Cout + co) = s4;
+    }
+  }
+  const float oscale = NS == 4 ? 1.0f / (yscale * WXSCALE) : 1.0f;
+  if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
+  float* slab = P.ws + (size_t)split * Cout * C;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ci = ci0 + (cj * 2 + j) * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < Cout && ci < C) slab[(size_t)co * C + ci] = NS == 4 ? acc[j][r] * oscale : acc[j][r];
+    }
+  }
+}
+
+static void wgrad1_plan(long long M, int C, int Cout, int& splits, int& tiles_per_split) {
+  const int ntiles = (int)((M + WTPIX - 1) / WTPIX);
+  const int base = ((Cout + 127) / 128) * ((C + 127) / 128);
+  int maxs = ntiles / 4; if (maxs < 1) maxs = 1;
+  if (maxs > 256) maxs = 256;
+  long long best = -1; int best_s = 1;
+  for (int s = 1; s <= maxs; ++s) {
+    const int tps = (ntiles + s - 1) / s, sp = (ntiles + tps - 1) / tps;
+    if (sp != s) continue;
+    const long long rounds = ((long long)base * sp + 255) / 256;
+    const long long cost = rounds * (tps + 2);
+    if (best < 0 || cost < best) { best = cost; best_s = s; }
+  }
+  tiles_per_split = (ntiles + best_s - 1) / best_s;
+  splits = (ntiles + tiles_per_split - 1) / tiles_per_split;
+}
+
+bool conv1x1w_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, int C1, long long M, int Cout) {
+  if (math < 1 || KH != 1 || KW != 1 || stride != 1 || pad != 0 || up) return false;
+  if ((C0 & 31) || (C1 & 31) || (Cout & 3) || Cout < 32 || C0 + C1 < 32) return false;
+  return M >= 16 * WTPIX;
+}
+
+size_t conv1x1w_workspace_bytes(long long M, int C, int Cout) {
+  int splits, tps;
+  wgrad1_plan(M, C, Cout, splits, tps);
+  return ((size_t)splits * Cout * C + (size_t)splits * Cout) * sizeof(float);
+}
+
+template <int NS> static int launch_w1(const Wgrad1Params& P, hipStream_t s) {
+  const size_t smem = (size_t)(2 * WNPL(NS) * WTPIX * WSY) * sizeof(unsigned short) + WTHREADS * sizeof(float4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1x1w_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { pdae_set_error("conv1x1w: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv1x1w_kernel<NS>), dim3(P.splits * P.co_tiles * P.ci_blocks), dim3(WTHREADS), smem, s, P);
+  return pdae_launch_status("conv1x1w");
+}
+
+int conv1x1w_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const float* dy, int Cout, float* dw, int accumulate,
+                    float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax) {
+  Wgrad1Params P;
+  P.dy_amax = dy_amax; P.sat = pdae_sat_counter();
+  if (math == 4 && !dy_amax) math = 3;
+  P.x0 = x0; P.x1 = x1; P.C0 = C0; P.C1 = C1; P.C = C0 + C1; P.M = M; P.dy = dy; P.Cout = Cout; P.ws = ws;
+  P.ntiles = (int)((M + WTPIX - 1) / WTPIX);
+  wgrad1_plan(M, P.C, Cout, P.splits, P.tiles_per_split);
+  P.co_tiles = (Cout + 127) / 128; P.ci_blocks = (P.C + 127) / 128;
+  const size_t need = ((size_t)P.splits * Cout * P.C + (size_t)P.splits * Cout) * sizeof(float);
+  P.db_part = db_part ? ws + (size_t)P.splits * Cout * P.C : nullptr;
+  if (db_part) { *db_part = P.db_part; *db_rows = P.splits; }
+  if (!ws || ws_bytes < need) { pdae_set_error("conv1x1w: workspace too small (%zu < %zu)", ws_bytes, need); return PDAE_EINVAL; }
+  int e = math == 1 ? launch_w1<1>(P, s) : (math == 2 ? launch_w1<2>(P, s) : (math == 4 ? launch_w1<4>(P, s) : launch_w1<3>(P, s)));
+  if (e) return e;
+  return igemm_splitk_reduce(ws, dw, (long long)Cout * P.C, P.splits, accumulate, s);
+}

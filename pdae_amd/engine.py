@@ -253,7 +253,7 @@ class Builder:
             self.p.need_ws(wsb)
             # the bias gradient rides along: the 3x3 kernel sums dY while staging it, the other paths run the column sum themselves
             ride = self.fuse_db
-            am = ((amax if (amax is not None and self.amax_ok(c)) else self.dy_amax(c, dy))) if c.KH == 3 else None   # generic 1x1 wgrad: no fp16 format
+            am = (amax if (amax is not None and self.amax_ok(c)) else self.dy_amax(c, dy))       # 3x3 and 1x1 weight-gradient kernels: fp16 format with dy_amax
             self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am), ws_slot=4,
                         wsb_slot=len(c.fields()) + 1)
             if am is not None:

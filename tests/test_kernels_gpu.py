@@ -645,3 +645,31 @@ def test_f16_format_gradient_kernels_with_dynamic_scale(H, case, gscale):
     H.run(H.op_conv_wgrad(c, xd, None, dyd, dw, ws(wsb), wsb, db=db, dy_amax=am))
     assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < 2e-5
     assert rel_err(db, dy.double().sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("math_mode", [1, 2, 4])
+@pytest.mark.parametrize("case", [(8, 16, 16, 128, 128, 128), (4, 32, 32, 64, 0, 96), (2, 48, 24, 256, 128, 160), (16, 16, 16, 384, 0, 1152), (3, 40, 28, 32, 32, 36)])
+def test_conv1x1_weight_gradient_kernel(H, case, math_mode):
+    """conv3x3w.hip: conv1x1w_kernel -- dW and the riding bias gradient of a (dual-source) 1x1 convolution, ragged pixel tiles, channel counts
+    that do not fill a 128-channel block, accumulate, and a tiny-magnitude dY in the fp16 format (dynamic scale); fp64 reference."""
+    N, Hh, W, C0, C1, Cout = case
+    Cin = C0 + C1
+    tol = MATH_TOL[math_mode]
+    x, dy = rn(1, N, Cin, Hh, W), rn(2, N, Cout, Hh, W)
+    dw_ref = torch.einsum("nohw,nihw->oi", dy.double(), x.double())
+    db_ref = dy.double().sum((0, 2, 3))
+    c = H.Conv(N, Hh, W, C0, C1, Cout, k=1, math=math_mode)
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous()
+    x1 = xh[..., C0:].contiguous() if C1 else None
+    for scale in (1.0, 1e-6):
+        dyd = nhwc(dy).cuda() * scale
+        am = torch.empty(4, device="cuda")
+        H.run(H.op_amax(dyd, dyd.numel(), am))
+        wsb = c.wgrad_ws_bytes()
+        dw = torch.full((Cout, 1, 1, Cin), float("nan"), device="cuda")
+        db = torch.full((Cout,), float("nan"), device="cuda")
+        H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb, db=db, dy_amax=am if math_mode == 4 else None))
+        assert rel_err(dw.reshape(Cout, Cin), dw_ref * scale) < 2 * tol and rel_err(db, db_ref * scale) < 1e-5
+        H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb, accumulate=1, db=db, dy_amax=am if math_mode == 4 else None))
+        assert rel_err(dw.reshape(Cout, Cin), 2 * dw_ref * scale) < 2 * tol and rel_err(db, 2 * db_ref * scale) < 1e-5
