@@ -117,6 +117,15 @@ int pdae_gemm(int transA, int transB, int M, int N, int K, float alpha, const fl
 typedef struct pdae_linear_item { const float* x; const float* w; const float* bias; float* y; int32_t n_out; int32_t reserved; } pdae_linear_item;
 int pdae_linear_group(const pdae_linear_item* items, const int32_t* first_feature, int n_items, int total_features, int M, int K, pdae_stream_t stream);
 
+/* Backward of such a family in ONE launch: dw_i (+)= dy_i^T x_i, db_i (+)= column sums of dy_i (acc_w selects "+="), and where dx_i != NULL
+ * dx_i (+)= dy_i W_i (acc_x).  At most ONE item of a call may write a given dx (no cross-block reduction).  first_block[i] = index of item i's
+ * first thread block: an item takes ceil(n_out/8) blocks, plus M * ceil(K/128) more when it has a dx; first_block[n_items] = total_blocks. */
+typedef struct pdae_linear_bwd_item {
+  const float* x; const float* dy; const float* w; float* dw; float* db; float* dx; int32_t n_out, acc_w, acc_x, reserved;
+} pdae_linear_bwd_item;
+int pdae_linear_bwd_group(const pdae_linear_bwd_item* items, const int32_t* first_block, int n_items, int total_blocks, int M, int K,
+                          pdae_stream_t stream);
+
 /* ---- GroupNorm(32,C) + AdaGN + SiLU (+Dropout, +AvgPool2d) : module.py:56-63,241,257-263,279-284,293-294,379-381 */
 size_t pdae_gn_workspace_bytes(int N, int C);
 int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, void* ws,
@@ -246,7 +255,7 @@ enum {
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
   PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
   PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP,
-  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD
+  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP
 };
 typedef struct pdae_op {
   int32_t kind;

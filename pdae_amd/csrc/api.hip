@@ -317,6 +317,13 @@ extern "C" int pdae_linear_group(const pdae_linear_item* items, const int32_t* f
   return skinny_group_launch(items, first_feature, n_items, total_features, M, K, S(stream));
 }
 
+extern "C" int pdae_linear_bwd_group(const pdae_linear_bwd_item* items, const int32_t* first_block, int n_items, int total_blocks, int M, int K,
+                                     pdae_stream_t stream) {
+  PDAE_CHECK_ARG(items && first_block && n_items > 0 && total_blocks > 0 && M > 0 && M <= 32 && K > 0 && (K & 3) == 0,
+                 "linear_bwd_group: bad arguments (M <= 32, K %% 4 == 0)");
+  return linear_bwd_group_launch(items, first_block, n_items, total_blocks, M, K, S(stream));
+}
+
 // ---- GroupNorm family
 extern "C" size_t pdae_gn_workspace_bytes(int N, int C) { return k_gn_workspace_floats(N, C) * sizeof(float); }
 extern "C" int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, float* mean, float* rstd, void* ws,
@@ -544,6 +551,8 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_DDPM_STEP_ROWS: return pdae_ddpm_step_rows(F(0), F(1), F(2), F(3), F(4), F(5), (int)i[0], (size_t)i[1], FM(6), st);
     case PDAE_OP_ATTN_FWD: return pdae_attn_fwd(F(0), (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], FM(1), FM(2), st);
     case PDAE_OP_ATTN_BWD: return pdae_attn_bwd(F(0), F(1), F(2), F(3), (int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], FM(4), p[5], st);
+    case PDAE_OP_LINEAR_BWD_GROUP:
+      return pdae_linear_bwd_group((const pdae_linear_bwd_item*)p[0], (const int32_t*)p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], st);
     case PDAE_OP_LINEAR_GROUP: return pdae_linear_group((const pdae_linear_item*)p[0], (const int32_t*)p[1], (int)i[0], (int)i[1], (int)i[2], (int)i[3], st);
     case PDAE_OP_ADAM_EMA:
       return pdae_adam_ema(FM(0), F(1), FM(2), FM(3), FM(4), (size_t)i[0], (float)f[0], (float)f[1], (float)f[2], (float)f[3], (float)f[4], (int)i[1],

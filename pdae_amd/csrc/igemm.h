@@ -82,6 +82,7 @@ bool conv1x1w_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, 
 size_t conv1x1w_workspace_bytes(long long M, int C, int Cout);
 int conv1x1w_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const float* dy, int Cout, float* dw, int accumulate,
                     float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax);
+int linear_bwd_group_launch(const void* items, const int* first, int n_items, int total_blocks, int M, int K, hipStream_t s);
 int skinny_group_launch(const void* items, const int* first, int n_items, int total, int M, int K, hipStream_t s);
 bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch);
 int skinny_launch(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, const float* bias, int M, int N, int K,

@@ -95,3 +95,81 @@ int skinny_launch(const float* A, long long lda, const float* B, long long ldb, 
   hipLaunchKernelGGL(skinny_nt_kernel, dim3((N + 3) / 4), dim3(256), 0, s, A, lda, B, ldb, C, ldc, bias, M, N, K, accumulate);
   return pdae_launch_status("skinny_nt");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward of a family of M <= 32 linear layers y_i = x_i W_i^T + b_i in ONE launch (the emb_layers / emb_z_layers pair of a ResBlock:
+// module.py:287-293, 371-380 under autograd):   dW_i (+)= dy_i^T x_i,   db_i (+)= column sums of dy_i,   dx_i (+)= dy_i W_i.
+// Exact fp32 FMA, fixed summation order (deterministic).  Block ranges: per item first n_out/8 blocks of weight-gradient rows (thread = 4 rows x
+// one k quad: the x tile, 32 x K, is read once per thread-quad of rows), then (dx != NULL) M * ceil(K/128) blocks, one per (batch row, k tile).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct LinearBwdItem { const float* x; const float* dy; const float* w; float* dw; float* db; float* dx; int n_out; int acc_w; int acc_x; int pad; };
+__global__ void __launch_bounds__(256) linear_bwd_group_kernel(const LinearBwdItem* __restrict__ items, const int* __restrict__ first, int n_items, int M, int K) {
+  __shared__ float4 red[256];
+  int lo = 0, hi = n_items - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (first[mid] <= b) lo = mid; else hi = mid - 1; }
+  const LinearBwdItem it = items[lo];
+  const int lb = b - first[lo], wblocks = (it.n_out + 7) >> 3;
+  const int t = threadIdx.x, KQ = K >> 2;
+  if (lb < wblocks) {                                    // ---- dW rows lb*8 .. +7 (+ db)
+    const int rg = t / 128, kq0 = t % 128;               // two groups of four rows, 128 k-quad lanes
+    const int n0 = lb * 8 + rg * 4;
+    for (int kq = kq0; kq < KQ; kq += 128) {
+      float4 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m = 0; m < M; ++m) {
+        const float4 xv = *reinterpret_cast<const float4*>(it.x + (size_t)m * K + kq * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = (n0 + j < it.n_out) ? it.dy[(size_t)m * it.n_out + n0 + j] : 0.f;
+          a[j].x = fmaf(d, xv.x, a[j].x); a[j].y = fmaf(d, xv.y, a[j].y); a[j].z = fmaf(d, xv.z, a[j].z); a[j].w = fmaf(d, xv.w, a[j].w);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + j < it.n_out) {
+          float4* dst = reinterpret_cast<float4*>(it.dw + (size_t)(n0 + j) * K + kq * 4);
+          if (it.acc_w) { const float4 u = *dst; a[j].x += u.x; a[j].y += u.y; a[j].z += u.z; a[j].w += u.w; }
+          *dst = a[j];
+        }
+    }
+    if (it.db && kq0 == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + j < it.n_out) {
+          float sdb = 0.f;
+          for (int m = 0; m < M; ++m) sdb += it.dy[(size_t)m * it.n_out + n0 + j];
+          it.db[n0 + j] = it.acc_w ? it.db[n0 + j] + sdb : sdb;
+        }
+    }
+    return;
+  }
+  // ---- dx: block (m, k tile of 128 floats) = lb - wblocks;  dx[m][k] (+)= sum_n dy[m][n] W[n][k]; 8 slices of the thread block split n
+  // (each W row segment is a 512-byte coalesced read), combined through LDS in fixed order
+  const int kt_n = (KQ + 31) >> 5, xb = lb - wblocks, m = xb / kt_n, kq = (xb - m * kt_n) * 32 + (t & 31), sl = t >> 5;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kq < KQ) {
+    const int per = (it.n_out + 7) >> 3, nb = sl * per, ne = min(it.n_out, nb + per);
+    for (int n = nb; n < ne; ++n) {
+      const float d = it.dy[(size_t)m * it.n_out + n];
+      const float4 wv = *reinterpret_cast<const float4*>(it.w + (size_t)n * K + kq * 4);
+      a.x = fmaf(d, wv.x, a.x); a.y = fmaf(d, wv.y, a.y); a.z = fmaf(d, wv.z, a.z); a.w = fmaf(d, wv.w, a.w);
+    }
+  }
+  red[t] = a;
+  __syncthreads();
+  if (sl == 0 && kq < KQ) {
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { const float4 u = red[t + 32 * j]; a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; }
+    float4* dst = reinterpret_cast<float4*>(it.dx + (size_t)m * K + kq * 4);
+    if (it.acc_x) { const float4 e = *dst; a.x += e.x; a.y += e.y; a.z += e.z; a.w += e.w; }
+    *dst = a;
+  }
+}
+
+int linear_bwd_group_launch(const void* items, const int* first, int n_items, int total_blocks, int M, int K, hipStream_t s) {
+  hipLaunchKernelGGL(linear_bwd_group_kernel, dim3(total_blocks), dim3(256), 0, s, (const LinearBwdItem*)items, first, n_items, M, K);
+  return pdae_launch_status("linear_bwd_group");
+}

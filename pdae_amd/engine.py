@@ -318,6 +318,31 @@ class Builder:
         for (x, wname), r in zip(jobs, res):
             self._emb[wname] = r
 
+    def linear_bwd_group(self, jobs):
+        """jobs = [(linear ctx, dy, dx or None, dx_acc)]: the backward of several M <= 32 linear layers (dW, db, optional dx) in ONE launch
+        (pdae_linear_bwd_group) instead of 2-3 launches each.  At most one job may carry a given dx."""
+        jobs = [j for j in jobs if j is not None]
+        if not jobs:
+            return
+        Nb, K = jobs[0][0].Nb, jobs[0][0].K
+        dxs = [id(dx) for _, _, dx, _ in jobs if dx is not None]
+        fits = (Nb <= 32 and K % 4 == 0 and all(lx.Nb == Nb and lx.K == K for lx, _, _, _ in jobs) and len(dxs) == len(set(dxs))
+                and os.environ.get("PDAE_GROUP_LINEAR_BWD", "1") != "0")
+        items = []
+        for lx, dy, dx, dx_acc in jobs:
+            gw, gb = self.Gr.get(lx.wname + ".weight"), self.Gr.get(lx.wname + ".bias")
+            if not fits or gw is None or gb is None:
+                fits = False
+                break
+            items.append((lx.x, dy, self.P[lx.wname + ".weight"], gw, gb, dx, self.acc, dx_acc))
+        if not fits:
+            for lx, dy, dx, dx_acc in jobs:
+                self.linear_bwd(lx, dy, dx=dx, dx_acc=dx_acc)
+            return
+        it, first, total = H.linear_bwd_group_tables(items, Nb, self.p.device)
+        self.p.live.extend([it, first])
+        self.p.emit(H.op_linear_bwd_group(it, first, len(items), total, Nb, K))
+
     def linear_bwd(self, lx, dy, dx=None, dx_acc=0):
         """dW = dy^T x, db = colsum(dy), optionally dx (+)= dy W."""
         Nb, K, out = lx.Nb, lx.K, lx.out
@@ -529,11 +554,9 @@ class Builder:
         am1 = pl.buf(4) if self.amax_ok(r.c1.c) else None      # max|dh1| falls out of the GroupNorm-backward apply pass
         dss, dzss = self.gn_bwd(g2, d_a2, 0, dx0=dh1, want_dss=True, want_dzss=True, dx0_amax=am1)
         pl.free(d_a2)
-        self.linear_bwd(r.l_ss, dss, dx=d_ea, dx_acc=1)
-        pl.free(dss)
-        if dzss is not None:
-            self.linear_bwd(r.l_zss, dzss, dx=d_eza, dx_acc=1)
-            pl.free(dzss)
+        # emb_layers / emb_z_layers Linear backward (dW, db, and the gradient of SiLU(emb) / SiLU(shift_emb)): one launch for the pair
+        self.linear_bwd_group([(r.l_ss, dss, d_ea, 1), (r.l_zss, dzss, d_eza, 1) if dzss is not None else None])
+        pl.free(dss, dzss)
         # conv1
         self.conv_bwd_params(r.c1, dh1, amax=am1)
         trainable_gn1 = (g1.gname + ".weight") in self.Gr

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PDAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpdae
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
  OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX,
- OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD) = range(1, 41)
+ OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD, OP_LINEAR_BWD_GROUP) = range(1, 42)
 
 
 class PdaeOp(ctypes.Structure):
@@ -103,7 +103,7 @@ def lib():
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
            "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
-           "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
+           "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_bwd_group", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
            "pdae_ssim_mse_workspace_bytes", "pdae_ssim_mse", "pdae_image_prepare_workspace_bytes", "pdae_image_prepare"]
 
@@ -301,6 +301,23 @@ def linear_group_tables(items, device):
         tot += n_out
         first.append(tot)
     return (torch.tensor(rows, dtype=torch.int64).to(device), torch.tensor(first, dtype=torch.int32).to(device), tot)
+
+
+def linear_bwd_group_tables(items, M, device, K=None):
+    """Device tables of pdae_linear_bwd_group for items = [(x, dy, w, dw, db, dx, acc_w, acc_x)]: (items int64 [n,8], first int32 [n+1], total blocks)."""
+    rows, first, tot = [], [0], 0
+    for x, dy, w, dw, db, dx, acc_w, acc_x in items:
+        n_out = int(w.shape[0])
+        p = lambda t: t.data_ptr() if t is not None else 0
+        rows.append([p(x), p(dy), p(w), p(dw), p(db), p(dx), n_out | (int(acc_w) << 32), int(acc_x)])     # two int32 per int64 word (little endian)
+        kk = int(w.shape[1]) if K is None else K
+        tot += (n_out + 7) // 8 + (M * ((kk // 4 + 31) // 32) if dx is not None else 0)
+        first.append(tot)
+    return (torch.tensor(rows, dtype=torch.int64).to(device), torch.tensor(first, dtype=torch.int32).to(device), tot)
+
+
+def op_linear_bwd_group(items_t, first_t, n_items, total_blocks, M, K):
+    return make_op(OP_LINEAR_BWD_GROUP, [items_t, first_t], [n_items, total_blocks, M, K])
 
 
 def op_linear_group(items_t, first_t, n_items, total, M, K):

@@ -673,3 +673,38 @@ def test_conv1x1_weight_gradient_kernel(H, case, math_mode):
         assert rel_err(dw.reshape(Cout, Cin), dw_ref * scale) < 2 * tol and rel_err(db, db_ref * scale) < 1e-5
         H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb, accumulate=1, db=db, dy_amax=am if math_mode == 4 else None))
         assert rel_err(dw.reshape(Cout, Cin), 2 * dw_ref * scale) < 2 * tol and rel_err(db, 2 * db_ref * scale) < 1e-5
+
+
+def test_grouped_linear_forward_and_backward(H):
+    """pdae_linear_group / pdae_linear_bwd_group: several M <= 32 linear layers (different widths, two different inputs) in one launch each,
+    against fp64; accumulate flags; an item without dx; every output element written."""
+    M, K = 32, 512
+    g = torch.Generator().manual_seed(1)
+    xa, xb = torch.randn(M, K, generator=g), torch.randn(M, K, generator=g)
+    specs = [(xa, 256), (xa, 1024), (xb, 768), (xb, 36)]
+    Ws = [torch.randn(n, K, generator=g) / 22 for _, n in specs]
+    bs = [torch.randn(n, generator=g) for _, n in specs]
+    xd = {id(xa): xa.cuda(), id(xb): xb.cuda()}
+    ys = [torch.full((M, n), float("nan"), device="cuda") for _, n in specs]
+    Wd, bd = [w.cuda() for w in Ws], [b.cuda() for b in bs]
+    items = [(xd[id(x)], Wd[i], bd[i], ys[i]) for i, (x, n) in enumerate(specs)]
+    it, first, total = H.linear_group_tables(items, "cuda")
+    H.run(H.op_linear_group(it, first, len(items), total, M, K))
+    for i, (x, n) in enumerate(specs):
+        assert rel_err(ys[i], x.double() @ Ws[i].double().T + bs[i].double()) < 1e-6
+    dys = [torch.randn(M, n, generator=g) for _, n in specs]
+    dyd = [d.cuda() for d in dys]
+    dW = [torch.ones(n, K, device="cuda") for _, n in specs]
+    db = [torch.ones(n, device="cuda") for _, n in specs]
+    dxa, dxb = torch.full((M, K), 2.0, device="cuda"), torch.full((M, K), float("nan"), device="cuda")
+    # item 0: accumulate into dW/db and into dxa; item 1: no dx; item 2: overwrite dxb; item 3: ragged width, no dx
+    bw = [(xd[id(xa)], dyd[0], Wd[0], dW[0], db[0], dxa, 1, 1), (xd[id(xa)], dyd[1], Wd[1], dW[1], db[1], None, 0, 0),
+          (xd[id(xb)], dyd[2], Wd[2], dW[2], db[2], dxb, 0, 0), (xd[id(xb)], dyd[3], Wd[3], dW[3], db[3], None, 0, 0)]
+    it, first, total = H.linear_bwd_group_tables(bw, M, "cuda")
+    H.run(H.op_linear_bwd_group(it, first, len(bw), total, M, K))
+    for i, (x, n) in enumerate(specs):
+        ref_w = dys[i].double().T @ x.double() + (1.0 if i == 0 else 0.0)
+        ref_b = dys[i].double().sum(0) + (1.0 if i == 0 else 0.0)
+        assert rel_err(dW[i], ref_w) < 1e-6 and rel_err(db[i], ref_b) < 1e-6, i
+    assert rel_err(dxa, dys[0].double() @ Ws[0].double() + 2.0) < 1e-6
+    assert rel_err(dxb, dys[2].double() @ Ws[2].double()) < 1e-6
