@@ -1,38 +1,60 @@
-"""Turns the raw rocprofv3 outputs under gpurun_out/ into the committed summaries under profiles/ (usage: collect_profiles.py <stats_dir> <pmc_prefix>)."""
-import csv, collections, glob, json, os, sys
+"""Turns the raw outputs of one tools/gpu_round.sh visit (gpurun_out/<tag>_*) into the committed summaries under profiles/.
+usage: collect_profiles.py <tag> <round-label, e.g. r02>"""
+import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-stats_dir, pmc_prefix = sys.argv[1], sys.argv[2]
-math_name = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
-rows = list(csv.DictReader(open(glob.glob(os.path.join(ROOT, "gpurun_out", stats_dir, "*", "*_kernel_stats.csv"))[0])))
+tag, rnd = sys.argv[1], sys.argv[2]
+G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+cmd = "python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ddim"
+
+# ---- kernel stats
+rows = list(csv.DictReader(open(glob.glob(os.path.join(G, tag + "_stats", "*", "*_kernel_stats.csv"))[0])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-out = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ddim   (MI355X, default arithmetic " + math_name + ", B=32 FFHQ-128 RL step)",
-       "# 7 training steps are in the trace (2 warm-up + 4 timed + 1 per-op profile pass); durations in ns; Percentage of total GPU kernel time",
+out = [f"# rocprofv3 --kernel-trace --stats -- {cmd}   (MI355X, default arithmetic f16x3, B=32 FFHQ-128 RL step)",
+       "# 7 training steps are in the trace (2 warm-up + 4 timed + 1 per-op profile pass); durations in ns; Pct of total GPU kernel time",
        f"# total kernel time {tot / 1e6:.1f} ms", f"{'Name':90s} {'Calls':>7s} {'TotalNs':>14s} {'AvgNs':>12s} {'Pct':>6s}"]
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:50]:
     out.append(f"{r['Name'][:90]:90s} {r['Calls']:>7s} {r['TotalDurationNs']:>14s} {float(r['AverageNs']):12.0f} {float(r['Percentage']):6.2f}")
-open(os.path.join(ROOT, "profiles", "r01_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
-print("\n".join(out[2:12]))
+open(os.path.join(P, f"{rnd}_kernel_stats.txt"), "w").write("\n".join(out) + "\n")
+print("\n".join(out[2:14]))
 
-
-def agg(path):
-    a = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
-        a[r["Kernel_Name"]][0] += 1; a[r["Kernel_Name"]][1] += float(r["Counter_Value"])
-    return a
-
-
-af = agg(glob.glob(os.path.join(ROOT, "gpurun_out", pmc_prefix + "FETCH_SIZE", "*", "*_counter_collection.csv"))[0])
-aw = agg(glob.glob(os.path.join(ROOT, "gpurun_out", pmc_prefix + "WRITE_SIZE", "*", "*_counter_collection.csv"))[0])
-o = {"math": math_name, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ddim",
+# ---- HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes)
+F = json.load(open(os.path.join(G, tag + "_pmc_FETCH_SIZE.json")))
+W = json.load(open(os.path.join(G, tag + "_pmc_WRITE_SIZE.json")))
+o = {"math": "f16x3", "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ddim",
      "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch; on gfx950 FETCH_SIZE counts wide coalesced reads at half their size (MI355X_MICROARCH.md, HBM "
-              "section): fetch_bytes = 2 x FETCH_SIZE x 1024. Calibration inside this very trace: gn_apply_stream_kernel reads and writes tensors of equal size "
-              "and reports WRITE_SIZE ~ 2 x FETCH_SIZE.", "kernels": {}}
-for k in af:
-    n = af[k][0]; fk = af[k][1] / n; wk = aw[k][1] / max(aw[k][0], 1)
-    o["kernels"][k] = {"dispatches": n, "fetch_size_kib_avg": round(fk, 1), "write_size_kib_avg": round(wk, 1), "hbm_bytes_per_launch": round((2 * fk + wk) * 1024)}
-json.dump(o, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
+              "section): fetch_bytes = 2 x FETCH_SIZE x 1024.", "kernels": {}}
+for k in F:
+    fk, wk = F[k].get("FETCH_SIZE", 0.0), W.get(k, {}).get("WRITE_SIZE", 0.0)
+    o["kernels"][k] = {"dispatches": F[k]["dispatches"], "fetch_size_kib_avg": round(fk, 1), "write_size_kib_avg": round(wk, 1), "hbm_bytes_per_launch": round((2 * fk + wk) * 1024)}
+json.dump(o, open(os.path.join(P, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
 lines = ["# " + o["source"], "# " + o["units"], f"{'kernel':70s} {'disp':>6s} {'FETCH KiB':>12s} {'WRITE KiB':>12s} {'HBM MB/launch':>14s}"]
 for k, v in sorted(o["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["dispatches"])[:25]:
     lines.append(f"{k[:70]:70s} {v['dispatches']:6d} {v['fetch_size_kib_avg']:12.1f} {v['write_size_kib_avg']:12.1f} {v['hbm_bytes_per_launch'] / 1e6:14.1f}")
-open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
-print("\n".join(lines[2:8]))
+open(os.path.join(P, f"{rnd}_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
+
+# ---- SQ counters of the MFMA kernels
+A = json.load(open(os.path.join(G, tag + "_pmcA.json")))
+B = json.load(open(os.path.join(G, tag + "_pmcB.json")))
+hdr = ["# rocprofv3 --pmc <8 SQ counters + GRBM_GUI_ACTIVE> --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ddim   (two passes)",
+       "# per-launch means.  MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)  [busy cycles = 32 per 32x32x16 MFMA];",
+       "# WAIT_ANY = parked in s_waitcnt / barrier, WAIT_INST_ANY = issue stalls (MFMA pipe / dependencies), ACTIVE = instruction issue -- fractions of SQ_WAVE_CYCLES;",
+       "# LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; resources from the kernel trace (VGPR incl. AGPR, LDS bytes / workgroup)",
+       f"{'kernel':58s} {'disp':>5s} {'MFMAutil':>8s} {'WAIT_ANY':>8s} {'WAIT_INST':>9s} {'ACTIVE':>7s} {'LDSconf':>7s} {'VALU/MFMA':>9s} {'LDS/MFMA':>8s} {'VGPR':>5s} {'AGPR':>5s} {'LDS':>7s} {'WG':>4s}"]
+for k, v in sorted(A.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * kv[1]["dispatches"]):
+    if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0:
+        continue
+    b = B.get(k, {})
+    wc = v["SQ_WAVE_CYCLES"]
+    util = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0)
+    nm = max(b.get("SQ_INSTS_MFMA", 0.0), 1.0)
+    r = v["resources"]
+    hdr.append(f"{k[:58]:58s} {v['dispatches']:5d} {util:8.3f} {v['SQ_WAIT_ANY'] / wc:8.3f} {v['SQ_WAIT_INST_ANY'] / wc:9.3f} {v['SQ_ACTIVE_INST_ANY'] / wc:7.3f} "
+               f"{v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_LDS_IDX_ACTIVE'], 1):7.3f} {(b.get('SQ_INSTS_VALU', 0) - nm) / nm:9.2f} {b.get('SQ_INSTS_LDS', 0) / nm:8.2f} "
+               f"{r['VGPR_Count']:>5s} {r['Accum_VGPR_Count']:>5s} {r['LDS_Block_Size']:>7s} {r['Workgroup_Size']:>4s}")
+open(os.path.join(P, f"{rnd}_pmc_sq.txt"), "w").write("\n".join(hdr) + "\n")
+print("\n".join(hdr[4:12]))
+
+# ---- bench line, test log
+for src, dst in ((tag + "_bench.json", f"{rnd}_bench_default.json"), (tag + "_bench.log", f"{rnd}_bench_default_run.log"), (tag + "_tests.txt", f"{rnd}_gpu_tests.txt")):
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, dst))
