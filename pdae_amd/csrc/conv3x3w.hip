@@ -29,8 +29,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define WPW_(W8_) ((W8_) ? 20 : WTW + 2)          // 8-pixel-wide images: two images side by side, their 10-pixel halo rows = pitch 20
 #define WNPIX_(W8_) ((WTH + 2) * WPW_(W8_))     // 180 (200) patch pixels
 #define WTPIX (WTH * WTW)            // 128 tile pixels
-#define WSX 40                       // X row stride (bf16): 32 ci + 8 pad
-#define WSY 136                      // dY row stride (bf16): 128 co + 8 pad
+// LDS row strides chosen for the transposing read: the 32 lanes of one ds_read_b64_tr_b16 group address 4 pixel rows x 16 channels (2 dwords
+// per lane); they are conflict-free when the 4 rows start 16 banks (dwords) apart.  X rows are exactly 32 bf16 = 16 dwords: no padding needed.
+// 128-channel rows (64 dwords = 0 mod 64) would put all 4 rows on the same banks: their channel index is XOR-swizzled with (pixel & 3) * 32
+// instead of padded (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.50 with the former 40 / 136 strides, profiles/r02_pmc_sq.txt).
+#define WSX 32                       // X row stride (bf16): 32 ci
+#define WSY 128                      // dY row stride (bf16): 128 co, swizzled
+#define WSWZ(pix) ((((pix) & 3)) << 5)   // bf16 column XOR of pixel row `pix`
 #define WTHREADS 512
 #define WX_LD_(W8_) ((WNPIX_(W8_) * 8 + WTHREADS - 1) / WTHREADS)    // 3 (4) float4 per thread
 #define WY_LD (WTPIX * 32 / WTHREADS)                    // 8 float4 per thread
@@ -125,7 +130,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
     for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
 
   // lane-constant parts of the transposing-read addresses (bytes)
-  const unsigned y_lane = (unsigned)(((h * 8 + (i16 >> 2)) * WSY + a * 32 + g16 * 16 + (i16 & 3) * 4) * 2);
+  const unsigned y_lane = (unsigned)(((h * 8 + (i16 >> 2)) * WSY + ((a * 32 + g16 * 16 + (i16 & 3) * 4) ^ WSWZ(i16 >> 2))) * 2);   // rows h*8 + (i16>>2) [+4]: low 2 bits = i16>>2
   const unsigned x_lane = (unsigned)(((h * (W8 ? 10 : 8) + (i16 >> 2)) * WSX + g16 * 16 + (i16 & 3) * 4) * 2);   // W8: columns 8..15 = second image
   const unsigned sX_base = 0u, sY_base = (unsigned)(SX * 2);   // LDS byte offsets: the dynamic segment is the only LDS of this kernel
 
@@ -191,7 +196,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
       unsigned u[WNPL(NS)], v[WNPL(NS)];
       w_split2<NS>(ypre[l].x, ypre[l].y, u); w_split2<NS>(ypre[l].z, ypre[l].w, v);
 #pragma unroll
-      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + c4 * 4]) = make_uint2(u[p], v[p]);
+      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + ((c4 * 4) ^ WSWZ(pix))]) = make_uint2(u[p], v[p]);
     }
   };
 
@@ -376,7 +381,7 @@ __global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const unsigned lane_off = (unsigned)(((h * 8 + (i16 >> 2)) * WSY + g16 * 16 + (i16 & 3) * 4) * 2);      // bytes; + channel-tile offset below
+  const unsigned lane_row = (unsigned)((h * 8 + (i16 >> 2)) * WSY), lane_col = (unsigned)(g16 * 16 + (i16 & 3) * 4), lane_swz = (unsigned)WSWZ(i16 >> 2);
   const unsigned sY_base = (unsigned)(WNPL(NS) * SPL * 2);
 
   float4 xpre[8], ypre[8];
@@ -419,10 +424,10 @@ __global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P
       unsigned u[WNPL(NS)], v[WNPL(NS)];
       w_split2<NS>(xpre[l].x, xpre[l].y, u); w_split2<NS>(xpre[l].z, xpre[l].w, v);
 #pragma unroll
-      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sX[(p * WTPIX + pix) * WSY + c4 * 4]) = make_uint2(u[p], v[p]);
+      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sX[(p * WTPIX + pix) * WSY + ((c4 * 4) ^ WSWZ(pix))]) = make_uint2(u[p], v[p]);
       w_split2<NS>(ypre[l].x, ypre[l].y, u); w_split2<NS>(ypre[l].z, ypre[l].w, v);
 #pragma unroll
-      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + c4 * 4]) = make_uint2(u[p], v[p]);
+      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + ((c4 * 4) ^ WSWZ(pix))]) = make_uint2(u[p], v[p]);
     }
   };
 
@@ -438,11 +443,11 @@ __global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P
       uint4 af[WNPL(NS)], bfr[2][WNPL(NS)];
 #pragma unroll
       for (int p = 0; p < WNPL(NS); ++p) {
-        const unsigned ad = sY_base + lane_off + (unsigned)(((p * WTPIX + kc * 16) * WSY + a * 32) * 2);
+        const unsigned ad = sY_base + (lane_row + (unsigned)((p * WTPIX + kc * 16) * WSY) + ((lane_col + a * 32) ^ lane_swz)) * 2;
         af[p] = tr_frag(ad, ad + 4 * WSY * 2);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const unsigned bd = lane_off + (unsigned)(((p * WTPIX + kc * 16) * WSY + (cj * 2 + j) * 32) * 2);
+          const unsigned bd = (lane_row + (unsigned)((p * WTPIX + kc * 16) * WSY) + ((lane_col + (cj * 2 + j) * 32) ^ lane_swz)) * 2;
           bfr[j][p] = tr_frag(bd, bd + 4 * WSY * 2);
         }
       }
