@@ -29,6 +29,20 @@ static inline int pdae_launch_status(const char* what) {
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// fp16 operand split of (e0 * sc, e1 * sc), sc a power of two: packed head plane (round-to-nearest fp16) and packed residual plane (fp16 of
+// e * sc - head, which is exact in fp32).  v_fma_mixlo/mixhi_f16 fuse scale, conversion and packing, and take the fp16 head straight back
+// as the addend of the residual: 4 VALU instructions per pair where mul + cvt + cvt back + sub + cvt + shift/or packing took 13.  It matters:
+// on a SIMD with two resident waves every VALU instruction costs ~5 issue cycles and the matrix pipe idles meanwhile (tools/probes/valu_rate.hip;
+// the weight-gradient kernel spent 6.6 VALU instructions per MFMA on this).  Bit-identical to the scalar conversions (tools/probes/mix_probe.hip).
+__device__ __forceinline__ void pdae_f16_split2s(float e0, float e1, float sc, unsigned& head, unsigned& resid) {
+  unsigned h, l;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(e0), "v"(sc));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(e1), "v"(sc));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(e0), "v"(sc), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(e1), "v"(sc), "v"(h));
+  head = h; resid = l;
+}
+
 // ---- fp16-window guard of the two-fp16-plane format (math 4).  Scaled operands must stay inside the fp16 range (|x| <= 65504) for both planes to
 // be finite.  Nothing is clamped: an operand beyond the window becomes Inf in the high plane and turns its output rows into NaN exactly like
 // an fp16 autocast overflow would, NaN / Inf inputs propagate as they do in fp32 arithmetic -- and the launch COUNTS the event in the device
@@ -37,10 +51,9 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 unsigned int* pdae_sat_counter();
 #ifdef __HIPCC__
 #define PDAE_F16_LIMIT 60000.f        // margin below 65504 for the round-to-nearest of the high plane
-// v *= sc; amax = running per-lane max |scaled operand| (one VGPR for the whole kernel, 3 VALU per float4: v_max3 with |.| modifiers)
-__device__ __forceinline__ void pdae_f16_scale4(float4& v, float sc, float& amax) {
-  v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-  amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+// amax = running per-lane max |v * sc| of the operands this lane has split (one VGPR for the whole kernel; NaN does not raise it, Inf does)
+__device__ __forceinline__ void pdae_f16_amax4(const float4& v, float sc, float& amax) {
+  amax = fmaxf(amax, sc * fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
 }
 __device__ __forceinline__ void pdae_sat_report(unsigned int* counter, float amax) {
   const unsigned long long over = __builtin_amdgcn_ballot_w64(!(amax <= PDAE_F16_LIMIT));

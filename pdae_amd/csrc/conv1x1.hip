@@ -28,9 +28,6 @@ __device__ __forceinline__ unsigned q_rn(float a, float b) {
   unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
   return (unsigned)x | ((unsigned)y << 16);
 }
-__device__ __forceinline__ unsigned q_pack_h(_Float16 a, _Float16 b) {
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
 __device__ __forceinline__ float q_pow2_scale(float amax) {            // 2^(10 - floor(log2(amax))); 1 for 0 / non-finite
   const int ex = (__float_as_int(amax) >> 23) & 0xff;
   if (ex == 0 || ex == 255) return 1.0f;
@@ -38,11 +35,9 @@ __device__ __forceinline__ float q_pow2_scale(float amax) {            // 2^(10 
   sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
   return __int_as_float(sb << 23);
 }
-template <int NS> __device__ __forceinline__ void q_split2(float e0, float e1, unsigned (&w)[QNPL(NS)]) {
-  if constexpr (NS == 4) {
-    const _Float16 h0 = (_Float16)e0, h1 = (_Float16)e1;
-    w[0] = q_pack_h(h0, h1);
-    w[1] = q_pack_h((_Float16)(e0 - (float)h0), (_Float16)(e1 - (float)h1));
+template <int NS> __device__ __forceinline__ void q_split2(float e0, float e1, unsigned (&w)[QNPL(NS)], float sc = 1.0f) {
+  if constexpr (NS == 4) {          // fp16 planes of e * sc (the other formats take no scale)
+    pdae_f16_split2s(e0, e1, sc, w[0], w[1]);
   } else if constexpr (NS == 1) { w[0] = q_rn(e0, e1); }
   else {
     float h0 = q_trunc(e0), h1 = q_trunc(e1);
@@ -115,10 +110,10 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
       const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
-      if constexpr (NS == 4) pdae_f16_scale4(apre[l], ascale, sat_hit);
+      if constexpr (NS == 4) pdae_f16_amax4(apre[l], ascale, sat_hit);
       unsigned a[QNPL(NS)], b[QNPL(NS)];
-      q_split2<NS>(apre[l].x, apre[l].y, a);
-      q_split2<NS>(apre[l].z, apre[l].w, b);
+      q_split2<NS>(apre[l].x, apre[l].y, a, ascale);
+      q_split2<NS>(apre[l].z, apre[l].w, b, ascale);
 #pragma unroll
       for (int p = 0; p < QNPL(NS); ++p) *reinterpret_cast<uint2*>(&sA[(p * 128 + row) * QLDH + qd * 4]) = make_uint2(a[p], b[p]);
     }

@@ -44,14 +44,9 @@ __device__ __forceinline__ unsigned p_rn(float a, float b) {
   unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
   return (unsigned)x | ((unsigned)y << 16);
 }
-__device__ __forceinline__ unsigned p_pack_h(_Float16 a, _Float16 b) {
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-}
-template <int NS> __device__ __forceinline__ void p_split2(float e0, float e1, unsigned (&w)[NPL(NS)]) {
-  if constexpr (NS == 4) {                       // fp16 hi (rn) + fp16 of the exact fp32 residual
-    const _Float16 h0 = (_Float16)e0, h1 = (_Float16)e1;
-    w[0] = p_pack_h(h0, h1);
-    w[1] = p_pack_h((_Float16)(e0 - (float)h0), (_Float16)(e1 - (float)h1));
+template <int NS> __device__ __forceinline__ void p_split2(float e0, float e1, unsigned (&w)[NPL(NS)], float sc = 1.0f) {
+  if constexpr (NS == 4) {          // fp16 planes of e * sc (the other formats take no scale)
+    pdae_f16_split2s(e0, e1, sc, w[0], w[1]);
   } else if constexpr (NS == 1) { w[0] = p_rn(e0, e1); }
   else {
     float h0 = p_trunc(e0), h1 = p_trunc(e1);
@@ -203,11 +198,11 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
           // a value outside the window (|x| > 3750 cannot occur behind GroupNorm unless the network has diverged) overflows to Inf / NaN
           // like any fp16 overflow and is counted: the step is then discarded and re-run in the range-free bf16x6 split (common.h)
           // skip chunks carry the RAW residual stream (no GroupNorm in front): unit activation scale, the 2^4 sits in their weights instead
-          pdae_f16_scale4(apre[l], pre_raw ? 1.0f : ascale, sat_hit);
+          pdae_f16_amax4(apre[l], pre_raw ? 1.0f : ascale, sat_hit);
         }
         unsigned a[NPL(NS)], b[NPL(NS)];
-        p_split2<NS>(apre[l].x, apre[l].y, a);
-        p_split2<NS>(apre[l].z, apre[l].w, b);
+        p_split2<NS>(apre[l].x, apre[l].y, a, pre_raw ? 1.0f : ascale);
+        p_split2<NS>(apre[l].z, apre[l].w, b, pre_raw ? 1.0f : ascale);
 #pragma unroll
         for (int p = 0; p < NPL(NS); ++p) *reinterpret_cast<uint2*>(&sA[p * PPLANE(PNPIX) + PSLOT(pix, qd >> 1) + (qd & 1) * 4]) = make_uint2(a[p], b[p]);
       }

@@ -8,14 +8,20 @@
 // gfx950 transposing LDS read build the MFMA fragments:
 //   ds_read_b64_tr_b16: within a 16-lane group lane i passes the address of row (i>>2), columns (i&3)*4..+3 and receives
 //   the 4-row column i (verified on MI355X by tools/probes/tr_probe.hip for arbitrary row strides).
-// Per 8x16-pixel tile the block stages dY[128 px][128 co] and the haloed X patch [10x18 px][32 ci] once (NS bf16 planes each,
-// see igemm.hip) and all nine taps read shifted pixel rows of the same patch.  Block = 8 waves: wave (a, kh) owns output
-// channels a*32..+31 for all 9 taps (9 accumulator tiles) and the k-chunks (tile rows) of parity kh; the two kh partial sums
-// go to separate split-K slabs, reduced in fixed order by splitk_reduce_kernel.
+// Per 8x16-pixel tile the block stages dY[128 px][64 co] and the haloed X patch [10x18 px][32 ci] once (NS planes each,
+// see igemm.hip) and all nine taps read shifted pixel rows of the same patch.  Block = 4 waves: wave (a, th) owns output
+// channels a*32..+31 and half of the taps -- th 0: taps 0..3 plus the centre tap on tile rows 0..3, th 1: taps 5..8 plus the
+// centre tap on rows 4..7 (108 MFMAs per tile either way; the two centre halves meet through LDS once, in the epilogue) --
+// i.e. 5 accumulator tiles.  60 KB of LDS and ~170 VGPRs put TWO blocks on a CU, so one block's staging phase (global ->
+// split -> LDS, fenced by two barriers) runs under the other block's MFMA phase.  The earlier layout (128 co per block, 8 waves
+// x 9 accumulators, one block per CU) idled the matrix pipe during every staging phase: MFMA busy 0.42 (profiles/r02_pmc_sq.txt).
+// Split-K over pixel tiles: one slab per split, reduced in fixed order by splitk_reduce_kernel.
 //
 // Replaces the weight-gradient of F.conv2d(k=3, padding=1) (model/module.py:242,265).
 #include "common.h"
 #include "igemm.h"
+#include <type_traits>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -31,23 +37,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define WTPIX (WTH * WTW)            // 128 tile pixels
 // LDS row strides chosen for the transposing read: the 32 lanes of one ds_read_b64_tr_b16 group address 4 pixel rows x 16 channels (2 dwords
 // per lane); they are conflict-free when the 4 rows start 16 banks (dwords) apart.  X rows are exactly 32 bf16 = 16 dwords: no padding needed.
-// 128-channel rows (64 dwords = 0 mod 64) would put all 4 rows on the same banks: their channel index is XOR-swizzled with (pixel & 3) * 32
-// instead of padded (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.50 with the former 40 / 136 strides, profiles/r02_pmc_sq.txt).
+// 64-channel dY rows (32 dwords) put rows r and r+2 on the same banks: their channel index is XOR-swizzled with bit 1 of the pixel row * 32,
+// so that rows 0..3 of a read land on bank groups {a, 2+a, a^1, 2+(a^1)} (a = the wave's 32-channel half) instead of being padded
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.50 with padded 40 / 136 strides, profiles/r02_pmc_sq.txt).
+#define WCO 64                       // output channels per block
 #define WSX 32                       // X row stride (bf16): 32 ci
-#define WSY 128                      // dY row stride (bf16): 128 co, swizzled
-#define WSWZ(pix) ((((pix) & 3)) << 5)   // bf16 column XOR of pixel row `pix`
-#define WTHREADS 512
-#define WX_LD_(W8_) ((WNPIX_(W8_) * 8 + WTHREADS - 1) / WTHREADS)    // 3 (4) float4 per thread
-#define WY_LD (WTPIX * 32 / WTHREADS)                    // 8 float4 per thread
+#define WSY WCO                      // dY row stride (bf16): 64 co, swizzled
+#define WSWZ(pix) ((((pix) >> 1) & 1) << 5)   // bf16 column XOR of pixel row `pix`
+#define WTHREADS 256
+#define WX_LD_(W8_) ((WNPIX_(W8_) * 8 + WTHREADS - 1) / WTHREADS)    // 6 (7) float4 per thread
+#define WY_LD (WTPIX * (WCO / 4) / WTHREADS)             // 8 float4 per thread
 
 __device__ __forceinline__ float w_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 __device__ __forceinline__ unsigned w_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
 __device__ __forceinline__ unsigned w_rn(float a, float b) {
   unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
   return (unsigned)x | ((unsigned)y << 16);
-}
-__device__ __forceinline__ unsigned w_pack_h(_Float16 a, _Float16 b) {
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 // 2^(10 - floor(log2(amax))): amax * scale in [1024, 2048)  (amax == 0 or non-finite: 1)
 __device__ __forceinline__ float w_pow2_scale(float amax) {
@@ -57,11 +62,9 @@ __device__ __forceinline__ float w_pow2_scale(float amax) {
   sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
   return __int_as_float(sb << 23);
 }
-template <int NS> __device__ __forceinline__ void w_split2(float e0, float e1, unsigned (&w)[WNPL(NS)]) {
-  if constexpr (NS == 4) {
-    const _Float16 h0 = (_Float16)e0, h1 = (_Float16)e1;
-    w[0] = w_pack_h(h0, h1);
-    w[1] = w_pack_h((_Float16)(e0 - (float)h0), (_Float16)(e1 - (float)h1));
+template <int NS> __device__ __forceinline__ void w_split2(float e0, float e1, unsigned (&w)[WNPL(NS)], float sc = 1.0f) {
+  if constexpr (NS == 4) {          // fp16 planes of e * sc (the other formats take no scale)
+    pdae_f16_split2s(e0, e1, sc, w[0], w[1]);
   } else if constexpr (NS == 1) { w[0] = w_rn(e0, e1); }
   else {
     float h0 = w_trunc(e0), h1 = w_trunc(e1);
@@ -92,17 +95,36 @@ struct WgradParams {
   const float* x; int N, Hs, Ws, C;      // stored input [N,Hs,Ws,C] (C = Cin)
   int H, W, up;                          // conv grid (output size == logical input size)
   const float* dy; int Cout;             // dY [N,H,W,Cout]
-  float* ws;                             // split-K slabs [2*splits][Cout][9][C]
+  float* ws;                             // split-K slabs [splits][Cout][9][C]
   int tiles_x, tiles_y, ntiles;          // pixel tiles per image / total
   int tiles_per_split, splits;
   int co_tiles, ci_chunks;
   const float* dy_amax;                  // fp16 format: device scalar max|dY| (pdae_amax) -> power-of-two dY scale
   float* db_part;                        // optional bias-gradient partials [splits][Cout] (column sums of dY, written by the ci_chunk 0 blocks)
   unsigned int* sat;                     // fp16 format: saturation counter (common.h) or NULL
+  int stagger;                           // start delay (units of 64 clocks) of every second block arriving on a CU, see w3_phase_offset
 };
 
+// Two blocks share a CU so that one stages while the other multiplies -- but blocks launched together run in lock step (same phase lengths),
+// stage at the same time and fight for the matrix pipe at the same time.  Every block therefore counts its arrival on its CU (hardware id
+// registers -> one counter per CU, never reset: only the parity matters) and every second arrival starts half a tile late; the offset then
+// persists because both blocks have the same period.  Timing only: results do not depend on it.
+__device__ unsigned int w3_cu_arrivals[4096];
+__device__ __forceinline__ void w3_phase_offset(int stagger, unsigned* lds_word) {
+  if (stagger <= 0) return;
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID [3:0]
+    *lds_word = atomicAdd(&w3_cu_arrivals[((hw >> 8) & 0xffu) | ((xcc & 0xfu) << 8)], 1u);
+  }
+  __syncthreads();
+  const unsigned late = *lds_word & 1u;
+  __syncthreads();
+  if (late) for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+}
+
 template <int NS, bool W8 = false>
-__global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P) {
+__global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams P) {
   constexpr int WPW = WPW_(W8), WNPIX = WNPIX_(W8), WX_LD = WX_LD_(W8);
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   constexpr int SX = WNPL(NS) * WNPIX * WSX;
@@ -110,7 +132,7 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
   unsigned short* sY = smem + SX;            // [NS][128][WSY]
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int a = wv >> 1, kh = wv & 1;        // output-channel tile, k-chunk parity
+  const int a = wv & 1, th = wv >> 1;        // output-channel tile, tap half
   const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
 
   // XCD-aware bijective block order (block b runs on XCD b % 8, each XCD has its own L2): consecutive LOGICAL ids share an XCD, and the
@@ -120,12 +142,12 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
   int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
   const int ci_chunk = bid % P.ci_chunks; bid /= P.ci_chunks;
   const int co_tile = bid % P.co_tiles; const int split = bid / P.co_tiles;
-  const int ci0 = ci_chunk * 32, co0 = co_tile * 128;
+  const int ci0 = ci_chunk * 32, co0 = co_tile * WCO;
   const int C = P.C, Cout = P.Cout;
 
-  f32x16 acc[9];
+  f32x16 acc[5];                            // th 0: taps 0..3, th 1: taps 5..8; acc[4]: this wave's half of the centre tap
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
+  for (int tp = 0; tp < 5; ++tp)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
 
@@ -138,37 +160,61 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
   float sat_hit = 0.f;                      // fp16 format: lanes with an activation clamped into the window (common.h)
   const bool want_db = P.db_part != nullptr && ci_chunk == 0;       // this block also owns the column sums of its dY tiles
   // per-thread running column sums live in LDS behind the operand planes (thread-private slots: deterministic, no registers held
-  // across the MFMA phase -- the kernel sits at the 256-VGPR limit); thread: output channels (t & 31) * 4 .. +3, pixels idx >> 5
+  // across the MFMA phase); thread: output channels (t & 15) * 4 .. +3, pixels idx >> 4
   float4* bred = reinterpret_cast<float4*>(smem + SX + WNPL(NS) * WTPIX * WSY);
   const float yscale = NS == 4 ? w_pow2_scale(*P.dy_amax) : 1.0f;
   if (want_db) bred[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Tile-invariant halves of the operand addresses, computed once per block (a VALU instruction costs ~5 issue cycles of a two-wave SIMD during
+  // which the matrix pipe idles, and the per-tile address arithmetic used to be a third of this kernel's VALU stream):
+  //   X patch slot l of this thread = pixel (py, px) of the haloed patch, channel quad qd:  xw[l] = (element offset from the tile's origin pixel) * 64
+  //   + border bits {1: top halo row, 2: bottom halo row, 4: left halo column, 8: right halo column, 16: never valid, 32: second image of a pair};
+  //   a tile contributes the set of bits that fall outside the image (scalar), so validity is one AND per load.
+  //   dY slot l = tile row l, column t >> 4, channel quad t & 15: one thread offset plus l * row stride.
+  int xw[WX_LD];
+  const int ush = P.up ? 1 : 0;              // nearest-neighbour 2x upsampling in front of the convolution: stored pixel = logical >> 1 (tile origins are even)
+#pragma unroll
+  for (int l = 0; l < WX_LD; ++l) {
+    const int idx = t + WTHREADS * l, pix = idx >> 3, qd = idx & 7;
+    int bm = 16, rel = 0;
+    if (pix < WNPIX) {
+      const int py = pix / WPW, px = pix - py * WPW;
+      int lx = px - 1, sub = 0;
+      bm = (py == 0 ? 1 : 0) | (py == WTH + 1 ? 2 : 0);
+      if constexpr (W8) { sub = px >= 10; lx = px - 1 - 10 * sub; bm |= ((unsigned)lx >= 8u ? 16 : 0) | (sub ? 32 : 0); }
+      else bm |= (px == 0 ? 4 : 0) | (px == WTW + 1 ? 8 : 0);
+      rel = ((sub * P.Hs + ((py - 1) >> ush)) * P.Ws + (lx >> ush)) * C + qd * 4;
+    }
+    xw[l] = rel * 64 + bm;
+  }
+  const int ycol = t >> 4, yc4 = t & 15;
+  const bool co_ok = co0 + yc4 * 4 < Cout;
+  const int ythr_a = ((W8 ? (ycol & 7) : ycol) * Cout) + (co_ok ? yc4 * 4 : 0);                    // first (only) image of the tile
+  const int ythr = W8 ? ythr_a + (ycol >> 3) * P.H * P.W * Cout : ythr_a;                          // W8: columns 8..15 = second image of the pair
+  const int yrow = P.W * Cout;
+  bool y_ok = co_ok;                          // W8: also false for the missing second image of an odd batch (set per tile)
+  const float yscale_ok = (W8 || co_ok) ? yscale : 0.f;      // fp16 format, 16-pixel-wide tiles: lanes beyond Cout load a valid address and are scaled to zero
   auto gload = [&](int tile) {
     int img = tile / (P.tiles_y * P.tiles_x); int rem = tile - img * P.tiles_y * P.tiles_x;
     int ty = rem / P.tiles_x, tx = rem - ty * P.tiles_x;
     if constexpr (W8) img *= 2;                 // first image of the pair
     const int y0 = ty * WTH, x0 = tx * WTW;
+    const bool pair_missing = W8 && img + 1 >= P.N;
+    const int tmask = 16 | (y0 == 0 ? 1 : 0) | (y0 + WTH >= P.H ? 2 : 0) | (!W8 && x0 == 0 ? 4 : 0) | (!W8 && x0 + WTW >= P.W ? 8 : 0) | (pair_missing ? 32 : 0);
+    const float* xb = P.x + ((size_t)(img * P.Hs + (y0 >> ush)) * P.Ws + (x0 >> ush)) * C + ci0;
 #pragma unroll
-    for (int l = 0; l < WX_LD; ++l) {
-      int idx = t + WTHREADS * l; int pix = idx >> 3, qd = idx & 7;
-      xpre[l] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pix < WNPIX) {
-        int py = pix / WPW, px = pix - py * WPW;
-        int ly = y0 - 1 + py, lx = x0 - 1 + px, im = img;
-        if constexpr (W8) { const int sub = px >= 10; im = img + sub; lx = px - 1 - 10 * sub; }
-        if (im < P.N && (unsigned)ly < (unsigned)P.H && (unsigned)lx < (unsigned)P.W) {
-          int sy = P.up ? ly >> 1 : ly, sx = P.up ? lx >> 1 : lx;
-          xpre[l] = *reinterpret_cast<const float4*>(P.x + ((size_t)(im * P.Hs + sy) * P.Ws + sx) * C + ci0 + qd * 4);
-        }
-      }
+    for (int l = 0; l < WX_LD; ++l) {            // unconditional loads from clamped addresses, zeroed afterwards
+      const bool ok = (xw[l] & tmask) == 0;
+      const float4 v = *reinterpret_cast<const float4*>(xb + (ok ? xw[l] >> 6 : 0));
+      xpre[l] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const float* yb = P.dy + ((size_t)(img * P.H + y0) * P.W + x0) * Cout + co0;
+    if constexpr (W8) y_ok = co_ok && !(pair_missing && ycol >= 8);
+    const int yo = (W8 && pair_missing) ? ythr_a : ythr;
 #pragma unroll
     for (int l = 0; l < WY_LD; ++l) {
-      int idx = t + WTHREADS * l; int pix = idx >> 5, c4 = idx & 31;
-      int oy = y0 + (pix >> 4), ox = x0 + (pix & 15), im = img;
-      if constexpr (W8) { im = img + ((pix & 15) >> 3); ox = pix & 7; }
-      int co = co0 + c4 * 4;
-      ypre[l] = (co < Cout && im < P.N) ? *reinterpret_cast<const float4*>(P.dy + ((size_t)(im * P.H + oy) * P.W + ox) * Cout + co)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v = *reinterpret_cast<const float4*>(yb + yo + l * yrow);
+      if constexpr (W8 || NS != 4) ypre[l] = y_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      else ypre[l] = v;                          // fp16 format: a lane beyond Cout is zeroed by its operand scale instead (lstore)
     }
   };
   auto lstore = [&]() {
@@ -176,9 +222,9 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
     for (int l = 0; l < WX_LD; ++l) {
       int idx = t + WTHREADS * l; int pix = idx >> 3, qd = idx & 7;
       if (pix < WNPIX) {
-        if constexpr (NS == 4) pdae_f16_scale4(xpre[l], WXSCALE, sat_hit);
+        if constexpr (NS == 4) pdae_f16_amax4(xpre[l], WXSCALE, sat_hit);
         unsigned u[WNPL(NS)], v[WNPL(NS)];
-        w_split2<NS>(xpre[l].x, xpre[l].y, u); w_split2<NS>(xpre[l].z, xpre[l].w, v);
+        w_split2<NS>(xpre[l].x, xpre[l].y, u, WXSCALE); w_split2<NS>(xpre[l].z, xpre[l].w, v, WXSCALE);
 #pragma unroll
         for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sX[(p * WNPIX + pix) * WSX + qd * 4]) = make_uint2(u[p], v[p]);
       }
@@ -191,103 +237,150 @@ __global__ void __launch_bounds__(WTHREADS) conv3x3w_kernel(const WgradParams P)
     }
 #pragma unroll
     for (int l = 0; l < WY_LD; ++l) {
-      int idx = t + WTHREADS * l; int pix = idx >> 5, c4 = idx & 31;
-      if constexpr (NS == 4) { ypre[l].x *= yscale; ypre[l].y *= yscale; ypre[l].z *= yscale; ypre[l].w *= yscale; }
+      int idx = t + WTHREADS * l; int pix = idx >> 4, c4 = idx & 15;
       unsigned u[WNPL(NS)], v[WNPL(NS)];
-      w_split2<NS>(ypre[l].x, ypre[l].y, u); w_split2<NS>(ypre[l].z, ypre[l].w, v);
+      w_split2<NS>(ypre[l].x, ypre[l].y, u, yscale_ok); w_split2<NS>(ypre[l].z, ypre[l].w, v, yscale_ok);
 #pragma unroll
       for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + ((c4 * 4) ^ WSWZ(pix))]) = make_uint2(u[p], v[p]);
+    }
+  };
+
+  // MFMA phase of one staged tile for tap half TH: 8 k-chunks (tile rows of 16 pixels) x (4 taps + the centre tap on this wave's 4 rows) = 36
+  // tap steps of 3 MFMAs (2 fragment reads per plane each), fully unrolled and software-pipelined by hand: the fragments of step s+2 are
+  // requested before the MFMAs of step s (ring of three buffers), so that the LDS latency of a step hides under two steps of matrix work
+  // instead of being exposed once per k-chunk (hipcc clusters the reads of a loop iteration at its top and does not pipeline across iterations).
+  auto mma_phase = [&](auto th_c) {
+    constexpr int TH = decltype(th_c)::value;
+    constexpr int PD = NS == 3 ? 1 : 2;          // prefetch distance in steps (three planes: registers only allow one)
+    uint4 af[2][WNPL(NS)], bq[PD + 1][WNPL(NS)];
+    auto lda = [&](uint4 (&f)[WNPL(NS)], int kc) {
+#pragma unroll
+      for (int p = 0; p < WNPL(NS); ++p) {
+        const unsigned ad = sY_base + y_lane + (unsigned)((p * WTPIX + kc * 16) * WSY * 2);
+        f[p] = tr_frag(ad, ad + 4 * WSY * 2);
+      }
+    };
+    auto ldb = [&](uint4 (&f)[WNPL(NS)], int kc, int j) {
+      const int tp = j == 4 ? 4 : TH * 5 + j;
+      const int dy = tp / 3, dx = tp - dy * 3;
+#pragma unroll
+      for (int p = 0; p < WNPL(NS); ++p) {
+        const unsigned ad = sX_base + x_lane + (unsigned)((p * WNPIX + (kc + dy) * WPW + dx) * WSX * 2);
+        f[p] = tr_frag(ad, ad + 4 * WSX * 2);
+      }
+    };
+    lda(af[0], 0); ldb(bq[0], 0, 0);
+    if constexpr (PD == 2) ldb(bq[1], 0, 1);
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+      const int n = (kc >> 2) == TH ? 5 : 4;                                   // taps of this k-chunk
+      const int before = 4 * kc + (TH == 0 ? (kc < 4 ? kc : 4) : (kc > 4 ? kc - 4 : 0));   // steps before this k-chunk
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (j < n) {
+          const int cur = (before + j) % (PD + 1), nxt = (before + j + PD) % (PD + 1);
+          if (j + PD < n) ldb(bq[nxt], kc, j + PD);
+          else if (kc + 1 < 8) {
+            if (j + PD == n) lda(af[(kc + 1) & 1], kc + 1);
+            ldb(bq[nxt], kc + 1, j + PD - n);
+          }
+#define WA(P_) __builtin_bit_cast(bf16x8, af[kc & 1][P_])
+#define WB(P_) __builtin_bit_cast(bf16x8, bq[cur][P_])
+#define WAH(P_) __builtin_bit_cast(f16x8, af[kc & 1][P_])
+#define WBH(P_) __builtin_bit_cast(f16x8, bq[cur][P_])
+          if constexpr (NS == 4) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(0), WBH(1), acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(1), WBH(0), acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(0), WBH(0), acc[j], 0, 0, 0);
+          } else {
+            if constexpr (NS == 3) {
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(1), WB(1), acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(2), acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(2), WB(0), acc[j], 0, 0, 0);
+            }
+            if constexpr (NS >= 2) {
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(1), acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(1), WB(0), acc[j], 0, 0, 0);
+            }
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(0), acc[j], 0, 0, 0);
+          }
+#undef WA
+#undef WB
+#undef WAH
+#undef WBH
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   };
 
   const int t_beg = split * P.tiles_per_split;
   const int t_end = min(P.ntiles, t_beg + P.tiles_per_split);
   if (t_beg < t_end) gload(t_beg);
+  w3_phase_offset(P.stagger, reinterpret_cast<unsigned*>(smem));
   for (int tile = t_beg; tile < t_end; ++tile) {
     __syncthreads();                          // previous tile's fragments have been consumed
+#ifndef PDAE_W3_PROBE_NOSTAGE
     lstore();
+#endif
     __syncthreads();
-    if (tile + 1 < t_end) gload(tile + 1);    // next tile in flight under ~200 MFMAs per wave
-#pragma unroll 1
-    for (int kq = 0; kq < 4; ++kq) {
-      const int kc = kq * 2 + kh;             // tile row handled by this wave (16 pixels = one k-chunk)
-      uint4 af[WNPL(NS)];
-#pragma unroll
-      for (int p = 0; p < WNPL(NS); ++p) {
-        unsigned ad = sY_base + y_lane + (unsigned)((p * WTPIX + kc * 16) * WSY * 2);
-        af[p] = tr_frag(ad, ad + 4 * WSY * 2);
-      }
-#pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {
-        const int dy = tp / 3, dx = tp - dy * 3;
-        uint4 bfr[WNPL(NS)];
-#pragma unroll
-        for (int p = 0; p < WNPL(NS); ++p) {
-          unsigned ad = sX_base + x_lane + (unsigned)((p * WNPIX + (kc + dy) * WPW + dx) * WSX * 2);
-          bfr[p] = tr_frag(ad, ad + 4 * WSX * 2);
-        }
-#define WA(P_) __builtin_bit_cast(bf16x8, af[P_])
-#define WB(P_) __builtin_bit_cast(bf16x8, bfr[P_])
-#define WAH(P_) __builtin_bit_cast(f16x8, af[P_])
-#define WBH(P_) __builtin_bit_cast(f16x8, bfr[P_])
-        if constexpr (NS == 4) {
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(0), WBH(1), acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(1), WBH(0), acc[tp], 0, 0, 0);
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WAH(0), WBH(0), acc[tp], 0, 0, 0);
-        } else {
-          if constexpr (NS == 3) {
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(1), WB(1), acc[tp], 0, 0, 0);
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(2), acc[tp], 0, 0, 0);
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(2), WB(0), acc[tp], 0, 0, 0);
-          }
-          if constexpr (NS >= 2) {
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(1), acc[tp], 0, 0, 0);
-            acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(1), WB(0), acc[tp], 0, 0, 0);
-          }
-          acc[tp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WA(0), WB(0), acc[tp], 0, 0, 0);
-        }
-#undef WA
-#undef WB
-#undef WAH
-#undef WBH
-      }
-    }
+#ifndef PDAE_W3_PROBE_NOLOAD
+    if (tile + 1 < t_end) gload(tile + 1);    // next tile in flight under the 108 MFMAs per wave
+#endif
+#ifndef PDAE_W3_PROBE_NOMMA            // timing probes (tools/probe_build.py): wrong results by design
+    if (th == 0) mma_phase(std::integral_constant<int, 0>{}); else mma_phase(std::integral_constant<int, 1>{});
+#endif
   }
 
   if (P.db_part != nullptr) {                 // bias gradient: 16 threads share each channel quad -> LDS -> fixed-order sum
     __syncthreads();
-    if (want_db && t < 32) {
+    if (want_db && t < 16) {
       float4 s4 = bred[t];
-      for (int k = 1; k < 16; ++k) { const float4 u = bred[t + 32 * k]; s4.x += u.x; s4.y += u.y; s4.z += u.z; s4.w += u.w; }
+      for (int k = 1; k < 16; ++k) { const float4 u = bred[t + 16 * k]; s4.x += u.x; s4.y += u.y; s4.z += u.z; s4.w += u.w; }
       const int co = co0 + t * 4;
       if (co < Cout) *reinterpret_cast<float4*>(P.db_part + (size_t)split * Cout + co) = s4;      // Cout % 4 == 0
     }
   }
   const float oscale = NS == 4 ? 1.0f / (yscale * WXSCALE) : 1.0f;      // exact: both scales are powers of two
   if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
-  // epilogue: slab (split*2 + kh) of the workspace, layout [Cout][9][C]
-  float* slab = P.ws + (size_t)(split * 2 + kh) * Cout * 9 * C;
+  // the two halves of the centre tap meet in LDS (operand planes are dead now): th 1 hands its acc[4] to the th 0 wave of the same channels
+  __syncthreads();
+  float* cen = reinterpret_cast<float*>(smem) + a * 16 * 64;
+  if (th == 1) {
 #pragma unroll
-  for (int tp = 0; tp < 9; ++tp)
+    for (int r = 0; r < 16; ++r) cen[r * 64 + lane] = acc[4][r];
+  }
+  __syncthreads();
+  if (th == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[4][r] += cen[r * 64 + lane];
+  }
+  // epilogue: slab `split` of the workspace, layout [Cout][9][C]
+  float* slab = P.ws + (size_t)split * Cout * 9 * C;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    if (j == 4 && th == 1) break;
+    const int tp = j == 4 ? 4 : th * 5 + j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (co < Cout) slab[((size_t)co * 9 + tp) * C + ci0 + li] = NS == 4 ? acc[tp][r] * oscale : acc[tp][r];
+      if (co < Cout) slab[((size_t)co * 9 + tp) * C + ci0 + li] = NS == 4 ? acc[j][r] * oscale : acc[j][r];
     }
+  }
 }
 
-// split of the pixel tiles over blocks: one block per CU (147 KB of LDS at NS=3), so the grid should fill 256 CUs in whole rounds:
-// minimise rounds(grid) x tiles-per-block (a 264-block grid costs two rounds for the work of one)
+// split of the pixel tiles over blocks: two blocks per CU (60 KB of LDS in the default format), so the grid should fill 512 slots in whole
+// rounds: minimise rounds(grid) x tiles-per-block (a 520-block grid costs two rounds for the work of one)
 static void wgradp_plan(int N, int H, int W, int C, int Cout, int& splits, int& tiles_per_split) {
   const int ntiles = W == 8 ? ((N + 1) / 2) * (H / WTH) : N * (H / WTH) * (W / WTW);
-  const int base = ((Cout + 127) / 128) * (C / 32);
+  const int base = ((Cout + WCO - 1) / WCO) * (C / 32);
   int maxs = ntiles / 4; if (maxs < 1) maxs = 1;      // at least 4 tiles per block
   if (maxs > 128) maxs = 128;
   long long best = -1; int best_s = 1;
   for (int s = 1; s <= maxs; ++s) {
     const int tps = (ntiles + s - 1) / s, sp = (ntiles + tps - 1) / tps;
     if (sp != s) continue;
-    const long long rounds = ((long long)base * sp + 255) / 256;
+    const long long rounds = ((long long)base * sp + 511) / 512;
     const long long cost = rounds * (tps + 1);          // +1: per-block prologue / slab write
     if (best < 0 || cost < best) { best = cost; best_s = s; }
   }
@@ -302,11 +395,11 @@ bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, i
   return (long long)N * (H / WTH) * (W / WTW) >= 64;
 }
 
-// slabs [2*splits][Cout][9][C] + bias-gradient partials [splits][Cout]
+// slabs [splits][Cout][9][C] + bias-gradient partials [splits][Cout]
 size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout) {
   int splits, tps;
   wgradp_plan(N, H, W, C, Cout, splits, tps);
-  return ((size_t)splits * 2 * Cout * 9 * C + (size_t)splits * Cout) * sizeof(float);
+  return ((size_t)splits * Cout * 9 * C + (size_t)splits * Cout) * sizeof(float);
 }
 
 template <int NS, bool W8 = false> static int launch_w(const WgradParams& P, hipStream_t s) {
@@ -325,21 +418,23 @@ int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
                     int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax) {
   WgradParams P;
   P.dy_amax = dy_amax; P.sat = pdae_sat_counter();
+  static const int stagger = [] { const char* e = getenv("PDAE_W3_STAGGER"); return e ? atoi(e) : 64; }();
+  P.stagger = stagger;
   if (math == 4 && !dy_amax) math = 3;          // fp16 format needs the dY scale: without it the exact bf16 split runs
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.dy = dy; P.Cout = Cout; P.ws = ws;
   const bool w8 = W == 8;
   P.tiles_x = w8 ? 1 : W / WTW; P.tiles_y = H / WTH; P.ntiles = (w8 ? (N + 1) / 2 : N) * P.tiles_x * P.tiles_y;
   wgradp_plan(N, H, W, C, Cout, P.splits, P.tiles_per_split);
-  P.co_tiles = (Cout + 127) / 128; P.ci_chunks = C / 32;
-  const size_t need = ((size_t)P.splits * 2 * Cout * 9 * C + (size_t)P.splits * Cout) * sizeof(float);
-  P.db_part = db_part ? ws + (size_t)P.splits * 2 * Cout * 9 * C : nullptr;
+  P.co_tiles = (Cout + WCO - 1) / WCO; P.ci_chunks = C / 32;
+  const size_t need = ((size_t)P.splits * Cout * 9 * C + (size_t)P.splits * Cout) * sizeof(float);
+  P.db_part = db_part ? ws + (size_t)P.splits * Cout * 9 * C : nullptr;
   if (db_part) { *db_part = P.db_part; *db_rows = P.splits; }
   if (!ws || ws_bytes < need) { pdae_set_error("conv3x3w: workspace too small (%zu < %zu)", ws_bytes, need); return PDAE_EINVAL; }
   int e;
   if (w8) e = math == 1 ? launch_w<1, true>(P, s) : (math == 2 ? launch_w<2, true>(P, s) : (math == 4 ? launch_w<4, true>(P, s) : launch_w<3, true>(P, s)));
   else e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : (math == 4 ? launch_w<4>(P, s) : launch_w<3>(P, s)));
   if (e) return e;
-  return igemm_splitk_reduce(ws, dw, (long long)Cout * 9 * C, P.splits * 2, accumulate, s);
+  return igemm_splitk_reduce(ws, dw, (long long)Cout * 9 * C, P.splits, accumulate, s);
 }
 
 
@@ -351,6 +446,9 @@ int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
 // k-parity split and one slab per pixel split.  (The generic implicit-GEMM kernel ran these launches at 35-85 TFLOP/s in 6-product arithmetic.)
 // Replaces the weight gradient of the ResBlock skip_connection (module.py:276) and the attention qkv / proj_out convolutions (:412,420).
 // =============================================================================================================================
+#define W1SY 128                     // row stride (bf16) of both operands: 128 channels = 64 dwords, all four rows of a read on the same banks ...
+#define W1SWZ(pix) ((((pix) & 3)) << 5)   // ... so the channel index is XOR-swizzled with (pixel & 3) * 32
+#define W1THREADS 512
 struct Wgrad1Params {
   const float* x0; const float* x1; int C0, C1, C;      // X rows of M pixels, C = C0 + C1
   long long M;                                          // pixels
@@ -361,11 +459,11 @@ struct Wgrad1Params {
 };
 
 template <int NS>
-__global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P) {
+__global__ void __launch_bounds__(W1THREADS) conv1x1w_kernel(const Wgrad1Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
-  constexpr int SPL = WTPIX * WSY;                        // one plane of one operand: 128 pixels x (128 channels + 8 pad)
-  unsigned short* sX = smem;                              // [NPL][128][WSY]
-  unsigned short* sY = smem + WNPL(NS) * SPL;             // [NPL][128][WSY]
+  constexpr int SPL = WTPIX * W1SY;                        // one plane of one operand: 128 pixels x (128 channels + 8 pad)
+  unsigned short* sX = smem;                              // [NPL][128][W1SY]
+  unsigned short* sY = smem + WNPL(NS) * SPL;             // [NPL][128][W1SY]
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int a = wv & 3, cj = wv >> 2;
   const int li = lane & 31, h = lane >> 5, i16 = lane & 15, g16 = (lane >> 4) & 1;
@@ -381,7 +479,7 @@ __global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const unsigned lane_row = (unsigned)((h * 8 + (i16 >> 2)) * WSY), lane_col = (unsigned)(g16 * 16 + (i16 & 3) * 4), lane_swz = (unsigned)WSWZ(i16 >> 2);
+  const unsigned lane_row = (unsigned)((h * 8 + (i16 >> 2)) * W1SY), lane_col = (unsigned)(g16 * 16 + (i16 & 3) * 4), lane_swz = (unsigned)W1SWZ(i16 >> 2);
   const unsigned sY_base = (unsigned)(WNPL(NS) * SPL * 2);
 
   float4 xpre[8], ypre[8];
@@ -394,7 +492,7 @@ __global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P
     const long long m0 = (long long)tile * WTPIX;
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
-      const int idx = t + WTHREADS * l, pix = idx >> 5, c4 = idx & 31;
+      const int idx = t + W1THREADS * l, pix = idx >> 5, c4 = idx & 31;
       const long long m = m0 + pix;
       const bool inm = m < P.M;
       const long long mm = inm ? m : 0;                   // unconditional loads from clamped addresses, zeroed afterwards
@@ -416,18 +514,15 @@ __global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P
     }
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
-      const int idx = t + WTHREADS * l, pix = idx >> 5, c4 = idx & 31;
-      if constexpr (NS == 4) {
-        pdae_f16_scale4(xpre[l], WXSCALE, sat_hit);
-        ypre[l].x *= yscale; ypre[l].y *= yscale; ypre[l].z *= yscale; ypre[l].w *= yscale;
-      }
+      const int idx = t + W1THREADS * l, pix = idx >> 5, c4 = idx & 31;
+      if constexpr (NS == 4) pdae_f16_amax4(xpre[l], WXSCALE, sat_hit);
       unsigned u[WNPL(NS)], v[WNPL(NS)];
-      w_split2<NS>(xpre[l].x, xpre[l].y, u); w_split2<NS>(xpre[l].z, xpre[l].w, v);
+      w_split2<NS>(xpre[l].x, xpre[l].y, u, WXSCALE); w_split2<NS>(xpre[l].z, xpre[l].w, v, WXSCALE);
 #pragma unroll
-      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sX[(p * WTPIX + pix) * WSY + ((c4 * 4) ^ WSWZ(pix))]) = make_uint2(u[p], v[p]);
-      w_split2<NS>(ypre[l].x, ypre[l].y, u); w_split2<NS>(ypre[l].z, ypre[l].w, v);
+      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sX[(p * WTPIX + pix) * W1SY + ((c4 * 4) ^ W1SWZ(pix))]) = make_uint2(u[p], v[p]);
+      w_split2<NS>(ypre[l].x, ypre[l].y, u, yscale); w_split2<NS>(ypre[l].z, ypre[l].w, v, yscale);
 #pragma unroll
-      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * WSY + ((c4 * 4) ^ WSWZ(pix))]) = make_uint2(u[p], v[p]);
+      for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * W1SY + ((c4 * 4) ^ W1SWZ(pix))]) = make_uint2(u[p], v[p]);
     }
   };
 
@@ -443,12 +538,12 @@ __global__ void __launch_bounds__(WTHREADS) conv1x1w_kernel(const Wgrad1Params P
       uint4 af[WNPL(NS)], bfr[2][WNPL(NS)];
 #pragma unroll
       for (int p = 0; p < WNPL(NS); ++p) {
-        const unsigned ad = sY_base + (lane_row + (unsigned)((p * WTPIX + kc * 16) * WSY) + ((lane_col + a * 32) ^ lane_swz)) * 2;
-        af[p] = tr_frag(ad, ad + 4 * WSY * 2);
+        const unsigned ad = sY_base + (lane_row + (unsigned)((p * WTPIX + kc * 16) * W1SY) + ((lane_col + a * 32) ^ lane_swz)) * 2;
+        af[p] = tr_frag(ad, ad + 4 * W1SY * 2);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const unsigned bd = (lane_row + (unsigned)((p * WTPIX + kc * 16) * WSY) + ((lane_col + (cj * 2 + j) * 32) ^ lane_swz)) * 2;
-          bfr[j][p] = tr_frag(bd, bd + 4 * WSY * 2);
+          const unsigned bd = (lane_row + (unsigned)((p * WTPIX + kc * 16) * W1SY) + ((lane_col + (cj * 2 + j) * 32) ^ lane_swz)) * 2;
+          bfr[j][p] = tr_frag(bd, bd + 4 * W1SY * 2);
         }
       }
 #define WA(P_) __builtin_bit_cast(bf16x8, af[P_])
@@ -532,14 +627,14 @@ size_t conv1x1w_workspace_bytes(long long M, int C, int Cout) {
 }
 
 template <int NS> static int launch_w1(const Wgrad1Params& P, hipStream_t s) {
-  const size_t smem = (size_t)(2 * WNPL(NS) * WTPIX * WSY) * sizeof(unsigned short) + WTHREADS * sizeof(float4);
+  const size_t smem = (size_t)(2 * WNPL(NS) * WTPIX * W1SY) * sizeof(unsigned short) + W1THREADS * sizeof(float4);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv1x1w_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv1x1w: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv1x1w_kernel<NS>), dim3(P.splits * P.co_tiles * P.ci_blocks), dim3(WTHREADS), smem, s, P);
+  hipLaunchKernelGGL((conv1x1w_kernel<NS>), dim3(P.splits * P.co_tiles * P.ci_blocks), dim3(W1THREADS), smem, s, P);
   return pdae_launch_status("conv1x1w");
 }
 
