@@ -76,7 +76,7 @@ template <int NS>
 __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   constexpr int SA_PLANES = QNPL(NS) * 128 * QLDH, SA_EPI = 4 * 32 * 68 * 2;        // operand planes | epilogue transpose tiles (4 waves x 32 x 68 fp32)
   __shared__ __attribute__((aligned(16))) unsigned short sA[SA_PLANES > SA_EPI ? SA_PLANES : SA_EPI];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, h = lane >> 5;   // wave id in an SGPR: everything derived from it is scalar
   const int wm = wv >> 1, wn = wv & 1;
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;

@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
   constexpr int SA = NPL(NS) * PPLANE(PNPIX);   // A patch planes
   unsigned short* sA = smem;
 
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, h = lane >> 5;   // wave id in an SGPR: everything derived from it is scalar
   // wave tile = 128 pixels x 32 output channels: the 4 waves (PTH 8) / 2 x 4 waves (PTH 16) that share a pixel set each own ONE 32-channel
   // weight tile, so no two waves of a block load the same B fragment (the 64 x 64 wave tile made pairs of waves fetch identical fragments:
   // probe timing put ~20 % of the kernel on the weight loads through the vector-memory path; A fragments come from LDS, which has headroom)
@@ -239,15 +239,23 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
 #pragma unroll
     for (int p = 0; p < NPL(NS); ++p) bq[p] = *reinterpret_cast<const uint4*>(base + p * ps);
   };
-  // A fragments of one k-step (16 channels = half kc of the staged chunk, one tap): 2 pixel groups x planes, 16 bytes per lane each
+  // A fragments of one k-step (16 channels = half kc of the staged chunk, one tap): 4 pixel groups x planes, 16 bytes per lane each.  All eight
+  // reads share ONE address register -- group 0 / plane 0 of this tap and k-half, made opaque so that hipcc keeps it as the base -- and reach
+  // their slot through the instruction's immediate offset: the pixel groups of a wave and the planes lie at compile-time distances.  (Left to
+  // itself the compiler picked a base in the middle and formed the other seven addresses with a v_add_u32 each, 8 VALU instructions per 12 MFMAs.)
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) const u32x4* lds_u4;
+  const unsigned a_lane = (unsigned)(size_t)sA + (unsigned)(PSLOT(apix[0], h) * 2);
   auto lda = [&](uint4 (&af)[4][NPL(NS)], int tap, int kc) {
     const int dy = tap / 3, dx = tap - dy * 3;
-    const int ashift = dy * PPW + dx;
+    unsigned ab = a_lane + (unsigned)((dy * PPW + dx) * (PLDH * 2) + kc * 32);
+    asm volatile("" : "+v"(ab));
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+      const int dpix = W8 ? (a >> 1) * 10 + (a & 1) * 4 : a * 4;             // apix[a] - apix[0]
 #pragma unroll
-      for (int p = 0; p < NPL(NS); ++p)
-        af[a][p] = *reinterpret_cast<const uint4*>(&sA[p * PPLANE(PNPIX) + PSLOT(apix[a] + ashift, kc * 2 + h)]);
+      for (int p = 0; p < NPL(NS); ++p) af[a][p] = __builtin_bit_cast(uint4, *(lds_u4)(size_t)(ab + (unsigned)((p * PPLANE(PNPIX) + dpix * PLDH) * 2)));
+    }
   };
   // the MFMAs of one k-step.  Product-major order: consecutive MFMAs target different accumulators (a dependent pair is 4 issues apart)
   auto mma = [&](const uint4 (&af)[4][NPL(NS)], const uint4 (&bq)[NPL(NS)]) {
