@@ -371,52 +371,51 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
     if (P.bias) bias4 = *reinterpret_cast<const float4*>(P.bias + colb);
     if (P.bias_x) { const float4 u = *reinterpret_cast<const float4*>(P.bias_x + colb); bias4.x += u.x; bias4.y += u.y; bias4.z += u.z; bias4.w += u.w; }
   }
+  // Addresses: a wave-uniform 64-bit base per (pixel group a, row pair it) -- scalar arithmetic -- plus ONE 32-bit per-lane offset for the whole
+  // epilogue (pixel (er >> 2, er & 3) of the 2 x 4 sub-block, channel quad ec).  The per-row 64-bit index / bounds arithmetic this replaces was
+  // ~800 VALU instructions per wave, as much as five chunks of the main loop.  Tiles are full in x (W % 16 == 0 or the image-pair form) and
+  // whole 8-row groups in y, so validity is the lane's column test plus a uniform test per pixel group.
+  const bool col_ok = colb < P.Nout;
+  const unsigned lane_d = (unsigned)(((er >> 2) * P.W + (er & 3)) * P.Nout + colc);
+  const unsigned lane_d2 = (unsigned)(((er & 3) >> 1) * P.Nout + colc);          // half-resolution residual: pixel (0, (er & 3) >> 1) of the 1 x 2 sub-block
+  const size_t row_pair = (size_t)2 * P.W * P.Nout;                                // two output rows
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const int g = wm * 4 + a, bx = g & 3;
-    // destination rows of the 4 float4 this lane stores, and the residual / accumulate operands: all loads are issued up front
-    // so that their latency runs under the LDS transposition instead of serialising the stores
-    long long rowv[4];
+    const int im_a = W8 ? img + (a >> 1) : img, x0a = W8 ? (a & 1) * 4 : x0 + a * 4, y0a = y0 + wm * 8;
+    const bool grp_ok = y0a < P.H && im_a < P.N;                                   // wave-uniform
+    const size_t rb = (((size_t)im_a * P.H + y0a) * P.W + x0a) * P.Nout;           // element offset of the group's first pixel
     float4 rv[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int i = it * 8 + er;
-      const int oy = y0 + (g >> 2) * 8 + (i >> 2);
-      const int ox = W8 ? (bx & 1) * 4 + (i & 3) : x0 + bx * 4 + (i & 3);
-      const int im = W8 ? img + (bx >> 1) : img;
-      rowv[it] = (oy >= P.H || ox >= P.W || im >= P.N || colb >= P.Nout) ? -1 : ((long long)im * P.H + oy) * P.W + ox;
-      rv[it] = bias4;
-    }
-    // residual / accumulate operands: wave-uniform conditions, per-lane addresses clamped to row 0 / column 0 where the lane has nothing to
-    // store -- independent loads in flight instead of load -> wait round trips behind exec-mask branches
-    if (P.splits == 1 && P.res_mode) {
+    for (int it = 0; it < 4; ++it) rv[it] = bias4;
+    // residual / accumulate operands: all loads are issued up front (clamped column for lanes that store nothing) so that their latency runs
+    // under the LDS transposition instead of serialising the stores
+    if (grp_ok && P.splits == 1 && P.res_mode) {
+      const size_t rb2 = (((size_t)im_a * (P.H >> 1) + (y0a >> 1)) * (P.W >> 1) + (x0a >> 1)) * P.Nout;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        long long rrow = rowv[it] < 0 ? 0 : rowv[it];
-        if (P.res_mode == 2) {
-          const int ox2 = (int)(rrow % P.W); const long long t2 = rrow / P.W; const int oy2 = (int)(t2 % P.H); const long long im2 = t2 / P.H;
-          rrow = (im2 * (P.H >> 1) + (oy2 >> 1)) * (P.W >> 1) + (ox2 >> 1);
-        }
-        const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + colc);
+        const float* src = P.res_mode == 2 ? P.res + rb2 + (size_t)it * (P.W >> 1) * P.Nout + lane_d2 : P.res + rb + it * row_pair + lane_d;
+        const float4 u = *reinterpret_cast<const float4*>(src);
         rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
-    if (P.splits == 1 && P.accumulate) {
+    if (grp_ok && P.splits == 1 && P.accumulate) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const float4 u = *reinterpret_cast<const float4*>(P.y + (rowv[it] < 0 ? 0 : rowv[it]) * P.Nout + colc);
+        const float4 u = *reinterpret_cast<const float4*>(P.y + rb + it * row_pair + lane_d);
         rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + li] = NS == 4 ? acc[a][r] * oscale : acc[a][r];
+    for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + li] = acc[a][r];
+    if (!grp_ok) continue;
+    float* dst = P.splits > 1 ? P.slab + (size_t)sp * Mtot * P.Nout + rb + lane_d : P.y + rb + lane_d;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       float4 v = *reinterpret_cast<const float4*>(&tw[(it * 8 + er) * EPW + ec]);
-      if (rowv[it] < 0) continue;
-      if (P.splits > 1) { *reinterpret_cast<float4*>(P.slab + ((long long)sp * Mtot + rowv[it]) * P.Nout + colb) = v; continue; }
-      v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
-      *reinterpret_cast<float4*>(P.y + rowv[it] * P.Nout + colb) = v;
+      // the operand scales are powers of two: scaling after the transpose, fused with the bias / residual add, is exact
+      if (P.splits > 1) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
+      else { v.x = fmaf(v.x, oscale, rv[it].x); v.y = fmaf(v.y, oscale, rv[it].y); v.z = fmaf(v.z, oscale, rv[it].z); v.w = fmaf(v.w, oscale, rv[it].w); }
+      if (col_ok) *reinterpret_cast<float4*>(dst + it * row_pair) = v;
     }
   }
 }
