@@ -25,29 +25,33 @@ __device__ __forceinline__ float4 ld4(const Src2& s, size_t pix, int c) {
 __device__ __forceinline__ float ld1(const Src2& s, size_t pix, int c) {
   return c < s.C0 ? s.x0[pix * s.C0 + c] : s.x1[pix * s.C1 + (c - s.C0)];
 }
-__device__ __forceinline__ float siluf(float v) { return v / (1.0f + expf(-v)); }
+// SiLU and its derivative through v_exp_f32 / v_rcp_f32 (~2 ulp): the GroupNorm apply / backward kernels evaluate them once per element and
+// were VALU-bound, not HBM-bound, with expf + IEEE divisions (two per derivative)
+__device__ __forceinline__ float sigmoidf_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float siluf(float v) { return v * sigmoidf_fast(v); }
 __device__ __forceinline__ float dsiluf(float v) {
-  float sg = 1.0f / (1.0f + expf(-v));
+  const float sg = sigmoidf_fast(v);
   return sg * (1.0f + v * (1.0f - sg));
 }
 
-// Philox4x32-10 counter RNG: the dropout keep-mask is a pure function of (seed, offset, element quad),
-// so backward regenerates it instead of storing a mask tensor.
-__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+// Philox2x32-10 counter RNG: the dropout keep-mask is a pure function of (seed, offset, element quad), so backward regenerates it instead of
+// storing a mask tensor.  One call yields 64 bits = four 16-bit uniforms, one per element of the quad (keep-probability resolution 2^-16);
+// the 4x32 variant with a 32-bit uniform per element spent 40 quarter-rate integer multiplies per quad -- three times per dropout layer and
+// step (forward, backward reduce, backward apply) -- and made those kernels compute-bound at 4 TB/s.
+__device__ __forceinline__ uint2 philox2x32(uint2 c, unsigned k) {
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-    k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    const unsigned hi = __umulhi(0xD256D193u, c.x), lo = 0xD256D193u * c.x;
+    c = make_uint2(hi ^ k ^ c.y, lo);
+    k += 0x9E3779B9u;
   }
   return c;
 }
 __device__ __forceinline__ float4 drop_mask(unsigned long long seed, unsigned long long offset, unsigned long long quad, float p, float scale) {
-  uint4 r = philox4x32(make_uint4((unsigned)quad, (unsigned)(quad >> 32), (unsigned)offset, (unsigned)(offset >> 32)),
-                       make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
-  const float u = 2.3283064365386963e-10f;   // 2^-32
-  return make_float4((r.x * u) >= p ? scale : 0.f, (r.y * u) >= p ? scale : 0.f, (r.z * u) >= p ? scale : 0.f, (r.w * u) >= p ? scale : 0.f);
+  const uint2 r = philox2x32(make_uint2((unsigned)quad, (unsigned)offset ^ ((unsigned)(quad >> 32) * 0x85EBCA6Bu)),
+                             (unsigned)seed ^ ((unsigned)(seed >> 32) * 0xC2B2AE35u) ^ ((unsigned)(offset >> 32) * 0x27D4EB2Fu));
+  const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);      // drop when the 16-bit uniform is below p
+  return make_float4((r.x & 0xffffu) >= thr ? scale : 0.f, (r.x >> 16) >= thr ? scale : 0.f, (r.y & 0xffffu) >= thr ? scale : 0.f, (r.y >> 16) >= thr ? scale : 0.f);
 }
 
 // ----------------------------------------------------------------------------------------------
