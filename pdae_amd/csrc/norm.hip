@@ -167,12 +167,16 @@ __device__ __forceinline__ void gn_finalize_coef_body(const Src2& s, int n, int 
                                                       float* __restrict__ coef) {
   __shared__ float smean[64], srstd[64];
   const int t = threadIdx.x, lane = t & 63, cg = C / G;
-  for (int g = t >> 6; g < G; g += 4) {
+  // eight groups per wave AT ONCE (lane = group-in-octet * 8 + slice of the partials): one round trip for the partial sums, one for the shift
+  // element and one fp64 divide / sqrt sequence per wave.  (One group per wave iteration -- eight dependent global-load round trips and eight
+  // fp64 sequences in a row -- made this 300-flop kernel take 11 us, 152 times per training step.)
+  for (int g0 = (t >> 6) * 8; g0 < G; g0 += 32) {
+    const int g = g0 + (lane >> 3), j = lane & 7;
     double a = 0.0, b = 0.0;
-    for (int k = lane; k < S; k += 64) { const float* o = part + (((size_t)n * S + k) * G + g) * 2; a += o[0]; b += o[1]; }
+    if (g < G) for (int k = j; k < S; k += 8) { const float* o = part + (((size_t)n * S + k) * G + g) * 2; a += o[0]; b += o[1]; }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-    if (lane == 0) {
+    for (int off = 4; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if (j == 0 && g < G) {
       const double cnt = (double)cg * HW, K = ld1(s, (size_t)n * HW, g * cg), m = a / cnt;
       double var = b / cnt - m * m;
       if (var < 0.0) var = 0.0;
@@ -377,7 +381,9 @@ __device__ __forceinline__ void gn_bwd_finalize_body(int n, int N, int HW, int C
   if (amax0 && n == 0 && t == 0) *amax0 = 0u;      // the apply kernel (next launch on this stream) accumulates max|dx0| into it
   for (int c = t; c < C; c += 256) {
     float S0 = 0.f, S1 = 0.f;
-    for (int k = 0; k < S; ++k) { const float* o = part + (((size_t)n * S + k) * C + c) * 2; S0 += o[0]; S1 += o[1]; }
+    const float2* o2 = reinterpret_cast<const float2*>(part) + (size_t)n * S * C + c;
+#pragma unroll 8
+    for (int k = 0; k < S; ++k) { const float2 o = o2[(size_t)k * C]; S0 += o.x; S1 += o.y; }      // independent 8-byte loads, eight in flight
     const float r = rstd[n * G + c / cg], gm = gamma[c], bt = beta[c];
     float sc = 1.f, sh = 0.f, zsc = 1.f;
     if (ss) { sc = 1.0f + ss[(size_t)n * 2 * C + c]; sh = ss[(size_t)n * 2 * C + C + c]; }
