@@ -260,8 +260,18 @@ __global__ void __launch_bounds__(256) conv1x1_reduce_kernel(const PointParams P
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long row = i / n4; const int col = (int)(i - row * n4) * 4;
     float4 v = *reinterpret_cast<const float4*>(P.slab + row * P.Nout + col);
-    for (int k = 1; k < P.splits; ++k) {
-      const float4 u = *reinterpret_cast<const float4*>(P.slab + ((long long)k * P.M + row) * P.Nout + col);
+    const float* sl = P.slab + row * P.Nout + col; const long long ss = P.M * P.Nout;
+    int k = 1;                                  // four slabs in flight, added in slab order (see splitk_reduce_kernel)
+    for (; k + 4 <= P.splits; k += 4) {
+      const float4 u0 = *reinterpret_cast<const float4*>(sl + k * ss), u1 = *reinterpret_cast<const float4*>(sl + (k + 1) * ss);
+      const float4 u2 = *reinterpret_cast<const float4*>(sl + (k + 2) * ss), u3 = *reinterpret_cast<const float4*>(sl + (k + 3) * ss);
+      v.x += u0.x; v.y += u0.y; v.z += u0.z; v.w += u0.w;
+      v.x += u1.x; v.y += u1.y; v.z += u1.z; v.w += u1.w;
+      v.x += u2.x; v.y += u2.y; v.z += u2.z; v.w += u2.w;
+      v.x += u3.x; v.y += u3.y; v.z += u3.z; v.w += u3.w;
+    }
+    for (; k < P.splits; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(sl + k * ss);
       v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
     if (P.bias) { const float4 u = *reinterpret_cast<const float4*>(P.bias + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }

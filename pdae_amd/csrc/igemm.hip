@@ -546,8 +546,19 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   if (i4 >= n) return;
   if (i4 + 3 < n) {
     float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i4) : f4zero();
-    for (int k = 0; k < splits; ++k) {
-      float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * n + i4);
+    // four slabs in flight per thread, added in slab order (the sum is bit-identical to the serial loop): one load -> wait -> add round trip
+    // per slab made these few-microsecond kernels latency chains of `splits` memory round trips
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+      const float4 v0 = *reinterpret_cast<const float4*>(ws + (long long)k * n + i4), v1 = *reinterpret_cast<const float4*>(ws + (long long)(k + 1) * n + i4);
+      const float4 v2 = *reinterpret_cast<const float4*>(ws + (long long)(k + 2) * n + i4), v3 = *reinterpret_cast<const float4*>(ws + (long long)(k + 3) * n + i4);
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; k < splits; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (long long)k * n + i4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     *reinterpret_cast<float4*>(out + i4) = s;

@@ -422,7 +422,8 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(int N, int HW, int
 __device__ __forceinline__ void gn_bwd_param_one(int c, int N, int C, const float* __restrict__ pgb, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                  int accumulate) {
   float a = 0.f, b = 0.f;
-  for (int n = 0; n < N; ++n) { a += pgb[((size_t)n * C + c) * 2]; b += pgb[((size_t)n * C + c) * 2 + 1]; }
+#pragma unroll 8
+  for (int n = 0; n < N; ++n) { const float2 v = *reinterpret_cast<const float2*>(pgb + ((size_t)n * C + c) * 2); a += v.x; b += v.y; }    // eight loads in flight
   if (accumulate) { a += dgamma[c]; b += dbeta[c]; }
   dgamma[c] = a; dbeta[c] = b;
 }
