@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(256) linear_bwd_group_kernel(const LinearBwdIt
       float4 a[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8                          // eight rows of loads in flight: the serial form was a chain of M memory round trips
       for (int m = 0; m < M; ++m) {
         const float4 xv = *reinterpret_cast<const float4*>(it.x + (size_t)m * K + kq * 4);
 #pragma unroll
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(256) linear_bwd_group_kernel(const LinearBwdIt
       for (int j = 0; j < 4; ++j)
         if (n0 + j < it.n_out) {
           float sdb = 0.f;
+#pragma unroll 8
           for (int m = 0; m < M; ++m) sdb += it.dy[(size_t)m * it.n_out + n0 + j];
           it.db[n0 + j] = it.acc_w ? it.db[n0 + j] + sdb : sdb;
         }
@@ -152,6 +154,7 @@ __global__ void __launch_bounds__(256) linear_bwd_group_kernel(const LinearBwdIt
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (kq < KQ) {
     const int per = (it.n_out + 7) >> 3, nb = sl * per, ne = min(it.n_out, nb + per);
+#pragma unroll 8
     for (int n = nb; n < ne; ++n) {
       const float d = it.dy[(size_t)m * it.n_out + n];
       const float4 wv = *reinterpret_cast<const float4*>(it.w + (size_t)n * K + kq * 4);
