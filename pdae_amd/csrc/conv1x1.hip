@@ -212,42 +212,75 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   const int colb = n0 + ec;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (P.bias && P.splits == 1 && colb < P.Nout) bias4 = *reinterpret_cast<const float4*>(P.bias + colb);      // Nout % 4 == 0
+  const bool col_ok = colb < P.Nout;
+  const unsigned lane_d = (unsigned)(er * P.Nout + (col_ok ? colb : 0));     // the lane's offset inside a 4-row group: the only per-lane address term
+  const size_t row4 = (size_t)4 * P.Nout;
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    long long rowv[8];
+    const long long rbase = mw + a * 32;                                     // wave-uniform first row of this 32-row group
     float4 rv[8];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const long long row = mw + a * 32 + it * 4 + er;
-      rowv[it] = (row >= P.M || colb >= P.Nout) ? -1 : row;
-      rv[it] = bias4;
+    for (int it = 0; it < 8; ++it) rv[it] = bias4;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + li] = acc[a][b][r];
+    if (rbase + 32 <= P.M && P.res_mode != 2) {
+      // whole group, same-resolution operands: scalar 64-bit bases + lane_d, no per-row index arithmetic (see conv3x3p.hip)
+      const size_t eb = (size_t)rbase * P.Nout;
+      if (P.splits == 1 && P.res) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const float4 u = *reinterpret_cast<const float4*>(P.res + eb + it * row4 + lane_d);
+          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+        }
+      }
+      if (P.splits == 1 && P.accumulate) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const float4 u = *reinterpret_cast<const float4*>(P.y + eb + it * row4 + lane_d);
+          rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
+        }
+      }
+      float* dst = P.splits > 1 ? P.slab + (size_t)sp * P.M * P.Nout + eb + lane_d : P.y + eb + lane_d;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * 68 + ec]);
+        // the operand scales are powers of two: scaling after the transpose, fused with the bias / residual add, is exact
+        if (P.splits > 1) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
+        else { v.x = fmaf(v.x, oscale, rv[it].x); v.y = fmaf(v.y, oscale, rv[it].y); v.z = fmaf(v.z, oscale, rv[it].z); v.w = fmaf(v.w, oscale, rv[it].w); }
+        if (col_ok) *reinterpret_cast<float4*>(dst + it * row4) = v;
+      }
+      continue;
     }
-    // wave-uniform conditions, clamped per-lane addresses: eight independent loads in flight per operand (see conv3x3p.hip)
+    // partial last group or half-resolution residual: per-row indices
+    long long rowv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const long long row = rbase + it * 4 + er;
+      rowv[it] = (row >= P.M || !col_ok) ? -1 : row;
+    }
     if (P.splits == 1 && P.res) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const long long row = rowv[it] < 0 ? 0 : rowv[it];
-        const float4 u = *reinterpret_cast<const float4*>(P.res + (P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + (colb < P.Nout ? colb : 0));
+        const float4 u = *reinterpret_cast<const float4*>(P.res + (P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + (col_ok ? colb : 0));
         rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
     if (P.splits == 1 && P.accumulate) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const float4 u = *reinterpret_cast<const float4*>(P.y + (rowv[it] < 0 ? 0 : rowv[it]) * P.Nout + (colb < P.Nout ? colb : 0));
+        const float4 u = *reinterpret_cast<const float4*>(P.y + (rowv[it] < 0 ? 0 : rowv[it]) * P.Nout + (col_ok ? colb : 0));
         rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + li] = NS == 4 ? acc[a][b][r] * oscale : acc[a][b][r];
-#pragma unroll
     for (int it = 0; it < 8; ++it) {
       float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * 68 + ec]);
       if (rowv[it] < 0) continue;
-      if (P.splits > 1) { *reinterpret_cast<float4*>(P.slab + ((long long)sp * P.M + rowv[it]) * P.Nout + colb) = v; continue; }
-      v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
+      if (P.splits > 1) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; *reinterpret_cast<float4*>(P.slab + ((long long)sp * P.M + rowv[it]) * P.Nout + colb) = v; continue; }
+      v.x = fmaf(v.x, oscale, rv[it].x); v.y = fmaf(v.y, oscale, rv[it].y); v.z = fmaf(v.z, oscale, rv[it].z); v.w = fmaf(v.w, oscale, rv[it].w);
       *reinterpret_cast<float4*>(P.y + rowv[it] * P.Nout + colb) = v;
     }
   }

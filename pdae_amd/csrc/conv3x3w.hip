@@ -488,23 +488,40 @@ __global__ void __launch_bounds__(W1THREADS) conv1x1w_kernel(const Wgrad1Params 
   float4* bred = reinterpret_cast<float4*>(smem + 2 * WNPL(NS) * SPL);
   const float yscale = NS == 4 ? w_pow2_scale(*P.dy_amax) : 1.0f;
   if (want_db) bred[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // thread-constant halves of the operand addresses (see conv3x3w_kernel): slot l of this thread = pixel (t >> 5) + 16 l of the tile, channel quad t & 31
+  const int c4t = t & 31, pixt = t >> 5;
+  const bool cx_ok = ci0 + c4t * 4 < C, cy_ok = co0 + c4t * 4 < Cout;
+  const int cic = cx_ok ? ci0 + c4t * 4 : 0;
+  const bool first = cic < P.C0;                                   // which tensor of the (never materialised) concat this thread reads
+  const float* xsrc = first ? P.x0 + cic : P.x1 + (cic - P.C0);
+  const int xC = first ? P.C0 : P.C1;
+  const float* ysrc = P.dy + (cy_ok ? co0 + c4t * 4 : 0);
   auto gload = [&](int tile) {
     const long long m0 = (long long)tile * WTPIX;
+    if (m0 + WTPIX <= P.M) {                                       // whole tile (all but possibly the last): no per-row tests
+      const float* xp = xsrc + (m0 + pixt) * xC;
+      const float* yp = ysrc + (m0 + pixt) * Cout;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const float4 vx = *reinterpret_cast<const float4*>(xp + (long long)(16 * l) * xC);
+        const float4 vy = *reinterpret_cast<const float4*>(yp + (long long)(16 * l) * Cout);
+        if constexpr (NS == 4) { xpre[l] = vx; ypre[l] = vy; }      // fp16 format: channels beyond C / Cout are zeroed by their operand scale (lstore)
+        else { xpre[l] = cx_ok ? vx : make_float4(0.f, 0.f, 0.f, 0.f); ypre[l] = cy_ok ? vy : make_float4(0.f, 0.f, 0.f, 0.f); }
+      }
+      return;
+    }
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
-      const int idx = t + W1THREADS * l, pix = idx >> 5, c4 = idx & 31;
-      const long long m = m0 + pix;
+      const long long m = m0 + pixt + 16 * l;
       const bool inm = m < P.M;
       const long long mm = inm ? m : 0;                   // unconditional loads from clamped addresses, zeroed afterwards
-      const int ci = ci0 + c4 * 4, co = co0 + c4 * 4;
-      const bool okx = inm && ci < C, oky = inm && co < Cout;
-      const int cic = okx ? ci : 0;
-      const float4 vx = *reinterpret_cast<const float4*>(cic < P.C0 ? P.x0 + mm * P.C0 + cic : P.x1 + mm * P.C1 + (cic - P.C0));
-      const float4 vy = *reinterpret_cast<const float4*>(P.dy + mm * Cout + (oky ? co : 0));
-      xpre[l] = okx ? vx : make_float4(0.f, 0.f, 0.f, 0.f);
-      ypre[l] = oky ? vy : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vx = *reinterpret_cast<const float4*>(xsrc + mm * xC);
+      const float4 vy = *reinterpret_cast<const float4*>(ysrc + mm * Cout);
+      xpre[l] = (inm && cx_ok) ? vx : make_float4(0.f, 0.f, 0.f, 0.f);
+      ypre[l] = (inm && cy_ok) ? vy : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+  const float xscale_ok = cx_ok ? WXSCALE : 0.f, yscale_ok = cy_ok ? yscale : 0.f;
   auto lstore = [&]() {
     if (want_db) {
       float4 b4 = bred[t];
@@ -515,12 +532,12 @@ __global__ void __launch_bounds__(W1THREADS) conv1x1w_kernel(const Wgrad1Params 
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
       const int idx = t + W1THREADS * l, pix = idx >> 5, c4 = idx & 31;
-      if constexpr (NS == 4) pdae_f16_amax4(xpre[l], WXSCALE, sat_hit);
+      if constexpr (NS == 4) pdae_f16_amax4(xpre[l], xscale_ok, sat_hit);
       unsigned u[WNPL(NS)], v[WNPL(NS)];
-      w_split2<NS>(xpre[l].x, xpre[l].y, u, WXSCALE); w_split2<NS>(xpre[l].z, xpre[l].w, v, WXSCALE);
+      w_split2<NS>(xpre[l].x, xpre[l].y, u, xscale_ok); w_split2<NS>(xpre[l].z, xpre[l].w, v, xscale_ok);
 #pragma unroll
       for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sX[(p * WTPIX + pix) * W1SY + ((c4 * 4) ^ W1SWZ(pix))]) = make_uint2(u[p], v[p]);
-      w_split2<NS>(ypre[l].x, ypre[l].y, u, yscale); w_split2<NS>(ypre[l].z, ypre[l].w, v, yscale);
+      w_split2<NS>(ypre[l].x, ypre[l].y, u, yscale_ok); w_split2<NS>(ypre[l].z, ypre[l].w, v, yscale_ok);
 #pragma unroll
       for (int p = 0; p < WNPL(NS); ++p) *reinterpret_cast<uint2*>(&sY[(p * WTPIX + pix) * W1SY + ((c4 * 4) ^ W1SWZ(pix))]) = make_uint2(u[p], v[p]);
     }

@@ -107,14 +107,24 @@ __device__ __forceinline__ void gn_stats_partial_body(const Src2& s, int HW, int
         d = v[u].w - K[3]; s1[3] += d; s2[3] += d * d;
       }
     }
+    if ((cg & 3) == 0) {                       // a thread's four channels lie in one group: one (s1, s2) pair per thread, summed in fixed order below
+      red[(pl * NQ + q) * 2] = (s1[0] + s1[1]) + (s1[2] + s1[3]); red[(pl * NQ + q) * 2 + 1] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[(pl * C + c + j) * 2] = s1[j]; red[(pl * C + c + j) * 2 + 1] = s2[j]; }
+      for (int j = 0; j < 4; ++j) { red[(pl * C + c + j) * 2] = s1[j]; red[(pl * C + c + j) * 2 + 1] = s2[j]; }
+    }
   }
   __syncthreads();
   if (t < G) {
     float a = 0.f, b = 0.f;
-    for (int l = 0; l < PL; ++l)
-      for (int j = 0; j < cg; ++j) { a += red[(l * C + t * cg + j) * 2]; b += red[(l * C + t * cg + j) * 2 + 1]; }
+    if ((cg & 3) == 0) {                         // PL x cg/4 = 256 / G entries per group (was PL x cg single-thread LDS reads: the tail of every block)
+      const int qg = cg >> 2;
+      for (int l = 0; l < PL; ++l)
+        for (int j = 0; j < qg; ++j) { const float2 v = *reinterpret_cast<const float2*>(&red[(l * NQ + t * qg + j) * 2]); a += v.x; b += v.y; }
+    } else {
+      for (int l = 0; l < PL; ++l)
+        for (int j = 0; j < cg; ++j) { a += red[(l * C + t * cg + j) * 2]; b += red[(l * C + t * cg + j) * 2 + 1]; }
+    }
     float* o = part + (((size_t)n * S + sidx) * G + t) * 2;
     o[0] = a; o[1] = b;
   }
