@@ -231,15 +231,22 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
   //   main chunks: wp [p][chunk][tap][kc][nt][lane],  skip chunks: wps [p][chunk - nmain][kc][nt][lane]
   const int nt0 = min((n0 >> 5) + wn, P.NT - 1);
   const size_t plane_main = (size_t)nmain * 18 * P.NT * 512, plane_skip = (size_t)P.nx * 2 * P.NT * 512;      // bf16 elements per plane
+  // Buffer loads: descriptor (SGPRs) + ONE constant per-lane byte offset (lane * 16) + a scalar byte offset per step and plane, so a weight
+  // fragment load needs no vector arithmetic at all (the flat form cost two 64-bit v_lshl_add per load, most of what was left of the loop's VALU)
+  typedef unsigned pw_u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t srd_main = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.wp), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srd_skip = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.wps ? P.wps : P.wp), 0, 0x7fffffff, 0x00020000);
+  const int lane16 = lane * 16;
   auto ldb = [&](uint4 (&bq)[NPL(NS)], int chunk, int tap, int kc) {
     const bool raw = chunk >= nmain;
-    const unsigned short* base = raw ? P.wps + ((size_t)(((chunk - nmain) << 1) + kc) * P.NT + nt0) * 512 + lane * 8
-                                     : P.wp + ((size_t)(((chunk * 9 + tap) << 1) + kc) * P.NT + nt0) * 512 + lane * 8;
-    const size_t ps = raw ? plane_skip : plane_main;
     // branch-free: a tile index beyond the last one is clamped onto it (those output columns are masked in the epilogue), so the loads are
     // unconditional straight-line code and the compiler can wait for them with a COUNTED vmcnt instead of draining everything in flight
+    const unsigned soff = (unsigned)((raw ? (((chunk - nmain) << 1) + kc) * P.NT + nt0 : (((chunk * 9 + tap) << 1) + kc) * P.NT + nt0) * 1024);   // bytes
+    const unsigned ps2 = (unsigned)((raw ? plane_skip : plane_main) * 2);
 #pragma unroll
-    for (int p = 0; p < NPL(NS); ++p) bq[p] = *reinterpret_cast<const uint4*>(base + p * ps);
+    for (int p = 0; p < NPL(NS); ++p)
+      bq[p] = __builtin_bit_cast(uint4, raw ? __builtin_amdgcn_raw_buffer_load_b128(srd_skip, lane16, (int)(soff + p * ps2), 0)
+                                            : __builtin_amdgcn_raw_buffer_load_b128(srd_main, lane16, (int)(soff + p * ps2), 0));
   };
   // A fragments of one k-step (16 channels = half kc of the staged chunk, one tap): 4 pixel groups x planes, 16 bytes per lane each.  All eight
   // reads share ONE address register -- group 0 / plane 0 of this tap and k-half, made opaque so that hipcc keeps it as the base -- and reach
