@@ -88,6 +88,19 @@ int pdae_conv_skip_wprep(const pdae_conv_desc* d, const pdae_conv_desc* ds, cons
 int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
                          const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps, const float* bias_s, float* y,
                          pdae_stream_t stream);
+/* GroupNorm statistics of a convolution's OUTPUT, produced by the convolution while it stores the tensor -- the GroupNorm that follows
+ * (module.py:241,257: in_layers / out_layers norm of the next stage) then needs no pass over the tensor at all:
+ *   bytes = pdae_conv_stats_bytes(d, ds, &tpi)   size of the partial-sum buffer, 0 when the forward convolution of d (with the fused skip
+ *                                                convolution ds, or NULL) would not run as ONE launch of the 3x3 patch kernel
+ *   pdae_conv_stats_arm(part)                    one-shot: the NEXT pdae_conv2d_fwd / _fwd_gn / _fwd_skip on this host thread also writes
+ *                                                part[N][tpi][Cout/4] x (sum, sum of squares) of its output (in a pdae_op record: p[19])
+ *   pdae_gn_coef_from_conv_stats(...)            mean / rstd / coef ([mu | a | b], as pdae_gn_stats_coef) of the virtual concat of one or two such
+ *                                                tensors from their partial sums (fp64 combine); C / G and C0 must be multiples of 4. */
+size_t pdae_conv_stats_bytes(const pdae_conv_desc* d, const pdae_conv_desc* ds, int32_t* tiles_per_image);
+int pdae_conv_stats_arm(float* part);
+int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G, float eps, const float* part0, int tpi0, const float* part1, int tpi1,
+                                 const float* gamma, const float* beta, const float* ss, const float* zss, float* mean, float* rstd, float* coef,
+                                 pdae_stream_t stream);
 /* dx[N,Hl,Wl,ci_cnt] (+)= dL/d(conv input channels ci_off..ci_off+ci_cnt) on the LOGICAL input grid (Hl = 2*Hi when up).
  * wp_t: NULL or pdae_conv_wprep(d, w, PDAE_WPREP_TRANSPOSED): the data gradient then runs as a forward convolution of dy (3x3: the
  * whole channel range only; 1x1: any 32-aligned ci_off). */
@@ -255,7 +268,7 @@ enum {
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
   PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
   PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP,
-  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP
+  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP, PDAE_OP_GN_COEF_FROM_CONV_STATS
 };
 typedef struct pdae_op {
   int32_t kind;

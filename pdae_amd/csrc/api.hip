@@ -19,7 +19,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 2; }
+extern "C" int pdae_abi_version(void) { return 3; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -110,13 +110,18 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd: res_mode 2 needs even output");
-  if (tile == 0 && res_mode == 0 && convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
+  if (tile == 0 && res_mode == 0 && !conv3x3p_stats_armed() && convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
     return convhead_fwd(x0, d->N, d->Hi, d->Wi, d->C0, w, d->Cout, bias, y, S(stream));
   const int kind = wp ? fast_kind(d, 0, false) : 0;
   PDAE_CHECK_ARG(!wp || (tile == 0 && kind != 0), "conv2d_fwd: wp given but the convolution is not eligible for a prepared-weight kernel");
   if (kind == 3)
     return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
                            res_mode ? res : nullptr, res_mode, 0, S(stream));
+  if (conv3x3p_stats_armed()) {
+    conv3x3p_arm_stats(nullptr);
+    pdae_set_error("conv2d_fwd: output statistics were requested (pdae_conv_stats_arm) but this convolution does not run on the 3x3 patch kernel");
+    return PDAE_EINVAL;
+  }
   if (kind == 1)
     return conv1x1_launch(d->math, x0, d->C0, x1, d->C1, (long long)d->N * d->Ho * d->Wo, (const unsigned short*)wp, d->Cout, 0, d->Cout, y, bias,
                           res_mode ? res : nullptr, res_mode, d->Ho, d->Wo, 0, S(stream));
@@ -175,6 +180,30 @@ extern "C" int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, co
   PatchSkip sk{s0, ds->C1 ? s1 : nullptr, ds->C0, ds->C1, (const unsigned short*)wps, bias_s};
   return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias, nullptr, 0,
                          0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act, &sk);
+}
+
+// ---- GroupNorm statistics of a convolution's output, produced by the convolution itself
+extern "C" size_t pdae_conv_stats_bytes(const pdae_conv_desc* d, const pdae_conv_desc* ds, int32_t* tiles_per_image) {
+  if (tiles_per_image) *tiles_per_image = 0;
+  if (!d || check_desc(d)) return 0;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || ((d->C0 + d->C1) & 31) || (d->Cout & 3)) return 0;
+  if (ds ? !pdae_conv2d_fwd_skip_ok(d, ds) : (fast_kind(d, 0, false) != 3 && !gn_patch_ok(d, false))) return 0;
+  int tpi = 0;
+  const size_t b = conv3x3p_stats_bytes(d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, ds ? (ds->C0 + ds->C1) >> 5 : 0, &tpi);
+  if (tiles_per_image) *tiles_per_image = b ? tpi : 0;
+  return b;
+}
+extern "C" int pdae_conv_stats_arm(float* part) {
+  conv3x3p_arm_stats(part);
+  return PDAE_OK;
+}
+extern "C" int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G, float eps, const float* part0, int tpi0, const float* part1, int tpi1,
+                                            const float* gamma, const float* beta, const float* ss, const float* zss, float* mean, float* rstd,
+                                            float* coef, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(part0 && tpi0 > 0 && (C1 == 0 || (part1 && tpi1 > 0)) && gamma && beta && mean && rstd && coef, "gn_coef_from_conv_stats: null pointer");
+  PDAE_CHECK_ARG(G > 0 && G <= 64 && (C0 + C1) % G == 0 && (((C0 + C1) / G) & 3) == 0 && (C0 & 3) == 0,
+                 "gn_coef_from_conv_stats: groups must be whole channel quads (C / G and C0 multiples of 4)");
+  return k_gn_coef_from_conv_stats(N, HW, C0, C1, G, eps, part0, tpi0, C1 ? part1 : nullptr, tpi1, gamma, beta, ss, zss, mean, rstd, coef, S(stream));
 }
 
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
@@ -508,7 +537,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
 #define FM(k) ((float*)p[k])
   pdae_conv_desc d;
   switch (o.kind) {
-    case PDAE_OP_CONV_FWD: desc_from(i, d); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), p[6], F(3), F(4), (int)i[14], FM(5), (int)i[15], st);
+    case PDAE_OP_CONV_FWD: desc_from(i, d); if (p[19]) conv3x3p_arm_stats((float*)p[19]); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), p[6], F(3), F(4), (int)i[14], FM(5), (int)i[15], st);
     case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), p[3], FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], F(4), st);
     case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), FM(5), (int)i[14], p[4], (size_t)i[15], F(6), st);
     case PDAE_OP_GEMM:
@@ -518,6 +547,9 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_GN_STATS_COEF:
       return pdae_gn_stats_coef(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(2), F(3), F(4), F(5), FM(6), FM(7),
                                 FM(8), p[9], (uint32_t*)p[10], st);
+    case PDAE_OP_GN_COEF_FROM_CONV_STATS:
+      return pdae_gn_coef_from_conv_stats((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), (int)i[5], F(1), (int)i[6], F(2), F(3),
+                                          F(4), F(5), FM(6), FM(7), FM(8), st);
     case PDAE_OP_GN_COEF: return pdae_gn_coef((int)i[0], (int)i[1], (int)i[2], F(0), F(1), F(2), F(3), F(4), F(5), FM(6), st);
     case PDAE_OP_GN_APPLY:
       return pdae_gn_apply(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], F(2), (int)i[5], (int)i[6], FM(3), FM(4), (float)f[0],
@@ -562,11 +594,13 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_COLSUM: return pdae_colsum(F(0), i[0], (int)i[1], FM(1), (int)i[2], p[2], st);
     case PDAE_OP_CONV_FWD_GN:
       desc_from(i, d);
+      if (p[19]) conv3x3p_arm_stats((float*)p[19]);      // p[19] of the forward-convolution records: pdae_conv_stats_arm
       return pdae_conv2d_fwd_gn(&d, F(0), F(1), F(2), (int)i[15], p[3], F(4), F(5), (int)i[14], FM(6), st);
     case PDAE_OP_CONV_FWD_SKIP: {
       desc_from(i, d);
       pdae_conv_desc ds = d;
       ds.Hi = d.Ho; ds.Wi = d.Wo; ds.C0 = (int)i[15]; ds.C1 = (int)i[16]; ds.KH = ds.KW = 1; ds.pad = 0; ds.up = 0; ds.stride = 1;
+      if (p[19]) conv3x3p_arm_stats((float*)p[19]);
       return pdae_conv2d_fwd_skip(&d, F(0), F(1), F(2), (int)i[14], p[3], F(4), &ds, F(5), F(6), p[7], F(8), FM(9), st);
     }
     case PDAE_OP_CONV_SKIP_WPREP: {

@@ -81,6 +81,10 @@ struct PatchParams {
   const float* amax;                    // fp16 format: NULL = activations (static 2^4 pre-scale); else device scalar max|input| (pdae_amax)
                                         // -> power-of-two scale putting the input's abs-max into [1024, 2048): gradients (dY) as input
   unsigned int* sat;                    // fp16 format: saturation counter (common.h) or NULL
+  // GroupNorm statistics of the OUTPUT, fused into the epilogue (splits == 1 only): every wave writes (sum, sum of squares) of its 128 pixels
+  // for each of its eight channel quads to stat_part[image][stat_tpi wave-tiles][Nout / 4] as float2; pdae_gn_coef_from_conv_stats sums the
+  // wave-tiles in fp64.  The next GroupNorm then needs no pass over this tensor (it was 9 % of a sampling step).
+  float* stat_part; int stat_tpi;
 };
 
 // 2^(10 - floor(log2(amax))): amax * scale in [1024, 2048)  (amax == 0 or non-finite: 1)
@@ -386,6 +390,20 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
   const unsigned lane_d = (unsigned)(((er >> 2) * P.W + (er & 3)) * P.Nout + colc);
   const unsigned lane_d2 = (unsigned)(((er & 3) >> 1) * P.Nout + colc);          // half-resolution residual: pixel (0, (er & 3) >> 1) of the 1 x 2 sub-block
   const size_t row_pair = (size_t)2 * P.W * P.Nout;                                // two output rows
+  const bool want_stat = P.stat_part != nullptr;                                   // wave-uniform
+  float st1 = 0.f, st2 = 0.f;                                                      // this lane's share of the wave's output statistics
+  // the eight lanes that hold the same channel quad (er = lane >> 3) combine; lane er == 0 writes.  Wave-tile index inside its image:
+  // ((ty, tx), 128-pixel half wm); the image-pair form flushes after each image of the pair.
+  auto stat_flush = [&](int im) {
+    st1 += __shfl_xor(st1, 8); st2 += __shfl_xor(st2, 8);
+    st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
+    st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+    if (lane < 8 && col_ok && im < P.N) {
+      const int wt = (ty_i * P.tiles_x + tx_i) * (PTH / 8) + wm;
+      reinterpret_cast<float2*>(P.stat_part)[((size_t)im * P.stat_tpi + wt) * (P.Nout >> 2) + (colb >> 2)] = make_float2(st1, st2);
+    }
+    st1 = st2 = 0.f;
+  };
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int im_a = W8 ? img + (a >> 1) : img, x0a = W8 ? (a & 1) * 4 : x0 + a * 4, y0a = y0 + wm * 8;
@@ -414,7 +432,7 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * EPW + li] = acc[a][r];
-    if (!grp_ok) continue;
+    if (!grp_ok) { if (W8 && want_stat && a == 1) stat_flush(img); continue; }
     float* dst = P.splits > 1 ? P.slab + (size_t)sp * Mtot * P.Nout + rb + lane_d : P.y + rb + lane_d;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -423,8 +441,14 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
       if (P.splits > 1) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
       else { v.x = fmaf(v.x, oscale, rv[it].x); v.y = fmaf(v.y, oscale, rv[it].y); v.z = fmaf(v.z, oscale, rv[it].z); v.w = fmaf(v.w, oscale, rv[it].w); }
       if (col_ok) *reinterpret_cast<float4*>(dst + it * row_pair) = v;
+      if (want_stat) {
+        st1 += (v.x + v.y) + (v.z + v.w);
+        st2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, st2))));
+      }
     }
+    if (W8 && want_stat && a == 1) stat_flush(img);
   }
+  if (want_stat) stat_flush(W8 ? img + 1 : img);
 }
 
 // y = sum of the split slabs (fixed order) + bias + residual (+ y)
@@ -554,6 +578,21 @@ float conv3x3p_wscale(int C) { int k = 0; while ((1 << (2 * k)) < 9 * C) ++k; re
 // prepared weights + split-K slabs of the convolution (one buffer: [planes | slabs])
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { return prep_bytes(math, Nout, C) + slab_bytes(C, H, W, N, Nout); }
 
+// One-shot request: the next conv3x3p_launch on this host thread also writes the GroupNorm partial statistics of its output (forward launches
+// only; the caller sized `part` with conv3x3p_stats_bytes, which is 0 whenever the launch would split K).
+static thread_local float* g_stat_arm = nullptr;
+void conv3x3p_arm_stats(float* part) { g_stat_arm = part; }
+bool conv3x3p_stats_armed() { return g_stat_arm != nullptr; }
+size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi) {
+  if (Nout & 3) return 0;
+  PatchPlan q = patch_plan(C + 32 * fused_skip_chunks, H, W, N, Nout);
+  if (fused_skip_chunks) q.splits = 1;
+  if (q.splits != 1) return 0;
+  const int t = q.tiles_x * q.tiles_y * (q.th / 8);
+  if (tpi) *tpi = t;
+  return (size_t)N * t * (Nout >> 2) * 2 * sizeof(float);
+}
+
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1, int C0,
                     const float* coef, int act, const PatchSkip* sk, const float* amax) {
@@ -570,6 +609,8 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (coef && (q.w8 || (x1 && (C0 & 31)))) { pdae_set_error("conv3x3p: fused GroupNorm input needs W %% 16 == 0 and C0 %% 32 == 0"); return PDAE_EINVAL; }
   P.tiles_x = q.tiles_x; P.tiles_y = q.tiles_y; P.tiles_n = q.tiles_n; P.splits = q.splits; P.cps = q.cps;
   P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));
+  P.stat_part = g_stat_arm; g_stat_arm = nullptr; P.stat_tpi = q.tiles_x * q.tiles_y * (q.th / 8);
+  if (P.stat_part && (q.splits != 1 || (Nout & 3))) { pdae_set_error("conv3x3p: output statistics requested for a split-K launch"); return PDAE_EINVAL; }
 #define PDAE_P3(NS_)                                                                                                    \
   (coef ? (q.th == 16 ? launch_ns<NS_, 16, false, true>(P, s) : launch_ns<NS_, 8, false, true>(P, s))                    \
         : (q.w8 ? launch_ns<NS_, 8, true>(P, s) : q.th == 16 ? launch_ns<NS_, 16, false>(P, s) : launch_ns<NS_, 8, false>(P, s)))

@@ -57,6 +57,9 @@ int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, un
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1 = nullptr,
                     int C0 = 0, const float* coef = nullptr, int act = 0, const PatchSkip* sk = nullptr, const float* amax = nullptr);
+void conv3x3p_arm_stats(float* part);          // one-shot: the next conv3x3p_launch of this thread writes GroupNorm partial statistics of its output
+bool conv3x3p_stats_armed();
+size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi);
 size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs);
 int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s);
 bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, int Cs0, int Cs1);

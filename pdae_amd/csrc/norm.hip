@@ -171,6 +171,23 @@ __global__ void gn_coef_kernel(int N, int C, int G, const float* __restrict__ me
 
 // statistics finalize + coefficient fold in one launch: block = sample n; waves reduce the per-chunk partials of their groups
 // (double butterfly), then all threads write the per-(n,c) coefficients
+// coef = [mu | a | b] of sample n from the group statistics in LDS:  y = a * (x - mu) + b  with the GroupNorm affine and the AdaGN scale / shift
+// pairs (ss: time embedding, zss: latent shift embedding) folded in
+__device__ __forceinline__ void gn_fold_coef(int n, int N, int C, int cg, const float* smean, const float* srstd, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, const float* __restrict__ ss, const float* __restrict__ zss,
+                                             float* __restrict__ coef) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cg;
+    float k = gamma[c] * srstd[g], b = beta[c];
+    if (ss) { float sc = 1.0f + ss[(size_t)n * 2 * C + c]; k *= sc; b = b * sc + ss[(size_t)n * 2 * C + C + c]; }
+    if (zss) { float sc = 1.0f + zss[(size_t)n * 2 * C + c]; k *= sc; b = b * sc + zss[(size_t)n * 2 * C + C + c]; }
+    const size_t i = (size_t)n * C + c;
+    coef[i] = smean[g];
+    coef[(size_t)N * C + i] = k;
+    coef[(size_t)2 * N * C + i] = b;
+  }
+}
+
 __device__ __forceinline__ void gn_finalize_coef_body(const Src2& s, int n, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ ss,
                                                       const float* __restrict__ zss, float* __restrict__ mean, float* __restrict__ rstd,
@@ -195,16 +212,7 @@ __device__ __forceinline__ void gn_finalize_coef_body(const Src2& s, int n, int 
     }
   }
   __syncthreads();
-  for (int c = t; c < C; c += 256) {
-    const int g = c / cg;
-    float k = gamma[c] * srstd[g], b = beta[c];
-    if (ss) { float sc = 1.0f + ss[(size_t)n * 2 * C + c]; k *= sc; b = b * sc + ss[(size_t)n * 2 * C + C + c]; }
-    if (zss) { float sc = 1.0f + zss[(size_t)n * 2 * C + c]; k *= sc; b = b * sc + zss[(size_t)n * 2 * C + C + c]; }
-    const size_t i = (size_t)n * C + c;
-    coef[i] = smean[g];
-    coef[(size_t)N * C + i] = k;
-    coef[(size_t)2 * N * C + i] = b;
-  }
+  gn_fold_coef(n, N, C, cg, smean, srstd, gamma, beta, ss, zss, coef);
 }
 
 __global__ void __launch_bounds__(256) gn_finalize_coef_kernel(Src2 s, int N, int HW, int C, int G, int S, float eps, const float* __restrict__ part,
@@ -212,6 +220,42 @@ __global__ void __launch_bounds__(256) gn_finalize_coef_kernel(Src2 s, int N, in
                                                                const float* __restrict__ ss, const float* __restrict__ zss,
                                                                float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ coef) {
   gn_finalize_coef_body(s, blockIdx.x, N, HW, C, G, S, eps, part, gamma, beta, ss, zss, mean, rstd, coef);
+}
+
+// Group statistics + coefficients from the partial sums the 3x3 convolution kernel left behind while it stored the tensor (conv3x3p.hip,
+// PatchParams::stat_part): per source [N][tpi wave-tiles][channels / 4] x (sum, sum of squares), unshifted fp32 over 128 pixels x 4 channels
+// each, combined here in fp64.  A group is a run of cg / 4 channel quads of the virtual concat [x0 | x1]; each quad lies in one source.
+__global__ void __launch_bounds__(256) gn_coef_from_conv_stats_kernel(int N, int HW, int C0, int C1, int G, float eps, const float2* __restrict__ part0,
+                                                                      int tpi0, const float2* __restrict__ part1, int tpi1,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      const float* __restrict__ ss, const float* __restrict__ zss,
+                                                                      float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ coef) {
+  __shared__ float smean[64], srstd[64];
+  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, C = C0 + C1, cg = C / G, qg = cg >> 2, nq0 = C0 >> 2, nq1 = C1 >> 2;
+  for (int g0 = (t >> 6) * 8; g0 < G; g0 += 32) {          // eight groups per wave at once, eight lanes per group (see gn_finalize_coef_body)
+    const int g = g0 + (lane >> 3), j = lane & 7;
+    double a = 0.0, b = 0.0;
+    if (g < G)
+      for (int q = 0; q < qg; ++q) {
+        const int cq = g * qg + q;
+        const bool first = cq < nq0;
+        const float2* src = first ? part0 + (size_t)n * tpi0 * nq0 + cq : part1 + (size_t)n * tpi1 * nq1 + (cq - nq0);
+        const int tpi = first ? tpi0 : tpi1, nq = first ? nq0 : nq1;
+#pragma unroll 4
+        for (int k = j; k < tpi; k += 8) { const float2 v = src[(size_t)k * nq]; a += v.x; b += v.y; }
+      }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    if (j == 0 && g < G) {
+      const double cnt = (double)cg * HW, m = a / cnt;
+      double var = b / cnt - m * m;
+      if (var < 0.0) var = 0.0;
+      smean[g] = (float)m; srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+      mean[n * G + g] = smean[g]; rstd[n * G + g] = srstd[g];
+    }
+  }
+  __syncthreads();
+  gn_fold_coef(n, N, C, cg, smean, srstd, gamma, beta, ss, zss, coef);
 }
 
 // statistics + finalize + coefficient fold in ONE launch: the partial-sum kernel, whose last block per sample finishes that sample
@@ -562,6 +606,14 @@ int k_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, 
   hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(S, N), dim3(256), 0, st, s, HW, C, G, chunk, ws);
   hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, st, s, N, HW, C, G, S, eps, ws, mean, rstd);
   return pdae_launch_status("gn_stats");
+}
+
+int k_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G, float eps, const float* part0, int tpi0, const float* part1, int tpi1,
+                              const float* gamma, const float* beta, const float* ss, const float* zss, float* mean, float* rstd, float* coef,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(gn_coef_from_conv_stats_kernel, dim3(N), dim3(256), 0, st, N, HW, C0, C1, G, eps, reinterpret_cast<const float2*>(part0), tpi0,
+                     reinterpret_cast<const float2*>(part1), tpi1, gamma, beta, ss, zss, mean, rstd, coef);
+  return pdae_launch_status("gn_coef_from_conv_stats");
 }
 
 int k_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma, const float* beta,

@@ -162,6 +162,10 @@ class Builder:
         self.fuse_db = os.environ.get("PDAE_FUSE_DB", "1") != "0"      # bias gradients ride in the weight-gradient launch
         self.fuse_skip = os.environ.get("PDAE_FUSE_SKIP", "1") != "0"  # ResBlock skip_connection rides in conv2's K loop (conv_skip)
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
+        # forward 3x3 convolutions leave the GroupNorm partial statistics of their output behind (pdae_conv_stats_arm); the GroupNorm that
+        # reads such a tensor takes them instead of a statistics pass over it
+        self.fuse_stats = os.environ.get("PDAE_FUSE_GN_STATS", "1") != "0"
+        self._ystats = {}         # id(tensor) -> (tensor, partial sums, wave-tiles per image)
         self.fuse_attn = os.environ.get("PDAE_FUSE_ATTN", "1") != "0"  # QK^T -> softmax -> PV (and its backward) as one kernel (pdae_attn_fwd / _bwd)
         self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
         self._frozen_wp = {}
@@ -174,6 +178,39 @@ class Builder:
         self.drop_p = drop_p
         self.drop_layers = 0
 
+    # ------------------------------------------------------------------ fused output statistics
+    def _stats_buf(self, c, cs=None):
+        """Partial-statistics buffer for the output of forward convolution c (None when it is not a single patch-kernel launch)."""
+        if not self.fuse_stats:
+            return None, 0
+        nbytes, tpi = H.conv_stats_bytes(c, cs)
+        if nbytes == 0:
+            return None, 0
+        part = torch.empty(nbytes // 4, dtype=torch.float32, device=self.p.device)      # lives as long as the plan: any later GroupNorm may read it
+        self.p.live.append(part)
+        self.p.bytes_alloc += nbytes
+        return part, tpi
+
+    def _note_stats(self, y, part, tpi):
+        if part is not None:
+            self._ystats[id(y)] = (y, part, tpi)
+
+    def _stats_of(self, x):
+        e = self._ystats.get(id(x)) if x is not None else None
+        return (e[1], e[2]) if (e is not None and e[0] is x) else None        # identity check: a recycled buffer is a new tensor object
+
+    def _gn_stats_coef(self, x0, C0, x1, C1, N, HW, gamma, beta, ss, zss, mean, rstd, coef):
+        """GroupNorm statistics + coefficients of [x0 | x1]: from the partial sums of the producing convolutions when every source has them."""
+        pl = self.p
+        s0, s1 = self._stats_of(x0), self._stats_of(x1)
+        C = C0 + C1
+        if s0 is not None and (x1 is None or s1 is not None) and (C // GROUPS) % 4 == 0 and C0 % 4 == 0:
+            pl.emit(H.op_gn_coef_from_conv_stats(N, HW, C0, C1, GROUPS, GN_EPS, s0[0], s0[1], s1[0] if s1 else None, s1[1] if s1 else 0,
+                                                 gamma, beta, ss, zss, mean, rstd, coef))
+            return
+        pl.need_ws(H.gn_ws_bytes(N, C))
+        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, HW, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None, ticket=pl.tickets(N)), ws_slot=9)
+
     # ------------------------------------------------------------------ primitives
     def conv(self, x0, x1, wname, k, stride=1, up=False, res=None, res_mode=0, bias=True):
         N, Hh, W, C0 = x0.shape
@@ -184,7 +221,9 @@ class Builder:
         assert w.numel() == c.Cout * k * k * c.Cin, (wname, tuple(w.shape), c.Cin)
         y = self.p.buf(N, c.Ho, c.Wo, c.Cout)
         wp = self._wprep(c, w, 0)
-        self.p.emit(H.op_conv_fwd(c, x0, x1, w, b, y, res=res, res_mode=res_mode, wp=wp))
+        part, tpi = self._stats_buf(c) if (wp is not None and k == 3) else (None, 0)
+        self.p.emit(H.op_conv_fwd(c, x0, x1, w, b, y, res=res, res_mode=res_mode, wp=wp, stats=part))
+        self._note_stats(y, part, tpi)
         if wp is not None:
             self.p.free(wp)
         return y, NS(c=c, x0=x0, x1=x1, wname=wname, y=y)
@@ -399,7 +438,9 @@ class Builder:
         cs, s0, s1, wps, bs, cs_ctx = sp
         wp = self._wprep(c, w, 0)
         y = self.p.buf(N, c.Ho, c.Wo, c.Cout)
-        self.p.emit(H.op_conv_fwd_skip(c, x, None, None, 0, wp, b, cs, s0, s1, wps, bs, y))
+        part, tpi = self._stats_buf(c, cs)
+        self.p.emit(H.op_conv_fwd_skip(c, x, None, None, 0, wp, b, cs, s0, s1, wps, bs, y, stats=part))
+        self._note_stats(y, part, tpi)
         self.p.free(wp, wps)
         return y, NS(c=c, x0=x, x1=None, wname=wname, y=y), cs_ctx
 
@@ -421,17 +462,19 @@ class Builder:
             return None
         pl = self.p
         gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]
-        pl.need_ws(H.gn_ws_bytes(N, C))
         mean, rstd, coef = pl.buf(N * GROUPS), pl.buf(N * GROUPS), pl.buf(3, N, C)
-        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None, ticket=pl.tickets(N)), ws_slot=9)
+        self._gn_stats_coef(x0, C0, x1, C1, N, Hh * W, gamma, beta, ss, zss, mean, rstd, coef)
         wp = self._wprep(c, w, 0, gn=True)
         y = pl.buf(N, c.Ho, c.Wo, c.Cout)
         if sp is not None:
             cs, s0, s1, wps, bs, _ = sp
-            pl.emit(H.op_conv_fwd_skip(c, x0, x1, coef, 1, wp, b, cs, s0, s1, wps, bs, y))
+            part, tpi = self._stats_buf(c, cs)
+            pl.emit(H.op_conv_fwd_skip(c, x0, x1, coef, 1, wp, b, cs, s0, s1, wps, bs, y, stats=part))
             pl.free(wps)
         else:
-            pl.emit(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, b, y, res=res, res_mode=res_mode))
+            part, tpi = self._stats_buf(c)
+            pl.emit(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, b, y, res=res, res_mode=res_mode, stats=part))
+        self._note_stats(y, part, tpi)
         pl.free(mean, rstd, coef, wp)
         return y
 
@@ -442,12 +485,11 @@ class Builder:
         C = C0 + C1
         gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]
         pl = self.p
-        pl.need_ws(H.gn_ws_bytes(N, C))
         mean, rstd, coef = pl.buf(N * GROUPS), pl.buf(N * GROUPS), pl.buf(3, N, C)
         Ho, Wo = (Hh // 2, W // 2) if mode == 1 else (Hh, W)
         y = pl.buf(N, Ho, Wo, C)
         xpool = pl.buf(N, Ho, Wo, C) if (mode == 1 and want_xpool) else None
-        pl.emit(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, GROUPS, GN_EPS, gamma, beta, ss, zss, mean, rstd, coef, None, ticket=pl.tickets(N)), ws_slot=9)
+        self._gn_stats_coef(x0, C0, x1, C1, N, Hh * W, gamma, beta, ss, zss, mean, rstd, coef)
         dp = self.drop_p if dropout else 0.0
         layer = 0
         if dp > 0:

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PDAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpdae
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
  OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX,
- OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD, OP_LINEAR_BWD_GROUP) = range(1, 42)
+ OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD, OP_LINEAR_BWD_GROUP, OP_GN_COEF_FROM_CONV_STATS) = range(1, 43)
 
 
 class PdaeOp(ctypes.Structure):
@@ -83,6 +83,8 @@ def lib():
         L.pdae_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
         L.pdae_colsum_workspace_bytes.restype = ctypes.c_size_t
         L.pdae_abi_version.restype = ctypes.c_int
+        L.pdae_conv_stats_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.pdae_conv_stats_bytes.restype = ctypes.c_size_t
         L.pdae_ssim_mse_workspace_bytes.restype = ctypes.c_size_t
         L.pdae_ssim_mse_workspace_bytes.argtypes = [ctypes.c_int] * 4
         L.pdae_ssim_mse.restype = ctypes.c_int
@@ -101,7 +103,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_bwd_group", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
@@ -237,18 +239,38 @@ class Conv:
         return int(lib().pdae_conv2d_wgrad_workspace_bytes(ctypes.byref(d)))
 
 
-def op_conv_fwd(c, x0, x1, w, bias, y, res=None, res_mode=0, tile=0, wp=None):
-    return make_op(OP_CONV_FWD, [x0, x1, w, bias, res, y, wp], c.fields() + [res_mode, tile])
+def _arm_stats(op, stats):
+    """stats: partial-sum buffer of pdae_conv_stats_bytes(c) bytes -> pointer slot 19 of a forward-convolution record (pdae_conv_stats_arm)."""
+    if stats is not None:
+        op.p[19] = _ptr(stats)
+    return op
 
 
-def op_conv_fwd_gn(c, x0, x1, coef, act, wp, bias, y, res=None, res_mode=0):
+def op_conv_fwd(c, x0, x1, w, bias, y, res=None, res_mode=0, tile=0, wp=None, stats=None):
+    return _arm_stats(make_op(OP_CONV_FWD, [x0, x1, w, bias, res, y, wp], c.fields() + [res_mode, tile]), stats)
+
+
+def op_conv_fwd_gn(c, x0, x1, coef, act, wp, bias, y, res=None, res_mode=0, stats=None):
     """conv of act(GN-affine(x)): GroupNorm/AdaGN(+SiLU) applied in the patch staging (pdae_conv2d_fwd_gn)."""
-    return make_op(OP_CONV_FWD_GN, [x0, x1, coef, wp, bias, res, y], c.fields() + [res_mode, act])
+    return _arm_stats(make_op(OP_CONV_FWD_GN, [x0, x1, coef, wp, bias, res, y], c.fields() + [res_mode, act]), stats)
 
 
-def op_conv_fwd_skip(c, x0, x1, coef, act, wp, bias, cs, s0, s1, wps, bias_s, y):
+def op_conv_fwd_skip(c, x0, x1, coef, act, wp, bias, cs, s0, s1, wps, bias_s, y, stats=None):
     """y = conv3x3_c(in) + bias + conv1x1_cs([s0 | s1]) + bias_s in one launch (pdae_conv2d_fwd_skip)."""
-    return make_op(OP_CONV_FWD_SKIP, [x0, x1, coef, wp, bias, s0, s1, wps, bias_s, y], c.fields() + [act, cs.C0, cs.C1])
+    return _arm_stats(make_op(OP_CONV_FWD_SKIP, [x0, x1, coef, wp, bias, s0, s1, wps, bias_s, y], c.fields() + [act, cs.C0, cs.C1]), stats)
+
+
+def conv_stats_bytes(c, cs=None):
+    """(bytes, wave-tiles per image) of the GroupNorm partial statistics the forward convolution c (with fused skip cs) can leave behind while
+    it stores its output; (0, 0) when it would not run as one launch of the 3x3 patch kernel (pdae_conv_stats_bytes)."""
+    d = c.cdesc()
+    tpi = ctypes.c_int32(0)
+    if cs is None:
+        b = lib().pdae_conv_stats_bytes(ctypes.byref(d), None, ctypes.byref(tpi))
+    else:
+        ds = cs.cdesc()
+        b = lib().pdae_conv_stats_bytes(ctypes.byref(d), ctypes.byref(ds), ctypes.byref(tpi))
+    return int(b), int(tpi.value)
 
 
 def op_conv_skip_wprep(c, cs, w_skip, wps):
@@ -342,6 +364,11 @@ def op_gn_stats(x0, C0, x1, C1, N, HW, G, eps, mean, rstd, ws):
 
 def op_gn_stats_coef(x0, C0, x1, C1, N, HW, G, eps, gamma, beta, ss, zss, mean, rstd, coef, ws, ticket=None):
     return make_op(OP_GN_STATS_COEF, [x0, x1, gamma, beta, ss, zss, mean, rstd, coef, ws, ticket], [C0, C1, N, HW, G], [eps])
+
+
+def op_gn_coef_from_conv_stats(N, HW, C0, C1, G, eps, part0, tpi0, part1, tpi1, gamma, beta, ss, zss, mean, rstd, coef):
+    """mean / rstd / coef of [x0 | x1] from the partial sums their producing convolutions wrote (pdae_gn_coef_from_conv_stats)."""
+    return make_op(OP_GN_COEF_FROM_CONV_STATS, [part0, part1, gamma, beta, ss, zss, mean, rstd, coef], [N, HW, C0, C1, G, tpi0, tpi1], [eps])
 
 
 def op_gn_coef(N, C, G, mean, rstd, gamma, beta, ss, zss, coef):

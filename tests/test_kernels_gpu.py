@@ -615,6 +615,68 @@ def test_conv_with_fused_skip_connection(H, case, math_mode):
     assert rel_err(nchw(y), y_ref) < tol
 
 
+@pytest.mark.parametrize("case", [(8, 64, 64, 32, 0, 128, "plain"), (3, 16, 48, 32, 0, 256, "plain"), (5, 8, 8, 32, 0, 128, "plain"), (32, 32, 32, 32, 0, 128, "skip"),
+                                  (32, 64, 64, 32, 32, 128, "gn"), (16, 64, 32, 64, 0, 128, "skip"), (32, 128, 128, 128, 0, 128, "plain")])
+def test_groupnorm_statistics_from_the_producing_convolution(H, case):
+    """pdae_conv_stats_arm + pdae_gn_coef_from_conv_stats: the 3x3 forward kernels (plain, fused-GroupNorm input, fused skip, image-pair tiles,
+    odd batch) leave per-wave (sum, sum of squares) of their OUTPUT behind, and the next GroupNorm's mean / rstd / coefficients computed from
+    them match the statistics pass over the stored tensor -- alone and as the second source of a two-tensor concat."""
+    N, Hh, W, C0, C1, Cout, form = case
+    C, G = C0 + C1, 32
+    x = rn(1, N, C, Hh, W) * 1.3 + 0.4
+    w = rn(2, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(3, Cout, scale=0.5) + 0.8       # a mean well away from zero
+    c = H.Conv(N, Hh, W, C0, C1, Cout, k=3, math=4)
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous(); x1 = xh[..., C0:].contiguous() if C1 else None
+    wd, bd = nhwc(w).cuda(), b.cuda()
+    y = torch.empty(N, Hh, W, Cout, device="cuda")
+    cs = None
+    if form == "skip":
+        cs = H.Conv(N, Hh, W, C0, 0, Cout, k=1, math=4)
+        assert H.conv_fwd_skip_ok(c, cs)
+    nbytes, tpi = H.conv_stats_bytes(c, cs)
+    assert nbytes > 0 and tpi > 0, "the launch would split K: pick a shape that fills the chip in one pass"
+    part = torch.full((nbytes // 4,), float("nan"), device="cuda")                              # every entry must be written
+    if form == "plain":
+        wp = torch.empty(c.wprep_bytes(0, force=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 0, wp))
+        H.run(H.op_conv_fwd(c, x0, None, wd, bd, y, wp=wp, stats=part))
+    else:
+        gamma, beta = (1 + 0.2 * rn(7, C)).cuda(), (0.2 * rn(8, C) + 0.4).cuda()
+        mean = torch.empty(N * G, device="cuda"); rstd = torch.empty(N * G, device="cuda"); coef = torch.empty(3, N, C, device="cuda")
+        H.run(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hh * W, G, 1e-5, gamma, beta, None, None, mean, rstd, coef, ws(H.gn_ws_bytes(N, C))))
+        wp = torch.empty(c.wprep_bytes(0, force=True, gn=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 4, wp))
+        if form == "gn":
+            H.run(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, bd, y, stats=part))
+        else:
+            wsk = rn(5, Cout, C0, 1, 1, scale=1.0 / math.sqrt(C0)); bsk = rn(6, Cout, scale=0.1)
+            wps = torch.empty(H.conv_skip_wprep_bytes(c, cs) // 4, device="cuda")
+            H.run(H.op_conv_skip_wprep(c, cs, nhwc(wsk).cuda(), wps))
+            H.run(H.op_conv_fwd_skip(c, x0, None, coef, 1, wp, bd, cs, x0, None, wps, bsk.cuda(), y, stats=part))
+    assert torch.isfinite(part).all()
+    # the same convolution without the request stores the same tensor
+    y_plain = torch.empty_like(y)
+    if form == "plain":
+        H.run(H.op_conv_fwd(c, x0, None, wd, bd, y_plain, wp=wp))
+        assert torch.equal(y, y_plain)
+    g2, b2 = (1 + 0.1 * rn(9, Cout)).cuda(), (0.1 * rn(10, Cout)).cuda()
+    ss = (0.3 * rn(11, N, 2 * Cout)).cuda()
+
+    def both(C0_, x0_, p0, C1_, x1_, p1, gam, bet, ss_):
+        Ct = C0_ + C1_
+        m_a, r_a, k_a = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, Ct, device="cuda")
+        m_b, r_b, k_b = torch.empty_like(m_a), torch.empty_like(r_a), torch.empty_like(k_a)
+        H.run(H.op_gn_stats_coef(x0_, C0_, x1_, C1_, N, Hh * W, G, 1e-5, gam, bet, ss_, None, m_a, r_a, k_a, ws(H.gn_ws_bytes(N, Ct))))
+        H.run(H.op_gn_coef_from_conv_stats(N, Hh * W, C0_, C1_, G, 1e-5, p0, tpi, p1, tpi if p1 is not None else 0, gam, bet, ss_, None, m_b, r_b, k_b))
+        assert (m_a - m_b).abs().max() < 2e-6 * max(1.0, float(m_a.abs().max()))
+        assert rel_err(r_b, r_a) < 5e-6 and rel_err(k_b, k_a) < 5e-6
+    both(Cout, y, part, 0, None, None, g2, b2, ss)
+    if Cout % 8 == 0:                                           # groups of the concat [y | y] are still whole channel quads
+        g3, b3 = torch.cat([g2, g2 * 0.9]), torch.cat([b2, b2 + 0.1])
+        both(Cout, y, part, Cout, y, part, g3, b3, None)
+
+
 @pytest.mark.parametrize("gscale", [1.0, 3e-7, 2e4])
 @pytest.mark.parametrize("case", [(4, 32, 32, 64, 128), (2, 16, 48, 128, 96), (3, 8, 8, 64, 64), (8, 64, 64, 32, 32),
                                   (16, 8, 8, 64, 64), (17, 8, 8, 32, 96), (8, 16, 8, 64, 32)])      # 8-wide: image-pair tiles in conv3x3w
