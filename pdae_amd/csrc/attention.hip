@@ -47,17 +47,30 @@ __device__ __forceinline__ void at_gemm_nt(const float* __restrict__ A, long lon
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
   float* sa = sm; float* sb = sm + AT_ROWS * AT_LDK;
   const int row0 = (wv & 1) * 32, colb = (wv >> 1) * NB;
+  // the next chunk's rows travel global -> registers under this chunk's MFMAs (the load -> LDS -> barrier sequence used to sit exposed in
+  // front of every chunk: these kernels run one block of four waves per CU, nothing else hides it)
+  constexpr int NL = 2 + 2 * NB;                       // float4 per thread and chunk: (64 + T) rows x 8 quads / 256 threads
+  float4 pre[NL];
+  auto gl = [&](int c0) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const int i = t + 256 * l, r = i >> 3, q = (i & 7) * 4;
+      pre[l] = r < AT_ROWS ? *reinterpret_cast<const float4*>(A + (long long)r * lda + c0 + q)
+                           : *reinterpret_cast<const float4*>(B + (long long)(r - AT_ROWS) * ldb + c0 + q);
+    }
+  };
+  gl(0);
   for (int c0 = 0; c0 < ch; c0 += AT_KC) {
     __syncthreads();                                   // the previous chunk has been consumed
-    for (int i = t; i < (AT_ROWS + T) * (AT_KC / 4); i += 256) {
-      const int r = i >> 3, q = (i & 7) * 4;
-      const float4 v = r < AT_ROWS ? *reinterpret_cast<const float4*>(A + (long long)r * lda + c0 + q)
-                                   : *reinterpret_cast<const float4*>(B + (long long)(r - AT_ROWS) * ldb + c0 + q);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      const int i = t + 256 * l, r = i >> 3, q = (i & 7) * 4;
       float* d = sm + r * AT_LDK + q;                  // 8-byte aligned (AT_LDK even): two ds_write_b64
-      *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
-      *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+      *reinterpret_cast<float2*>(d) = make_float2(pre[l].x, pre[l].y);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(pre[l].z, pre[l].w);
     }
     __syncthreads();
+    if (c0 + AT_KC < ch) gl(c0 + AT_KC);
 #pragma unroll
     for (int m = 0; m < AT_KC / 4; ++m) {              // 4 channels per iteration = 2 MFMAs: k set {4m+2h, 4m+2h+1}
       const float2 a = *reinterpret_cast<const float2*>(sa + (row0 + li) * AT_LDK + 4 * m + 2 * h);
@@ -73,22 +86,32 @@ __device__ __forceinline__ void at_gemm_nt(const float* __restrict__ A, long lon
 
 // dst[64 rows][ch] (global, row stride ldd) = alpha * M[64][T] (LDS, row stride T + 1) * B[T][ch] (global, row stride ldb).
 // sv: >= T * AT_LDV floats.  All 256 threads must call it; M must be complete (caller syncs).
+template <int NB>
 __device__ __forceinline__ void at_gemm_nn(const float* sM, const float* __restrict__ B, long long ldb, int ch, int T, float alpha,
                                            float* __restrict__ dst, long long ldd, float* sv) {
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, h = lane >> 5;
   const int row0 = (wv & 1) * 32, colw = (wv >> 1) * 32, ldm = T + 1;
+  constexpr int NL = 4 * NB;                           // float4 per thread and chunk: T rows x 16 quads / 256 threads
+  float4 pre[NL];
+  const int pq = (t & 15) * 4;                         // this thread's channel quad inside a chunk; rows (t >> 4) + 16 l
+  auto gl = [&](int c0) {                              // next chunk's rows: global -> registers under this chunk's MFMAs (see at_gemm_nt)
+    const int cq = c0 + pq < ch ? c0 + pq : 0;         // quads beyond the last channel load a valid address and are never stored to LDS
+#pragma unroll
+    for (int l = 0; l < NL; ++l) pre[l] = *reinterpret_cast<const float4*>(B + (long long)((t >> 4) + 16 * l) * ldb + cq);
+  };
+  gl(0);
   for (int c0 = 0; c0 < ch; c0 += AT_VC) {
     const int cw = min(AT_VC, ch - c0);                // 32 or 64 valid channels
     __syncthreads();
-    for (int i = t; i < T * (AT_VC / 4); i += 256) {
-      const int r = i >> 4, q = (i & 15) * 4;
-      if (q < cw) {
-        const float4 v = *reinterpret_cast<const float4*>(B + (long long)r * ldb + c0 + q);
-        float* d = sv + r * AT_LDV + q;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    if (pq < cw) {
+#pragma unroll
+      for (int l = 0; l < NL; ++l) {
+        float* d = sv + ((t >> 4) + 16 * l) * AT_LDV + pq;
+        d[0] = pre[l].x; d[1] = pre[l].y; d[2] = pre[l].z; d[3] = pre[l].w;
       }
     }
     __syncthreads();
+    if (c0 + AT_VC < ch) gl(c0 + AT_VC);
     if (colw < cw) {
       f32x16 acc;
 #pragma unroll
@@ -150,7 +173,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams P) {
     if (lane == 0 && P.lse_out) P.lse_out[((long long)n * P.heads + hd) * T + q0 + row] = mx + logf(sum);
   }
   __syncthreads();
-  at_gemm_nn(sM, base + P.ov, ld3, P.ch, T, 1.0f, P.out + ((long long)n * T + q0) * P.C + hd * P.ch, P.C, st);
+  at_gemm_nn<NB>(sM, base + P.ov, ld3, P.ch, T, 1.0f, P.out + ((long long)n * T + q0) * P.C + hd * P.ch, P.C, st);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -211,7 +234,7 @@ __global__ void __launch_bounds__(256) attn_bwd_q_kernel(const AttnParams P) {
   at_p_ds<NB>(s, dp, svec, svec + AT_ROWS, true, row0, colb, P.scale2, li, h);
   at_store_tile<NB>(sM, ldm, dp, row0, colb, li, h);                                                // dS
   __syncthreads();
-  at_gemm_nn(sM, base + P.ok, ld3, P.ch, T, P.scale2, P.dqkv + ((long long)n * T + q0) * ld3 + hd * P.hs + P.oq, ld3, st);   // dQ = s dS K
+  at_gemm_nn<NB>(sM, base + P.ok, ld3, P.ch, T, P.scale2, P.dqkv + ((long long)n * T + q0) * ld3 + hd * P.hs + P.oq, ld3, st);   // dQ = s dS K
 }
 
 template <int NB>
@@ -235,11 +258,11 @@ __global__ void __launch_bounds__(256) attn_bwd_kv_kernel(const AttnParams P) {
   float* dq = P.dqkv + ((long long)n * T + k0) * ld3 + hd * P.hs;
   at_store_tile<NB>(sM, ldm, s, row0, colb, li, h);                                                 // P^T
   __syncthreads();
-  at_gemm_nn(sM, dO, P.C, P.ch, T, 1.0f, dq + P.ov, ld3, st);                                       // dV = P^T dO
+  at_gemm_nn<NB>(sM, dO, P.C, P.ch, T, 1.0f, dq + P.ov, ld3, st);                                       // dV = P^T dO
   __syncthreads();
   at_store_tile<NB>(sM, ldm, dp, row0, colb, li, h);                                                // dS^T
   __syncthreads();
-  at_gemm_nn(sM, base + P.oq, ld3, P.ch, T, P.scale2, dq + P.ok, ld3, st);                          // dK = s dS^T Q
+  at_gemm_nn<NB>(sM, base + P.oq, ld3, P.ch, T, P.scale2, dq + P.ok, ld3, st);                          // dK = s dS^T Q
 }
 
 // ------------------------------------------------------------------------------------------------ host
