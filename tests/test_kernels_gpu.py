@@ -277,6 +277,24 @@ def test_dropout_mask_consistency(H):
     H.run(H.op_gn_bwd(x, C, None, 0, N, Hh, W, G, coef, rstd, gamma, beta, None, None, dA, 0, 0, wsp, dx0=dx, dgamma=dg, dbeta=db,
                       drop_p=p, seed=1234, offset=7))
     assert rel_err(db, (keep.float() / (1 - p)).sum((0, 1, 2))) < 1e-5
+    # the mask stream: keep rate at the configured probability (16-bit uniforms: resolution 1.5e-5), a new mask per step offset and per layer
+    # seed, no correlation between the four lanes of a Philox2x32 call or between neighbouring quads
+    for pp in (0.1, 0.5):
+        ya = torch.empty_like(x); yb = torch.empty_like(x); yc = torch.empty_like(x)
+        H.run(H.op_gn_apply(x, C, None, 0, N, Hh, W, coef, 0, 0, ya, drop_p=pp, seed=3, offset=11))
+        H.run(H.op_gn_apply(x, C, None, 0, N, Hh, W, coef, 0, 0, yb, drop_p=pp, seed=3, offset=12))
+        H.run(H.op_gn_apply(x, C, None, 0, N, Hh, W, coef, 0, 0, yc, drop_p=pp, seed=4, offset=11))
+        ka, kb, kc = (ya != 0).float(), (yb != 0).float(), (yc != 0).float()
+        n = ka.numel()
+        sigma = math.sqrt(pp * (1 - pp) / n)
+        for k in (ka, kb, kc):
+            assert abs(k.mean().item() - (1 - pp)) < 5 * sigma + 2e-5
+        for u, v in ((ka, kb), (ka, kc)):                                  # independent masks: agreement rate = p^2 + (1-p)^2
+            assert abs((u == v).float().mean().item() - (pp * pp + (1 - pp) * (1 - pp))) < 6 * math.sqrt(0.25 / n)
+        flat = ka.reshape(-1, 4)                                           # the four elements of a quad come from one call
+        for i in range(1, 4):
+            cov = ((flat[:, 0] - (1 - pp)) * (flat[:, i] - (1 - pp))).mean().item()
+            assert abs(cov) < 6 * pp * (1 - pp) / math.sqrt(flat.shape[0])
 
 
 def test_elementwise_diffusion(H):
