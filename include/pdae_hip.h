@@ -29,7 +29,7 @@ extern "C" {
 typedef void* pdae_stream_t; /* hipStream_t */
 
 const char* pdae_last_error(void);
-int pdae_abi_version(void);
+int pdae_abi_version(void);   /* 3: + pdae_conv_stats_* / pdae_gn_coef_from_conv_stats (2: saturation counter, row-coefficient samplers, fused attention, RCCL) */
 
 /* ---- convolution (F.conv2d / conv1d k=1: module.py:242,265,276,412,420; unet.py:62,174; encoder/ffhq.py:12-30) */
 typedef struct pdae_conv_desc {
