@@ -208,6 +208,7 @@ extern "C" int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G
 
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
                                  int accumulate, int tile, const float* dy_amax, pdae_stream_t stream) {
+  conv3x3p_arm_stats(nullptr);            // output statistics belong to forward convolutions only (a stale request from a failed call ends here)
   if (int e = check_desc(d)) return e;
   const int Cin = d->C0 + d->C1;
   PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
@@ -630,6 +631,7 @@ extern "C" int pdae_run_ops(const pdae_op* ops, int n, pdae_stream_t stream) {
   for (int k = 0; k < n; ++k) {
     int e = run_one(ops[k], stream);
     if (e != PDAE_OK) {
+      conv3x3p_arm_stats(nullptr);          // a statistics request armed for the failed op must not reach a later launch
       char msg[400];
       snprintf(msg, sizeof(msg), "%s", g_err);
       pdae_set_error("op %d (kind %d): %s", k, ops[k].kind, msg);
