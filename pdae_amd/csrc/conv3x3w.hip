@@ -418,7 +418,7 @@ int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
                     int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax) {
   WgradParams P;
   P.dy_amax = dy_amax; P.sat = pdae_sat_counter();
-  static const int stagger = [] { const char* e = getenv("PDAE_W3_STAGGER"); return e ? atoi(e) : 64; }();
+  static const int stagger = [] { const char* e = getenv("PDAE_W3_STAGGER"); return e ? atoi(e) : 0; }();      // off by default: measured +-0 (the kernel is power-bound, not phase-bound)
   P.stagger = stagger;
   if (math == 4 && !dy_amax) math = 3;          // fp16 format needs the dY scale: without it the exact bf16 split runs
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.dy = dy; P.Cout = Cout; P.ws = ws;
