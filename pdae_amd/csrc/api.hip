@@ -106,19 +106,19 @@ extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flag
 
 extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
                                const float* res, int res_mode, float* y, int tile, pdae_stream_t stream) {
+  float* const stat = conv3x3p_take_stats();            // consumed here whatever happens below: a failed call never leaves the request armed
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd: res_mode 2 needs even output");
-  if (tile == 0 && res_mode == 0 && !conv3x3p_stats_armed() && convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
+  if (tile == 0 && res_mode == 0 && !stat && convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
     return convhead_fwd(x0, d->N, d->Hi, d->Wi, d->C0, w, d->Cout, bias, y, S(stream));
   const int kind = wp ? fast_kind(d, 0, false) : 0;
   PDAE_CHECK_ARG(!wp || (tile == 0 && kind != 0), "conv2d_fwd: wp given but the convolution is not eligible for a prepared-weight kernel");
   if (kind == 3)
     return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
-                           res_mode ? res : nullptr, res_mode, 0, S(stream));
-  if (conv3x3p_stats_armed()) {
-    conv3x3p_arm_stats(nullptr);
+                           res_mode ? res : nullptr, res_mode, 0, S(stream), nullptr, 0, nullptr, 0, nullptr, nullptr, stat);
+  if (stat) {
     pdae_set_error("conv2d_fwd: output statistics were requested (pdae_conv_stats_arm) but this convolution does not run on the 3x3 patch kernel");
     return PDAE_EINVAL;
   }
@@ -138,13 +138,14 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
 
 extern "C" int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp,
                                   const float* bias, const float* res, int res_mode, float* y, pdae_stream_t stream) {
+  float* const stat = conv3x3p_take_stats();
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && coef && wp && y && (d->C1 == 0 || x1), "conv2d_fwd_gn: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd_gn: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd_gn: res_mode 2 needs even output");
   PDAE_CHECK_ARG(gn_patch_ok(d, false), "conv2d_fwd_gn: convolution not eligible (pdae_conv_wprep_bytes(d, PDAE_WPREP_GN) == 0)");
   return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
-                         res_mode ? res : nullptr, res_mode, 0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act);
+                         res_mode ? res : nullptr, res_mode, 0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act, nullptr, nullptr, stat);
 }
 
 static bool skip_desc_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds) {
@@ -171,6 +172,7 @@ extern "C" int pdae_conv_skip_wprep(const pdae_conv_desc* d, const pdae_conv_des
 extern "C" int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp,
                                     const float* bias, const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps,
                                     const float* bias_s, float* y, pdae_stream_t stream) {
+  float* const stat = conv3x3p_take_stats();
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(ds && !check_desc(ds) && skip_desc_ok(d, ds), "conv2d_fwd_skip: the 1x1 descriptor must map the conv's output grid (same N, H, W, Cout, math)");
   PDAE_CHECK_ARG(x0 && wp && y && s0 && wps && (ds->C1 == 0 || s1), "conv2d_fwd_skip: null pointer");
@@ -179,7 +181,7 @@ extern "C" int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, co
   PDAE_CHECK_ARG(pdae_conv2d_fwd_skip_ok(d, ds), "conv2d_fwd_skip: shape not eligible (pdae_conv2d_fwd_skip_ok == 0)");
   PatchSkip sk{s0, ds->C1 ? s1 : nullptr, ds->C0, ds->C1, (const unsigned short*)wps, bias_s};
   return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias, nullptr, 0,
-                         0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act, &sk);
+                         0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act, &sk, nullptr, stat);
 }
 
 // ---- GroupNorm statistics of a convolution's output, produced by the convolution itself
@@ -208,7 +210,7 @@ extern "C" int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G
 
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
                                  int accumulate, int tile, const float* dy_amax, pdae_stream_t stream) {
-  conv3x3p_arm_stats(nullptr);            // output statistics belong to forward convolutions only (a stale request from a failed call ends here)
+  conv3x3p_take_stats();                  // output statistics belong to forward convolutions only
   if (int e = check_desc(d)) return e;
   const int Cin = d->C0 + d->C1;
   PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
@@ -631,7 +633,7 @@ extern "C" int pdae_run_ops(const pdae_op* ops, int n, pdae_stream_t stream) {
   for (int k = 0; k < n; ++k) {
     int e = run_one(ops[k], stream);
     if (e != PDAE_OK) {
-      conv3x3p_arm_stats(nullptr);          // a statistics request armed for the failed op must not reach a later launch
+      conv3x3p_take_stats();                // a statistics request armed for an op that failed before its entry point must not reach a later launch
       char msg[400];
       snprintf(msg, sizeof(msg), "%s", g_err);
       pdae_set_error("op %d (kind %d): %s", k, ops[k].kind, msg);

@@ -578,11 +578,13 @@ float conv3x3p_wscale(int C) { int k = 0; while ((1 << (2 * k)) < 9 * C) ++k; re
 // prepared weights + split-K slabs of the convolution (one buffer: [planes | slabs])
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { return prep_bytes(math, Nout, C) + slab_bytes(C, H, W, N, Nout); }
 
-// One-shot request: the next conv3x3p_launch on this host thread also writes the GroupNorm partial statistics of its output (forward launches
-// only; the caller sized `part` with conv3x3p_stats_bytes, which is 0 whenever the launch would split K).
+// One-shot request (pdae_conv_stats_arm): the next forward convolution entry point on this host thread TAKES it -- on entry, before any argument
+// check, so that no return path leaves it armed for a later launch on another tensor -- and hands it to conv3x3p_launch explicitly, which
+// then also writes the GroupNorm partial statistics of its output (the caller sized `part` with conv3x3p_stats_bytes, which is 0 whenever
+// the launch would split K).
 static thread_local float* g_stat_arm = nullptr;
 void conv3x3p_arm_stats(float* part) { g_stat_arm = part; }
-bool conv3x3p_stats_armed() { return g_stat_arm != nullptr; }
+float* conv3x3p_take_stats() { float* p = g_stat_arm; g_stat_arm = nullptr; return p; }
 size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi) {
   if (Nout & 3) return 0;
   PatchPlan q = patch_plan(C + 32 * fused_skip_chunks, H, W, N, Nout);
@@ -595,7 +597,7 @@ size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip
 
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1, int C0,
-                    const float* coef, int act, const PatchSkip* sk, const float* amax) {
+                    const float* coef, int act, const PatchSkip* sk, const float* amax, float* stat_part) {
   PatchParams P;
   P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
   P.woscale = 1.0f / conv3x3p_wscale(C); P.amax = amax; P.sat = pdae_sat_counter();
@@ -609,7 +611,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (coef && (q.w8 || (x1 && (C0 & 31)))) { pdae_set_error("conv3x3p: fused GroupNorm input needs W %% 16 == 0 and C0 %% 32 == 0"); return PDAE_EINVAL; }
   P.tiles_x = q.tiles_x; P.tiles_y = q.tiles_y; P.tiles_n = q.tiles_n; P.splits = q.splits; P.cps = q.cps;
   P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));
-  P.stat_part = g_stat_arm; g_stat_arm = nullptr; P.stat_tpi = q.tiles_x * q.tiles_y * (q.th / 8);
+  P.stat_part = stat_part; P.stat_tpi = q.tiles_x * q.tiles_y * (q.th / 8);
   if (P.stat_part && (q.splits != 1 || (Nout & 3))) { pdae_set_error("conv3x3p: output statistics requested for a split-K launch"); return PDAE_EINVAL; }
 #define PDAE_P3(NS_)                                                                                                    \
   (coef ? (q.th == 16 ? launch_ns<NS_, 16, false, true>(P, s) : launch_ns<NS_, 8, false, true>(P, s))                    \

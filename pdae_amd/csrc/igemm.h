@@ -56,9 +56,10 @@ size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N);
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s);
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1 = nullptr,
-                    int C0 = 0, const float* coef = nullptr, int act = 0, const PatchSkip* sk = nullptr, const float* amax = nullptr);
-void conv3x3p_arm_stats(float* part);          // one-shot: the next conv3x3p_launch of this thread writes GroupNorm partial statistics of its output
-bool conv3x3p_stats_armed();
+                    int C0 = 0, const float* coef = nullptr, int act = 0, const PatchSkip* sk = nullptr, const float* amax = nullptr,
+                    float* stat_part = nullptr);
+void conv3x3p_arm_stats(float* part);          // one-shot request of pdae_conv_stats_arm (thread-local)
+float* conv3x3p_take_stats();                  // ... taken AND cleared by the next forward entry point, first thing, on every return path
 size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi);
 size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs);
 int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s);

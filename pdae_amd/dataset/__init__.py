@@ -64,11 +64,40 @@ class ShardedImages:
             out[k] = img if img.ndim == 3 else img[..., None]
 
 
+class EpochOrder:
+    """Which images a rank visits, in which order, and which of them are mirrored: DistributedSampler semantics
+    (base_trainer.py:73-78: shuffle=True for training, a fresh permutation per epoch shared by all ranks, rank-strided shares padded to equal
+    length by wrapping around) plus the per-image coin of RandomHorizontalFlip (dataset/ffhq.py:22-23).  Pure numpy: the multi-rank behaviour is
+    tested on CPU (tests/test_host_cpu.py)."""
+
+    def __init__(self, length, rank=0, world_size=1, seed=0, shuffle=True, flip=True):
+        if not (0 <= rank < world_size):
+            raise ValueError(f"rank {rank} outside world of {world_size}")
+        self.length, self.rank, self.world, self.seed = int(length), int(rank), int(world_size), int(seed)
+        self.shuffle, self.flip = bool(shuffle), bool(flip)
+        self.per_rank = (self.length + self.world - 1) // self.world
+
+    def indices(self, epoch):
+        """This rank's image indices of `epoch` (every rank the same count; the union over ranks covers the dataset)."""
+        order = np.random.default_rng([self.seed, epoch]).permutation(self.length) if self.shuffle else np.arange(self.length)
+        pad = self.per_rank * self.world - self.length
+        if pad:
+            order = np.concatenate([order, order[:pad]])
+        return order[self.rank::self.world]
+
+    def flips(self, epoch, start, count):
+        """Mirror flags of the `count` images at position `start` of this rank's epoch share (independent streams per rank and epoch)."""
+        if not self.flip:
+            return np.zeros(count, dtype=np.uint8)
+        return (np.random.default_rng([self.seed, epoch, self.rank, start, 0x666c6970]).random(count) < 0.5).astype(np.uint8)
+
+
 class DeviceImagePipeline:
     """Double-buffered host -> device image batches with on-GPU crop / resize / flip / normalise (module docstring)."""
 
-    def __init__(self, config, device, rank=0, world_size=1, seed=0):
+    def __init__(self, config, device, rank=0, world_size=1, seed=0, shuffle=True, drop_last=True):
         self.device = torch.device(device)
+        self.drop_last = bool(drop_last)       # training loaders drop the ragged last batch of an epoch (base_trainer.py:86), the evaluator serves it
         if self.device.type != "cuda":
             raise H.PdaeError("the device image pipeline needs a ROCm device (pdae_image_prepare has no CPU fallback)")
         self.size = int(config["image_size"])
@@ -84,7 +113,10 @@ class DeviceImagePipeline:
         dev = self.device
         self._tabs = [torch.from_numpy(a).to(dev) for a in (kx, bx, ky, by)]
         self._ks = (kx.shape[1], ky.shape[1])
+        # shuffling is a property of the split (train: yes, eval / inference: no), the mirror flip of `augmentation` (dataset/ffhq.py:21-23)
+        self.order = EpochOrder(len(self.images), rank, world_size, seed, shuffle=bool(config.get("shuffle", shuffle)), flip=self.augmentation)
         self.rank, self.world, self.seed, self.epoch = rank, world_size, seed, 0
+        self._batch = None
         self._stream = torch.cuda.Stream(device=dev)
         self._slots = None
         self._q = None
@@ -92,12 +124,6 @@ class DeviceImagePipeline:
 
     def __len__(self):
         return len(self.images)
-
-    # ------------------------------------------------------------------ index order (DistributedSampler semantics: shuffled per epoch, rank-strided)
-    def _epoch_indices(self, epoch):
-        g = np.random.default_rng(self.seed + epoch)
-        order = g.permutation(len(self.images)) if self.augmentation else np.arange(len(self.images))
-        return order[self.rank::self.world]
 
     def _alloc(self, B):
         Hs, Ws, C = self.images.shape
@@ -116,20 +142,20 @@ class DeviceImagePipeline:
     def _producer(self, B):
         k, epoch = 0, self.epoch
         while True:
-            idx = self._epoch_indices(epoch)
-            for s in range(0, len(idx) - B + 1, B):              # drop_last like the reference's DataLoader (base_trainer.py:71-79)
+            idx = self.order.indices(epoch)
+            for s in range(0, len(idx), B):
+                ids = idx[s:s + B]
+                n = len(ids)
+                if n < B and self.drop_last:                       # the reference's training DataLoader drops it (base_trainer.py:86)
+                    break
                 slot = self._slots[k % 2]
                 slot["free"].wait()                                # the consumer has issued the kernel that reads this slot's device buffer
                 slot["free"].clear()
                 if slot["done"] is not None:
                     slot["ready"].synchronize()                    # the previous H2D out of this pinned buffer has finished
                     self._stream.wait_event(slot["done"])          # the next H2D into the device buffer queues behind that kernel (no host wait)
-                ids = idx[s:s + B]
-                self.images.gather(ids, slot["np"])
-                if self.augmentation:
-                    slot["flip_host"].copy_(torch.from_numpy((np.random.default_rng(self.seed * 7919 + epoch * 104729 + s).random(B) < 0.5).astype(np.uint8)))
-                else:
-                    slot["flip_host"].zero_()
+                self.images.gather(ids, slot["np"][:n])
+                slot["flip_host"][:n].copy_(torch.from_numpy(self.order.flips(epoch, s, n)))
                 with torch.cuda.stream(self._stream):
                     slot["dev"].copy_(slot["host"], non_blocking=True)
                     slot["flip"].copy_(slot["flip_host"], non_blocking=True)
@@ -139,17 +165,26 @@ class DeviceImagePipeline:
             epoch += 1
 
     def batch(self, batch_size, device=None, generator=None, out=None):
-        """Next batch.  `out`: optional float32 destination (any strides, e.g. the NHWC plan buffer viewed as (B,C,S,S))."""
+        """Next batch of this rank's epoch share: `batch_size` images, or the ragged remainder of the epoch when the pipeline was built with
+        drop_last=False (read the size off x_0).  `out`: optional float32 destination (any strides, e.g. the NHWC plan buffer viewed as (B,C,S,S))."""
         if self._thread is None:
+            if batch_size > len(self.order.indices(0)):
+                raise ValueError(f"batch of {batch_size} images but this rank's share of the dataset holds {len(self.order.indices(0))}")
+            self._batch = int(batch_size)
             self._slots = self._alloc(batch_size)
             self._q = queue.Queue(maxsize=2)
             self._thread = threading.Thread(target=self._producer, args=(batch_size,), daemon=True)
             self._thread.start()
+        if batch_size != self._batch:
+            # the producer thread, the pinned / device slots and the index bookkeeping are sized by the first request; a different size would
+            # hand back an `idx` that does not describe x_0.  Callers that need another size (an evaluation batch) build their own pipeline.
+            raise ValueError(f"this pipeline serves batches of {self._batch} images (got a request for {batch_size}): build a second pipeline")
         k, ids = self._q.get()
         slot = self._slots[k]
+        batch_size = int(ids.numel())
         Hs, Ws, C = self.images.shape
         S = self.size
-        x0 = torch.empty(batch_size, C, S, S, device=self.device) if out is None else out
+        x0 = torch.empty(batch_size, C, S, S, device=self.device) if out is None else out[:batch_size]
         gts = torch.empty(batch_size, S, S, C, dtype=torch.uint8, device=self.device)
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(slot["ready"])                              # the H2D copy of this slot ran on the side stream
@@ -168,12 +203,16 @@ class DeviceImagePipeline:
         return {"idx": ids, "x_0": x0, "gts": gts}
 
 
-def build(config, device=None, rank=0, world_size=1, seed=0):
-    """dataset_module.build(train_dataset_config): 'SYNTHETIC', or any other name with a `data_path` of .npy shards."""
+def build(config, device=None, rank=0, world_size=1, seed=0, shuffle=True, drop_last=True):
+    """dataset_module.build(train_dataset_config): 'SYNTHETIC', or any other name with a `data_path` of .npy shards.
+    rank / world_size / seed: this process's share of every epoch (the reference wraps its datasets in a DistributedSampler,
+    base_trainer.py:73-78); seed must be the same on all ranks.  shuffle / drop_last: True for training splits; the autoencoding evaluator reads its
+    dataset in order and to the last image (sampler/autoencoding_eval.py:26-43)."""
     name = config.get("name", config.get("dataset_name", "SYNTHETIC"))
     if name == "SYNTHETIC":
         return SYNTHETIC(config)
     if not config.get("data_path"):
         raise NotImplementedError(f"dataset {name!r}: give train_dataset_config.data_path = a directory of decoded uint8 .npy shards "
                                   "(the reference's LMDB / torchvision readers are not part of pdae_amd)")
-    return DeviceImagePipeline(config, device if device is not None else torch.device("cuda", torch.cuda.current_device()), rank, world_size, seed)
+    return DeviceImagePipeline(config, device if device is not None else torch.device("cuda", torch.cuda.current_device()), rank, world_size, seed, shuffle,
+                               drop_last)

@@ -105,14 +105,19 @@ class DDIM:
         return torch.full((n,), i, device=self.device, dtype=torch.long)
 
     def _guarded(self, net, body):
-        """Runs body() on a planned network; if the fp16-window guard fired meanwhile, switches the process to bf16x6 and runs it again."""
-        out = body()
+        """Runs body() on a planned network; if the fp16-window guard fired INSIDE it, switches the process to bf16x6 and runs it again.
+        The guard words are process-wide and sticky: word [0] may already be non-zero from a training step the trainer has not polled yet
+        (handle_saturation owns that state, and word [1], its discarded-step count), so only the events of this loop are looked at -- the
+        difference against a snapshot -- and only they are taken back."""
         g = H.SaturationGuard.get(net.device)
-        if g is not None and H.default_math() == "f16x3" and g.read()[0]:
+        watch = g is not None and H.default_math() == "f16x3"
+        before = g.read()[0] if watch else 0
+        out = body()
+        if watch and g.read()[0] != before:
             print("[pdae_amd] fp16 window exceeded during a DDIM loop: re-running it in bf16x6 arithmetic", file=sys.stderr, flush=True)
             H.set_default_math("bf16x6")
             net.invalidate_plans()
-            g.reset()
+            g.t[0:1].fill_(before)
             out = body()
         return out
 

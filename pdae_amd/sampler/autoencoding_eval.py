@@ -18,7 +18,10 @@ class Sampler:
         self.global_rank, self.global_world_size, self.local_rank = init_distributed_mode()
         self.device = torch.device("cuda", self.local_rank)
         torch.cuda.set_device(self.device)
-        self.dataset = dataset_module.build(config["dataset_config"])
+        # in order, to the last image, each rank its own stride of the dataset (sampler/autoencoding_eval.py:26-43: DistributedSampler
+        # shuffle=False, drop_last=False; DataLoader drop_last=False)
+        self.dataset = dataset_module.build(config["dataset_config"], device=self.device, rank=self.global_rank, world_size=self.global_world_size,
+                                            shuffle=False, drop_last=False)
         self.gaussian_diffusion = GaussianDiffusion(config["diffusion_config"], device=self.device)
         if encoder is None:
             mc = load_yaml(config["config_path"])
@@ -35,13 +38,18 @@ class Sampler:
 
     def start(self, num_images=None, encoder_style="ddim1000", decoder_style="ddim100"):
         total = len(self.dataset) if num_images is None else num_images
-        mine = dispatch_num_samples_for_process(total, self.global_world_size, self.global_rank)
+        order = getattr(self.dataset, "order", None)
+        if order is not None and num_images is None:
+            mine = order.per_rank                  # the sampler's padded share: every rank the same count, like the reference
+        else:
+            mine = dispatch_num_samples_for_process(total, self.global_world_size, self.global_rank)
         bs = self.config["batch_size"]
         with torch.inference_mode():
             done = 0
             while done < mine:
                 n = min(bs, mine - done)
-                x_0 = self.dataset.batch(n, self.device)["x_0"]
+                x_0 = self.dataset.batch(bs if order is not None else n, self.device)["x_0"]
+                n = x_0.shape[0]                   # a device pipeline serves its epoch share in batches of bs and a ragged last one
                 rec = self.gaussian_diffusion.representation_learning_autoencoding(encoder_style, decoder_style, self.encoder, self.decoder, x_0)
                 # one fused kernel: (x+1)/2 of both batches, SSIM and MSE per image (autoencoding_eval.py:83-88 + metric/utils.py:35-63)
                 s, m = ssim_mse(x_0, rec, denormalize=True)

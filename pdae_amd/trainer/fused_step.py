@@ -193,11 +193,14 @@ class _FusedStep:
 
     def handle_saturation(self, log=True):
         """Polls the guard; if it fired: rewinds the step counter by the discarded steps, switches the process default to "bf16x6",
-        rebuilds this plan and resets the counter.  Returns the number of discarded steps (0 = nothing happened)."""
+        rebuilds this plan and resets the counter.  Returns the number of optimizer steps that were discarded -- exactly the amount
+        `step_count` was rewound by, so a trainer that subtracts it from its own counter stays in lock-step with the optimizer (the guard
+        can fire inside a micro-batch whose optimizer step has not run yet: events > 0, nothing discarded).  `recoveries` counts the firings."""
         events, skipped = self.saturation()
         if events == 0:
             return 0
         self.step_count -= skipped
+        self.recoveries = getattr(self, "recoveries", 0) + 1
         if log:
             print(f"[pdae_amd] fp16 window exceeded in {events} convolution launch(es): {skipped} optimizer step(s) discarded, "
                   "continuing in bf16x6 arithmetic", file=sys.stderr, flush=True)
@@ -206,7 +209,7 @@ class _FusedStep:
             n.invalidate_plans()
         self.rebuild("bf16x6")
         self.guard.reset()
-        return max(skipped, 1)
+        return skipped
 
 
 class FusedRLStep(_FusedStep):

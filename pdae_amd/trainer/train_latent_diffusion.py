@@ -16,7 +16,7 @@ from ..model.representation_learning import encoder as encoder_module
 from ..model.representation_learning import latent_denoise_fn as latent_denoise_fn_module
 from ..utils import load_yaml, set_seed
 from .fused_step import FusedLatentStep, export_adam_state, load_adam_state
-from .train_regular_diffusion import _LoopMixin, _parser
+from .train_regular_diffusion import DATA_SEED, _LoopMixin, _parser
 
 
 class LatentDiffusionTrainer(_LoopMixin):
@@ -24,7 +24,8 @@ class LatentDiffusionTrainer(_LoopMixin):
         self._init_common(args)
         c = self.config
         rl = load_yaml(c["trained_representation_learning_config"])
-        self.dataset = dataset_module.build(c["train_dataset_config"])
+        self.dataset = dataset_module.build(c["train_dataset_config"], device=self.device, rank=self.global_rank, world_size=self.global_world_size,
+                                            seed=DATA_SEED)
         self.batch_size = c["dataloader_config"]["train"]["batch_size"]
         self.gaussian_diffusion = GaussianDiffusion(rl["diffusion_config"], device=self.device)
         self.latent_denoise_fn = getattr(latent_denoise_fn_module, c["latent_denoise_fn_config"]["model"])(device=self.device,

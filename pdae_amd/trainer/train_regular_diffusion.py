@@ -18,6 +18,9 @@ from ..utils import init_distributed_mode, load_yaml, save_yaml, set_seed
 from .fused_step import FusedRegularStep, export_adam_state, load_adam_state
 
 
+DATA_SEED = 666666666          # one permutation stream for all ranks (utils/utils.py:30 base seed)
+
+
 class _LoopMixin:
     """Logging / checkpoint cadence shared by the secondary trainers (base_trainer.py + train_*.py main loops)."""
 
@@ -49,10 +52,11 @@ class _LoopMixin:
             for _ in range(n_it):                        # micro-batches of one optimizer step (train_regular_diffusion.py:82-110)
                 acc += one_step()
             self.step += 1
+            saving = self.step % int(rc["save_latest_every_steps"]) == 0 or self.step % int(rc["save_checkpoint_every_steps"]) == 0
+            if self.step % display == 0 or saving:
+                # fp16-window guard: discarded steps are re-counted, plan -> bf16x6; polled in front of every checkpoint as well
+                self.step -= self.fused.handle_saturation()
             if self.step % display == 0:
-                lost = self.fused.handle_saturation()    # fp16-window guard: discarded steps are re-counted, plan -> bf16x6
-                if lost:
-                    self.step -= lost
                 loss = float(acc.item()) / display
                 if torch.distributed.is_initialized():
                     t = torch.tensor([loss], device=self.device)
@@ -77,7 +81,8 @@ class RegularDiffusionTrainer(_LoopMixin):
     def __init__(self, args):
         self._init_common(args)
         c = self.config
-        self.dataset = dataset_module.build(c["train_dataset_config"])
+        self.dataset = dataset_module.build(c["train_dataset_config"], device=self.device, rank=self.global_rank, world_size=self.global_world_size,
+                                            seed=DATA_SEED)          # shared seed, rank-strided shares (DistributedSampler, base_trainer.py:73-78)
         self.batch_size = c["dataloader_config"]["train"]["batch_size"]
         self.gaussian_diffusion = GaussianDiffusion(c["diffusion_config"], device=self.device)
         self.denoise_fn = getattr(denoise_fn_module, c["denoise_fn_config"]["model"])(device=self.device, **c["denoise_fn_config"])

@@ -20,6 +20,8 @@ from ..model.representation_learning import encoder as encoder_module
 from ..utils import init_distributed_mode, load_yaml, save_yaml, set_seed
 from .fused_step import FusedRLStep, export_adam_state, load_adam_state
 
+DATA_SEED = 666666666          # one permutation stream for all ranks (utils/utils.py:30 base seed)
+
 
 class RepresentationLearningTrainer:
     def __init__(self, args):
@@ -48,7 +50,13 @@ class RepresentationLearningTrainer:
 
     def _build_dataloader(self):
         cfg = self.config["train_dataset_config"]
-        self.dataset = dataset_module.build(cfg)
+        # every rank walks its own share of one common per-epoch permutation (DistributedSampler, base_trainer.py:73-78): the seed is shared,
+        # the rank selects the share.  Evaluation reads from its own loader (train config overridden by eval_dataset_config, :62-64).
+        share = dict(device=self.device, rank=self.global_rank, world_size=self.global_world_size, seed=DATA_SEED)
+        self.dataset = dataset_module.build(cfg, **share)
+        ecfg = copy.deepcopy(cfg)
+        ecfg.update(self.config.get("eval_dataset_config") or {})
+        self.eval_dataset = dataset_module.build(ecfg, **share)
         self.batch_size = self.config["dataloader_config"]["train"]["batch_size"]     # per process (base_trainer.py:71)
 
     def _build_model(self):
@@ -105,10 +113,13 @@ class RepresentationLearningTrainer:
                 batch = self.dataset.batch(self.batch_size, self.device, gen)
                 acc += self.fused.step(batch["x_0"])                    # device-side accumulation: no per-step host sync
             self.step += 1
+            rc_save = (self.step % int(rc["save_latest_every_steps"]) == 0 or self.step % int(rc["save_checkpoint_every_steps"]) == 0
+                       or self.step % int(rc["evaluate_every_steps"]) == 0)
+            if self.step % display == 0 or rc_save:
+                # fp16-window guard: discarded steps are re-counted, plan -> bf16x6.  Polled at the logging cadence AND in front of every
+                # checkpoint / evaluation, so that no file records a step count or optimizer state that includes a discarded update
+                self.step -= self.fused.handle_saturation()
             if self.step % display == 0:
-                lost = self.fused.handle_saturation()                  # fp16-window guard: discarded steps are re-counted, plan -> bf16x6
-                if lost:
-                    self.step -= lost
                 loss = float(acc.item()) / display
                 if torch.distributed.is_initialized():
                     t = torch.tensor([loss], device=self.device)
@@ -134,7 +145,7 @@ class RepresentationLearningTrainer:
         """DDIM-100 samples from the EMA networks (train_representation_learning.py:158-190), saved as a tensor file."""
         n = min(int(self.config["dataloader_config"]["eval"]["num_generations"]), self.batch_size)
         with torch.no_grad():
-            batch = self.dataset.batch(n, self.device)
+            batch = self.eval_dataset.batch(n, self.device)
             images = self.gaussian_diffusion.representation_learning_ddim_sample("ddim100", self.ema_encoder, self.ema_decoder, batch["x_0"],
                                                                                  torch.randn_like(batch["x_0"]))
             images = images.mul(0.5).add(0.5).mul(255).add(0.5).clamp(0, 255).permute(0, 2, 3, 1).to("cpu", torch.uint8)

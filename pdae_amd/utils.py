@@ -18,16 +18,12 @@ def set_seed(inc, base_seed=666666666):
 
 
 def dispatch_num_samples_for_process(num_samples, num_process, rank):
-    """trainer/base_trainer.py:143-153: equal shares, the remainder goes to the last rank."""
-    assert 1 <= num_process <= num_samples
-    assert 0 <= rank <= num_process - 1
-    average = num_samples // num_process
-    remainder = num_samples % num_process
-    dispatch = [average] * num_process
-    if remainder > 0:
-        dispatch[-1] += remainder
-    assert sum(dispatch) == num_samples
-    return dispatch[rank]
+    """Share of `num_samples` that process `rank` of `num_process` generates: floor(n / w) each, the last rank also takes the n mod w left
+    over (the contract of trainer/base_trainer.py:143-153; table-tested in tests/test_ddp_cpu.py)."""
+    if not (1 <= num_process <= num_samples and 0 <= rank < num_process):
+        raise AssertionError(f"cannot split {num_samples} samples over {num_process} processes for rank {rank}")
+    share, left = divmod(num_samples, num_process)
+    return share + (left if rank == num_process - 1 else 0)
 
 
 def load_yaml(filename):

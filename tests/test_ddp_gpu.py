@@ -136,3 +136,60 @@ def test_native_rccl_communicator_single_rank():
     floats = [c for c in set_calls if c[2] == "sum"]
     assert len(floats) == 2 * len(st_b.buckets) and sum(n for _, n, _ in floats) == 2 * (dec_b.flat_grad.numel() + enc_b.flat_grad.numel())
     st_b.ncomm.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# REAL multi-process runs: HIP kernels and a real collective together (tests/ddp_worker.py under torch.distributed.run)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _launch_ranks(tmp_path, backend, native, steps=3, per_rank=2, world=2):
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / f"{backend}_{native}"
+    out.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("PDAE_NATIVE_RCCL", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "ddp_worker.py"), "--backend", backend, "--native", str(int(native)), "--steps", str(steps),
+           "--per_rank", str(per_rank), "--out", str(out)]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return torch.load(out / "result.pt", map_location="cpu")
+
+
+def _single_process_reference(steps, n):
+    x0, t, noise = _data(n)
+    enc, dec, st = _build(n)
+    losses = [float(st.step(x0, t=t, noise=noise).item()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    return losses, {"dec": dec.flat_train.cpu(), "enc": enc.flat_train.cpu(), "ema_dec": st.ema_dec.flat_train.cpu()}
+
+
+def _check_against_single_process(res, steps=3, n=4):
+    assert res["identical"], "parameters / EMA / Adam moments differ between ranks after the all-reduced steps"
+    assert res["guard"][0] == 0
+    ref_losses, ref = _single_process_reference(steps, n)
+    for a, b in zip(res["losses"], ref_losses):
+        assert abs(a - b) < 2e-4 * abs(b), (res["losses"], ref_losses)
+    for k, v in ref.items():                         # see the bounds of the emulated test above: Adam amplifies rounding noise on |g| ~ eps
+        diff = (res["state"][k] - v).abs()
+        assert float(diff.max()) < 3e-4 and float((diff > 2e-6).float().mean()) < 5e-3 and float(diff.mean()) < 2e-7, (k, float(diff.max()), float(diff.mean()))
+
+
+def test_two_processes_one_gpu_real_collective_bucketed_step(tmp_path):
+    """Two OS processes share GPU 0; the gradient buckets go through torch.distributed's gloo all-reduce (async, one per bucket, issued
+    between the backward segments) -- the production code path of FusedRLStep.backward_with_allreduce with a real collective, on a 1-GPU
+    box.  Ranks must end bit-identical and equal to one process on the concatenated batch."""
+    _check_against_single_process(_launch_ranks(tmp_path, "gloo", native=False))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL places one rank per device)")
+@pytest.mark.parametrize("native", [False, True], ids=["torch_nccl", "native_rccl"])
+def test_two_gpus_rccl_both_exchange_backends(tmp_path, native):
+    """Two ranks on two GPUs over RCCL: ProcessGroupNCCL (default) and the library's own communicator (pdae_allreduce_bucket)."""
+    _check_against_single_process(_launch_ranks(tmp_path, "nccl", native=native))

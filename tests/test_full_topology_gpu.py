@@ -204,3 +204,80 @@ def test_m32_regular_step_full_topology_vs_oracle(gd):
     assert abs(float(st.loss.item()) - float(loss)) < 1e-4 * abs(float(loss))
     _check_grads(net.grads(), {k: v.grad for k, v in sd.items()}, 1e-3)
     assert abs(sum(p.numel() for p in net.P.values()) - 19.4e6) < 0.1e6                                         # 19.4 M
+
+
+def test_f128_ddim100_decode_vs_oracle_psnr_and_ssim_three_decimals(gd):
+    """The evaluator's decoding protocol at the benchmarked network: 100 DDIM steps of the FFHQ-128 decoder (sampler/autoencoding_eval.py:78,
+    diffusion/ddim.py:110-120), B=1, against the oracle walking the same trajectory on the host cores.  This is the oracle check of the
+    SAMPLING-ONLY kernel paths at real size -- GroupNorm applied inside the conv staging, skip conv inside the K loop, statistics from the
+    producing conv's epilogue (engine.py gn_conv / conv_skip / _stats_buf) -- which no training-step test touches.
+    Stated bounds: PSNR of the decoded image vs the oracle's > 55 dB on [-1,1] images after 100 steps (toy nets: > 80 dB, ddim5+ddim5: > 60 dB);
+    SSIM and MSE of (x_0, reconstruction) through pdae_ssim_mse equal to 3 decimals for the two reconstructions."""
+    from pdae_amd.metric import ssim_mse
+    c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml", seed_enc=4, seed_dec=6)
+    dec.set_eval_mode()
+    x0 = _batch(1, 3, 128, seed=8)[0]
+    xT = torch.randn(1, 3, 128, 128, generator=torch.Generator().manual_seed(21))
+    s = O.Schedules()
+    with torch.no_grad():
+        z = O.encoder_forward(enc_sd, ename, x0)
+        rec_ref = O.shift_ddim_sample_loop(s, "ddim100", dec_sd, dcfg, z, xT)
+        _guard().reset()
+        rec = gd.representation_learning_ddim_sample("ddim100", enc, dec, x0.to(DEV), xT.to(DEV))
+    assert _guard().read()[0] == 0
+    psnr = 10 * math.log10(4.0 / float(((rec.double().cpu() - rec_ref.double()) ** 2).mean()))
+    sg, mg = ssim_mse(x0.to(DEV), rec, denormalize=True)
+    sr, mr = ssim_mse(x0.to(DEV), rec_ref.to(DEV), denormalize=True)
+    print(f"[F128 ddim100 decode, B=1] PSNR vs oracle {psnr:.1f} dB; ssim {float(sg):.5f} / {float(sr):.5f}; mse {float(mg):.6f} / {float(mr):.6f}")
+    assert psnr > 55, psnr
+    assert abs(float(sg) - float(sr)) < 5e-4 and abs(float(mg) - float(mr)) < 5e-4, (float(sg), float(sr), float(mg), float(mr))
+    assert rel_err(ssim_mse(x0.to(DEV), rec_ref.to(DEV), denormalize=True)[0], O.ssim((x0 + 1) / 2, (rec_ref + 1) / 2)) < 1e-4     # the metric kernel itself, at 128^2
+
+
+def test_latent_ffhq_yaml_full_topology_step_vs_oracle(gd):
+    """BASELINE config #5 exactly as shipped: config/ffhq_latent.yml -> MLPSkipNet 10 x 2048 with skip-concats, per-GPU batch 128, L1 loss,
+    AdamW(1e-3, wd 0.01) + EMA -- through FusedLatentStep (model/mlp_skip_net.py:55-141, gaussian_diffusion.py:373-398,
+    train_latent_diffusion.py:95-178).  Output, loss 1e-4; every gradient 1e-3 in norm; parameters after the optimizer step vs the oracle's
+    AdamW on the oracle's gradients."""
+    from pdae_amd.model.representation_learning import latent_denoise_fn as latent_module
+    from pdae_amd.trainer.fused_step import FusedLatentStep
+    c = _yaml("config/ffhq_latent.yml")
+    mc = c["latent_denoise_fn_config"]
+    cfg = {k: v for k, v in mc.items() if k != "model"}
+    B = c["dataloader_config"]["train"]["batch_size"]
+    assert (cfg["model_channel"], cfg["num_layers"], B, c["optimizer_config"]["name"]) == (2048, 10, 128, "AdamW")
+    sd = O.synth_state_dict(O.mlp_skip_net_param_shapes(cfg), 13)
+    net = getattr(latent_module, mc["model"])(device=DEV, **cfg)
+    net.load_state_dict(sd, strict=False)                  # the duplicate cond_layers.1.* keys alias linear_emb.*
+    net.train()
+    import copy
+    ema = copy.deepcopy(net)
+    oc = c["optimizer_config"]
+    opt = dict(lr=float(oc["lr"]), betas=eval(oc["adam_betas"]), eps=float(oc["adam_eps"]), weight_decay=float(oc["weight_decay"]))
+    st = FusedLatentStep(gd, net, ema, B, decoupled=True, ema_decay=float(c["runner_config"]["ema_decay"]), **opt)
+    g = torch.Generator().manual_seed(17)
+    ic = cfg["input_channel"]
+    z0, noise, t = torch.randn(B, ic, generator=g), torch.randn(B, ic, generator=g), torch.randint(0, 1000, (B,), generator=g)
+    # oracle: q_sample on the latent schedule (constant beta 0.008), L1 loss, autograd, AdamW
+    ac = np.cumprod(1.0 - np.full(1000, 0.008))
+    z_t = torch.tensor(np.sqrt(ac), dtype=torch.float32)[t].view(-1, 1) * z0 + torch.tensor(np.sqrt(1 - ac), dtype=torch.float32)[t].view(-1, 1) * noise
+    ref_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref_out = O.mlp_skip_net_forward(ref_sd, cfg, z_t, t)
+    ref_loss = (noise - ref_out).abs().mean()
+    ref_loss.backward()
+    p_before = {k: net.P[k].detach().clone() for k in sd if k in net.P}
+    loss = st.step(z0.to(DEV), t=t.to(DEV), noise=noise.to(DEV))
+    torch.cuda.synchronize()
+    assert abs(float(loss.item()) - float(ref_loss)) < 1e-4 * abs(float(ref_loss)), (float(loss.item()), float(ref_loss))
+    G = net.grads()
+    ref_g = {k: v.grad for k, v in ref_sd.items() if k in G}
+    assert len(ref_g) >= 4 * cfg["num_layers"]
+    _check_grads(G, ref_g, 1e-3)
+    # optimizer: AdamW step 1 on the oracle's gradients from the same parameters.  At step 1 the update is lr * sign-like(g): compare where the
+    # gradient is well above rounding noise, and bound the rest by one step size
+    for k, gr in ref_g.items():
+        want, _, _ = O.adam_step(p_before[k].cpu(), gr, torch.zeros_like(gr), torch.zeros_like(gr), 1, opt["lr"], *opt["betas"], opt["eps"], opt["weight_decay"], True)
+        diff = (net.P[k].detach().cpu() - want).abs()
+        solid = gr.abs() > 1e-3 * gr.abs().max()
+        assert float(diff[solid].max() if solid.any() else 0.0) < 2e-5 and float(diff.max()) < 2.1 * opt["lr"], (k, float(diff.max()))
+    assert not torch.equal(ema.flat_train, net.flat_train)

@@ -69,3 +69,46 @@ def test_plans_take_groupnorm_statistics_from_the_producing_convolution(monkeypa
     assert armed_on > 0 and on[H.OP_GN_COEF_FROM_CONV_STATS] > 0
     assert on[H.OP_GN_STATS_COEF] + on[H.OP_GN_COEF_FROM_CONV_STATS] == off[H.OP_GN_STATS_COEF]       # every GroupNorm is still there
     assert on[H.OP_GN_STATS_COEF] >= 1                                                               # e.g. the tensor behind the stem convolution
+
+
+def test_epoch_order_partitions_every_epoch_across_ranks():
+    """every data-parallel rank must walk its OWN share of one common per-epoch permutation (DistributedSampler,
+    base_trainer.py:73-78) -- not the same images on every rank.  Shares are disjoint, equally long, cover the dataset, change per epoch,
+    do not depend on `augmentation`; mirror coins differ between ranks; an evaluation order is the identity."""
+    from pdae_amd.dataset import EpochOrder
+    L, W = 1003, 4
+    for epoch in (0, 1, 7):
+        shares = [EpochOrder(L, r, W, seed=5).indices(epoch) for r in range(W)]
+        assert len({len(s) for s in shares}) == 1 and len(shares[0]) == (L + W - 1) // W
+        allidx = np.concatenate(shares)
+        assert set(allidx.tolist()) == set(range(L))                              # covers the dataset ...
+        assert len(allidx) - len(set(allidx.tolist())) == W * len(shares[0]) - L   # ... with only the wrap-around padding duplicated
+        for a in range(W):
+            for b in range(a + 1, W):
+                assert len(set(shares[a].tolist()) & set(shares[b].tolist())) <= W * len(shares[0]) - L
+    e0, e1 = EpochOrder(L, 1, W, seed=5).indices(0), EpochOrder(L, 1, W, seed=5).indices(1)
+    assert not np.array_equal(e0, e1) and not np.array_equal(e0, np.sort(e0))     # shuffled, and reshuffled per epoch
+    assert np.array_equal(EpochOrder(L, 1, W, seed=5, flip=False).indices(0), e0)  # the order does not depend on the augmentation flag
+    assert np.array_equal(EpochOrder(L, 0, 1, shuffle=False).indices(3), np.arange(L))
+    f0, f1 = EpochOrder(L, 0, W, seed=5).flips(0, 0, 256), EpochOrder(L, 1, W, seed=5).flips(0, 0, 256)
+    assert not np.array_equal(f0, f1) and 64 < int(f0.sum()) < 192
+    assert int(EpochOrder(L, 0, W, seed=5, flip=False).flips(0, 0, 64).sum()) == 0
+
+
+def test_trainers_and_sampler_hand_their_rank_to_the_dataset(monkeypatch):
+    """The four entry points that build a dataset pass device / rank / world_size (and a seed shared by all ranks)."""
+    import ast
+    import inspect
+    import pdae_amd.sampler.autoencoding_eval as S
+    import pdae_amd.trainer.train_latent_diffusion as TL
+    import pdae_amd.trainer.train_regular_diffusion as TG
+    import pdae_amd.trainer.train_representation_learning as TR
+    n = 0
+    for mod in (S, TL, TG, TR):
+        for node in ast.walk(ast.parse(inspect.getsource(mod))):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "build" and getattr(node.func.value, "id", "") == "dataset_module":
+                kws = {k.arg for k in node.keywords} | ({"**"} if any(k.arg is None for k in node.keywords) else set())
+                assert {"rank", "world_size", "device"} <= kws or "**" in kws, (mod.__name__, kws)
+                n += 1
+    assert n >= 5
+    assert TR.DATA_SEED == TG.DATA_SEED == TL.DATA_SEED
