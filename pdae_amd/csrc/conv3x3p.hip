@@ -15,89 +15,7 @@
 #include "common.h"
 #include "igemm.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// NS encodes the operand format: 1..3 = that many bf16 planes; 4 = TWO fp16 planes (11 + 11 mantissa bits, 3 products ~2^-21:
-// fp32-grade at half the MFMAs of bf16x6, for operands inside the fp16 range -- forward activations / weights)
-#define NPL(NS_) ((NS_) == 4 ? 2 : (NS_))
-#define PASCALE 16.0f            // fp16 format: activations are multiplied by 2^4 before the split (undone exactly in the epilogue)
-
-// Geometries (template PTH, W8):
-//   PTH = 16      : 16x16-pixel tile, 512 threads (4x2 waves), 86 KB LDS at NS=3 (one block per CU)
-//   PTH =  8      :  8x16-pixel tile, 256 threads (2x2 waves), 48 KB LDS (several independent blocks per CU)
-//   PTH =  8, W8  :  8-pixel-wide images: the tile is 8 rows of TWO images side by side (their 10-pixel halo rows fill the
-//                    20-pixel patch pitch exactly), so the 8x8 bottleneck layers run on the same kernel
-// Small layers (few tiles) are additionally split over ranges of input-channel chunks (split-K): every split writes its
-// partial tile to a slab behind the prepared weights and conv3x3p_reduce adds the slabs, bias and residual in fixed order.
-#define PLDH 40                 // bf16 per LDS row (32 + 8 pad): 80-byte rows
-#define PTW 16
-#define PPW 20                  // patch pitch in pixels (18 used): with the 4x8 fragment blocks below every ds_read_b128 is conflict-free
-#define PBN 128
-#define PSLOT(row, slot) ((row) * PLDH + ((slot) << 3))       // bf16 offset of 16-byte k-slot `slot` of `row`
-#define PPLANE(rows) ((rows) * PLDH)
-#define EPW 36                  // floats per row of the epilogue transpose tile (32 + 4 pad)
-
-__device__ __forceinline__ float p_trunc(float a) { return __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
-__device__ __forceinline__ unsigned p_hi16(float a, float b) { return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u); }
-__device__ __forceinline__ unsigned p_rn(float a, float b) {
-  unsigned short x = __builtin_bit_cast(unsigned short, (__bf16)a), y = __builtin_bit_cast(unsigned short, (__bf16)b);
-  return (unsigned)x | ((unsigned)y << 16);
-}
-template <int NS> __device__ __forceinline__ void p_split2(float e0, float e1, unsigned (&w)[NPL(NS)], float sc = 1.0f) {
-  if constexpr (NS == 4) {          // fp16 planes of e * sc (the other formats take no scale)
-    pdae_f16_split2s(e0, e1, sc, w[0], w[1]);
-  } else if constexpr (NS == 1) { w[0] = p_rn(e0, e1); }
-  else {
-    float h0 = p_trunc(e0), h1 = p_trunc(e1);
-    float r0 = e0 - h0, r1 = e1 - h1;
-    w[0] = p_hi16(h0, h1);
-    if constexpr (NS == 2) { w[1] = p_rn(r0, r1); }
-    else {
-      float m0 = p_trunc(r0), m1 = p_trunc(r1);
-      w[1] = p_hi16(m0, m1);
-      w[2] = p_hi16(r0 - m0, r1 - m1);
-    }
-  }
-}
-
-struct PatchParams {
-  const float* x; int N, Hs, Ws, C;     // stored input [N,Hs,Ws,C]
-  int H, W, up;                         // output (= logical input) size; up: stored = logical >> 1
-  const unsigned short* wp;             // pre-split weights [NS][C/32][9][2][NT][64][8] bf16 (conv3x3p_wprep)
-  int NT;                               // 32-channel output tiles in wp (= ceil(Nout/32))
-  int Nout;                             // GEMM N
-  float* y; const float* bias; const float* res; int res_mode; int accumulate;
-  int tiles_x, tiles_y, tiles_n;
-  int splits, cps;                      // split-K: `splits` ranges of `cps` chunks; splits > 1 => raw partials to slab[split][M][Nout]
-  float* slab;
-  // fused GroupNorm / AdaGN + SiLU on the input (GN instantiation): the conv reads act(a[n,c] * (x - mu[n,c]) + b[n,c]) of the virtual
-  // concat [x | x1] (C0 channels in x), coefficients coef = [mu | a | b] each [N][C] from pdae_gn_coef; zero padding applies AFTER the map
-  const float* x1; int C0; const float* coef; int act;
-  // fused 1x1 skip convolution (ResBlock skip_connection, module.py:276,297): nx extra 32-channel chunks of the raw two-source tensor
-  // [s0 | s1] enter the K loop with the centre tap only, weights wps = conv1x1_wprep layout, bias_x added in the epilogue
-  int nx; const float* s0; const float* s1; int Cs0, Cs1; const unsigned short* wps; const float* bias_x;
-  float woscale;                        // fp16 format: 1 / (power-of-two scale of the prepared weights, conv3x3p_wscale)
-  const float* amax;                    // fp16 format: NULL = activations (static 2^4 pre-scale); else device scalar max|input| (pdae_amax)
-                                        // -> power-of-two scale putting the input's abs-max into [1024, 2048): gradients (dY) as input
-  unsigned int* sat;                    // fp16 format: saturation counter (common.h) or NULL
-  // GroupNorm statistics of the OUTPUT, fused into the epilogue (splits == 1 only): every wave writes (sum, sum of squares) of its 128 pixels
-  // for each of its eight channel quads to stat_part[image][stat_tpi wave-tiles][Nout / 4] as float2; pdae_gn_coef_from_conv_stats sums the
-  // wave-tiles in fp64.  The next GroupNorm then needs no pass over this tensor (it was 9 % of a sampling step).
-  float* stat_part; int stat_tpi;
-};
-
-// 2^(10 - floor(log2(amax))): amax * scale in [1024, 2048)  (amax == 0 or non-finite: 1)
-__device__ __forceinline__ float p_pow2_scale(float amax) {
-  const int ex = (__float_as_int(amax) >> 23) & 0xff;
-  if (ex == 0 || ex == 255) return 1.0f;
-  int sb = 127 + 10 - (ex - 127);
-  sb = sb < 1 ? 1 : (sb > 254 ? 254 : sb);
-  return __int_as_float(sb << 23);
-}
-// SiLU in 5 VALU instructions (v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul; ~2 ulp) instead of ~17 for expf + IEEE division: the fused-GroupNorm
-// variant evaluates it once per staged element per block, and under the power cap every VALU instruction is paid for in matrix throughput
-__device__ __forceinline__ float p_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+#include "conv3x3p.h"
 
 // issue pattern of one k-step: one LDS / vector-memory load of the NEXT step behind each MFMA of this one (measured +2..4 % over "all loads,
 // then the 12 MFMAs"; -DPDAE_P3_CLUSTERED restores that form for tools/probe_build.py)
@@ -613,6 +531,8 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));
   P.stat_part = stat_part; P.stat_tpi = q.tiles_x * q.tiles_y * (q.th / 8);
   if (P.stat_part && (q.splits != 1 || (Nout & 3))) { pdae_set_error("conv3x3p: output statistics requested for a split-K launch"); return PDAE_EINVAL; }
+  // large layers: 256-pixel x 64-channel wave tiles at one wave per SIMD (conv3x3q.hip); same parameters, same results
+  if (q.splits == 1 && !q.w8 && (!coef || act) && conv3x3q_ok(math, C, H, W, N, Nout, Hs, Ws, P.C0, P.Cs0, P.Cs1)) return conv3x3q_launch(math, P, s);
 #define PDAE_P3(NS_)                                                                                                    \
   (coef ? (q.th == 16 ? launch_ns<NS_, 16, false, true>(P, s) : launch_ns<NS_, 8, false, true>(P, s))                    \
         : (q.w8 ? launch_ns<NS_, 8, true>(P, s) : q.th == 16 ? launch_ns<NS_, 16, false>(P, s) : launch_ns<NS_, 8, false>(P, s)))
