@@ -91,3 +91,7 @@ __device__ __forceinline__ float p_silu(float v) { return v * __builtin_amdgcn_r
 // conv3x3q.hip: the one-wave-per-SIMD form for large layers.  conv3x3p_launch fills PatchParams and hands launches that need no split-K over
 bool conv3x3q_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws, int C0, int Cs0, int Cs1);
 int conv3x3q_launch(int math, const PatchParams& P, hipStream_t s);
+
+// conv3x3r.hip: persistent workgroups with a deferred epilogue for layers with at least two 16 x 16 x 128-channel tiles per CU
+bool conv3x3r_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws, int C0, int Cs0, int Cs1);
+int conv3x3r_launch(int math, const PatchParams& P, hipStream_t s);

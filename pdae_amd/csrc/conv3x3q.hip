@@ -239,19 +239,50 @@ __global__ void __launch_bounds__(QTHREADS, 1) conv3x3q_kernel(const PatchParams
   lstore_all();
   __syncthreads();
 
-  // one unit = the 12 MFMAs of 2 pixel groups x 2 channel tiles x 3 products; TAP / I (k-half * 4 + unit) / U (unit of the chunk) are constants
-#define PDAE_Q_UNIT(TAP, I, U, LAST_TAP, NG)                                                                 \
-    {                                                                                                       \
-      const int kc_ = (I) >> 2, u_ = (I) & 3;                                                               \
+  // timing probes (tools/probe_build.py, WRONG RESULTS by design): pieces of the unit compiled out to see what the single wave waits for
+#ifdef PDAE_Q_PROBE_NOGLOAD
+#define PDAE_Q_GLOADS(U, NG)
+#else
+#ifdef PDAE_Q_BURST
+// the vector-memory path returns data in order: a weight-fragment load (L2 hit) queued behind a patch prefetch (HBM) inherits its latency.  Bursts
+// right behind the weight loads of every 4th k-step leave each weight batch at least two k-steps between the youngest older prefetch and its use
+#define PDAE_Q_GLOADS(U, NG)                                                                                 \
+      if ((NG) == 1) { if ((U) % 16 == 0) { _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) if (((U) / 16) * 6 + g_ < QLD) gload_one(((U) / 16) * 6 + g_); } } \
+      else { _Pragma("unroll") for (int g_ = 0; g_ < (NG); ++g_) if ((U) * (NG) + g_ < QLD) gload_one((U) * (NG) + g_); }
+#else
+#define PDAE_Q_GLOADS(U, NG) _Pragma("unroll") for (int g_ = 0; g_ < (NG); ++g_) if ((U) * (NG) + g_ < QLD) gload_one((U) * (NG) + g_);
+#endif
+#endif
+#ifdef PDAE_Q_PROBE_NOCONV
+#define PDAE_Q_CONVERT(U, NG)
+#else
+#define PDAE_Q_CONVERT(U, NG) if ((NG) == 1 && (U) >= QCV0 && (U) < QCV0 + QLD) convert_one((U) - QCV0);
+#endif
+#ifdef PDAE_Q_PROBE_NOA
+#define PDAE_Q_LDA(TAP, I, LAST_TAP)
+#else
+#define PDAE_Q_LDA(TAP, I, LAST_TAP)                                                                         \
       if ((I) < 7) lda(fa[((I) + 1) & 1], TAP, ((I) + 1) >> 2, ((I) + 1) & 3);                              \
-      else lda(fa[0], (LAST_TAP) ? (TAP) : (TAP) + 1, 0, 0);                                                \
+      else lda(fa[0], (LAST_TAP) ? (TAP) : (TAP) + 1, 0, 0);
+#endif
+#ifdef PDAE_Q_PROBE_NOB
+#define PDAE_Q_LDB(TAP, LAST_TAP)
+#else
+#define PDAE_Q_LDB(TAP, LAST_TAP)                                                                            \
       if (u_ == 0) {                                                                                        \
         if (kc_ == 0) ldb(qb[1], chunk, TAP, 1);                                                            \
         else if (!(LAST_TAP)) ldb(qb[0], chunk, (TAP) + 1, 0);                                              \
         else ldb(qb[0], nxt, nxt_tap0, 0);                                                                  \
-      }                                                                                                     \
-      _Pragma("unroll") for (int g_ = 0; g_ < (NG); ++g_) if ((U) * (NG) + g_ < QLD) gload_one((U) * (NG) + g_); \
-      if ((NG) == 1 && (U) >= QCV0 && (U) < QCV0 + QLD) convert_one((U) - QCV0);                            \
+      }
+#endif
+  // one unit = the 12 MFMAs of 2 pixel groups x 2 channel tiles x 3 products; TAP / I (k-half * 4 + unit) / U (unit of the chunk) are constants
+#define PDAE_Q_UNIT(TAP, I, U, LAST_TAP, NG)                                                                 \
+    {                                                                                                       \
+      const int kc_ = (I) >> 2, u_ = (I) & 3;                                                               \
+      PDAE_Q_LDA(TAP, I, LAST_TAP)                                                                          \
+      PDAE_Q_LDB(TAP, LAST_TAP)                                                                             \
+      PDAE_Q_GLOADS(U, NG)                                                                                  \
+      PDAE_Q_CONVERT(U, NG)                                                                                 \
       mma(fa[(I) & 1], qb[kc_], u_);                                                                        \
       PDAE_Q_PATTERN(4)                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -291,6 +322,9 @@ __global__ void __launch_bounds__(QTHREADS, 1) conv3x3q_kernel(const PatchParams
     }
   }
 #undef PDAE_Q_UNIT
+#if defined(PDAE_Q_PROBE_NOA) || defined(PDAE_Q_PROBE_NOB)
+  lda(fa[1], 0, 0, 0); ldb(qb[1], 0, 0, 0);              // probes: keep every buffer defined
+#endif
 
   // ---- epilogue: every wave transposes its sixteen 32-pixel x 32-channel accumulator tiles through a private LDS region (the patch is dead)
   // so that global traffic is float4 per lane in 128-byte runs; bias / residual / accumulate / output statistics as in conv3x3p

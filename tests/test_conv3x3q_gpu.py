@@ -1,7 +1,8 @@
-"""GPU: the one-wave-per-SIMD 3x3 patch kernel (csrc/conv3x3q.hip: 256-pixel x 64-channel wave tiles, 256 accumulator registers) against
-fp64 references AND against the two-waves-per-SIMD kernel it replaces on large layers (csrc/conv3x3p.hip).  Both kernels accumulate every
+"""GPU: the one-wave-per-SIMD 3x3 patch kernels -- csrc/conv3x3r.hip (persistent workgroups, 128-pixel x 64-channel wave tiles, epilogue of
+tile i deferred into the main loop of tile i+1) and csrc/conv3x3q.hip (256-pixel x 64-channel wave tiles, one tile per workgroup) -- against
+fp64 references AND against the two-waves-per-SIMD kernel they replace on large layers (csrc/conv3x3p.hip).  All three accumulate every
 output element in the same order (chunks, taps, k-halves, products; same epilogue expression), so their results must be BIT-IDENTICAL:
-PDAE_P3Q=0 routes a launch to conv3x3p, PDAE_P3Q=2 to conv3x3q regardless of the fill heuristic (read per launch).
+PDAE_P3R / PDAE_P3Q = 0 keeps a launch away from that kernel, = 2 routes it there regardless of the fill heuristic (read per launch).
 Covers: plain forward with bias / residual (same- and half-resolution) / nearest-upsampled input, fused GroupNorm input (one and two
 sources), fused 1x1 skip chunks (plain and GroupNorm main input, one and two skip sources), output statistics, the data gradient with the
 dynamic fp16 scale, bf16 operands (math 1) and the three-product bf16 split (math 2), multi-tile / multi-image / several 128-channel tiles."""
@@ -36,11 +37,15 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).double().cpu()
 
 
-def _both(monkeypatch, run):
-    """run() under conv3x3p (PDAE_P3Q=0) and under conv3x3q (PDAE_P3Q=2): returns the two result lists."""
+KERNELS = ["r", "q"]
+
+
+def _both(monkeypatch, run, kernel):
+    """run() under conv3x3p (both overrides 0) and under conv3x3r / conv3x3q (its override = 2): returns the two results."""
     out = []
-    for mode in ("0", "2"):
-        monkeypatch.setenv("PDAE_P3Q", mode)
+    for on in (False, True):
+        monkeypatch.setenv("PDAE_P3R", "2" if (on and kernel == "r") else "0")
+        monkeypatch.setenv("PDAE_P3Q", "2" if (on and kernel == "q") else "0")
         out.append(run())
         torch.cuda.synchronize()
     return out
@@ -55,6 +60,7 @@ def _gn_ref(x, gamma, beta, ss, G=32):
     return F.silu(xn)
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("math_mode", [4, 1, 2])
 @pytest.mark.parametrize("case", [
     # N, H, W, Cin, Cout, up, res_mode
@@ -62,9 +68,15 @@ def _gn_ref(x, gamma, beta, ss, G=32):
     (1, 64, 48, 96, 256, 0, 1),            # 2 x 3 tiles, 3 chunks, two 128-channel tiles, same-resolution residual
     (3, 32, 32, 64, 128, 1, 2),            # nearest-upsampled input (stored 16 x 16) + half-resolution residual
     (2, 96, 32, 128, 128, 0, 0),           # three tile rows: interior rows see no zero padding at top / bottom
+    (9, 96, 96, 32, 128, 0, 1),            # 324 tiles of 16 x 16: the persistent workgroups walk two tiles each (deferred epilogue, next-tile prefetch)
+    (5, 80, 112, 64, 256, 0, 0),           # 350 tiles x 2 channel tiles = 700: three tiles per workgroup, ragged last round
 ])
-def test_forward_bit_identical_to_conv3x3p_and_close_to_fp64(H, monkeypatch, case, math_mode):
+def test_forward_bit_identical_to_conv3x3p_and_close_to_fp64(H, monkeypatch, case, math_mode, kernel):
     N, Hh, W, C, Cout, up, res_mode = case
+    if kernel == "q" and Hh % 32:
+        pytest.skip("conv3x3q tiles are 32 rows high")
+    if N * Hh * W > 50000 and math_mode != 4:
+        pytest.skip("large cases in the default arithmetic only")
     Hs, Ws = (Hh // 2, W // 2) if up else (Hh, W)
     x = rn(1, N, C, Hs, Ws) * 1.3 + 0.2
     w = rn(2, Cout, C, 3, 3, scale=1.0 / math.sqrt(9 * C)); b = rn(3, Cout, scale=0.2)
@@ -85,18 +97,20 @@ def test_forward_bit_identical_to_conv3x3p_and_close_to_fp64(H, monkeypatch, cas
         y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
         H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, res=resd, res_mode=res_mode, wp=wp))
         return y
-    y_p, y_q = _both(monkeypatch, run)
+    y_p, y_q = _both(monkeypatch, run, kernel)
     assert rel_err(nchw(y_q), y_ref) < TOL[math_mode]
     assert torch.equal(y_p, y_q), float((y_p - y_q).abs().max())
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("case", [
     # N, H, W, C0, C1, Cout, up, res_mode, AdaGN
     (2, 32, 32, 64, 0, 128, 0, 1, True),
     (2, 64, 16, 64, 32, 128, 0, 0, False),     # two-source concat
     (1, 32, 32, 32, 0, 256, 1, 2, True),       # upsampled input, half-resolution residual
+    (6, 96, 128, 32, 32, 128, 0, 1, True),     # 288 tiles: two per persistent workgroup, coefficients of the NEXT image prefetched across the tile boundary
 ])
-def test_fused_groupnorm_input_bit_identical_and_close_to_fp64(H, monkeypatch, case):
+def test_fused_groupnorm_input_bit_identical_and_close_to_fp64(H, monkeypatch, case, kernel):
     N, Hh, W, C0, C1, Cout, up, res_mode, ada = case
     C, G = C0 + C1, 32
     Hs, Ws = (Hh // 2, W // 2) if up else (Hh, W)
@@ -126,13 +140,14 @@ def test_fused_groupnorm_input_bit_identical_and_close_to_fp64(H, monkeypatch, c
         y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
         H.run(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, bd, y, res=resd, res_mode=res_mode))
         return y
-    y_p, y_q = _both(monkeypatch, run)
+    y_p, y_q = _both(monkeypatch, run, kernel)
     assert rel_err(nchw(y_q), y_ref) < 1e-5
     assert torch.equal(y_p, y_q), float((y_p - y_q).abs().max())
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("case", [(16, 64, 32, 64, 64, 32, 128, True), (16, 64, 32, 32, 96, 0, 128, False), (8, 64, 64, 96, 32, 32, 256, False)])
-def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case):
+def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case, kernel):
     """conv3x3(x) + conv1x1([s0 | s1]) in one K loop (centre-tap chunks behind the main chunks), and the GroupNorm partial statistics of the
     output written by the epilogue: same tensor, and the same statistics after the reader's fp64 combine, as conv3x3p."""
     N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
@@ -144,7 +159,6 @@ def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case):
     gamma, beta = 1 + 0.2 * rn(7, C), 0.2 * rn(8, C) + 0.4
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
     cs = H.Conv(N, Hh, W, Cs0, Cs1, Cout, k=1, math=4)
-    monkeypatch.setenv("PDAE_P3Q", "0")
     if not H.conv_fwd_skip_ok(c, cs):
         pytest.skip("pair not eligible for the fused launch at this size")
     a_ref = _gn_ref(x.double(), gamma.double(), beta.double(), None) if use_gn else x.double()
@@ -172,7 +186,7 @@ def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case):
         m, r, k = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, Cout, device="cuda")
         H.run(H.op_gn_coef_from_conv_stats(N, Hh * W, Cout, 0, G, 1e-5, part, tpi, None, 0, g2, b2, None, None, m, r, k))
         return y, part, m, r
-    (y_p, part_p, m_p, r_p), (y_q, part_q, m_q, r_q) = _both(monkeypatch, run)
+    (y_p, part_p, m_p, r_p), (y_q, part_q, m_q, r_q) = _both(monkeypatch, run, kernel)
     assert rel_err(nchw(y_q), y_ref) < 1e-5
     assert torch.equal(y_p, y_q)
     assert torch.isfinite(part_q).all()
@@ -183,9 +197,10 @@ def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case):
     assert (m_q.double() - mean_ref).abs().max() < 5e-6 * max(1.0, float(mean_ref.abs().max()))
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("gscale", [1.0, 3e-7, 2e4])
-@pytest.mark.parametrize("case", [(2, 32, 32, 128, 64), (1, 64, 32, 256, 128)])
-def test_data_gradient_with_dynamic_fp16_scale(H, monkeypatch, case, gscale):
+@pytest.mark.parametrize("case", [(2, 32, 32, 128, 64), (1, 64, 32, 256, 128), (3, 160, 160, 128, 32)])
+def test_data_gradient_with_dynamic_fp16_scale(H, monkeypatch, case, gscale, kernel):
     """dX of a 3x3 convolution = the same kernel on transposed, tap-flipped prepared weights with the per-tensor power-of-two dY scale
     (pdae_amax): Cin of the convolution is the GEMM N here, so it must be a multiple of 128."""
     N, Hh, W, Cin, Cout = case
@@ -205,12 +220,13 @@ def test_data_gradient_with_dynamic_fp16_scale(H, monkeypatch, case, gscale):
         dx = torch.full((N, Hh, W, Cin), float("nan"), device="cuda")
         H.run(H.op_conv_dgrad(c, dyd, wd, dx, wp_t=wp_t, dy_amax=amax))
         return dx
-    dx_p, dx_q = _both(monkeypatch, run)
+    dx_p, dx_q = _both(monkeypatch, run, kernel)
     assert rel_err(nchw(dx_q), xr.grad) < 1e-5
     assert torch.equal(dx_p, dx_q)
 
 
-def test_accumulating_data_gradient(H, monkeypatch):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_accumulating_data_gradient(H, monkeypatch, kernel):
     """accumulate = 1 (a second consumer's gradient joins the buffer): read-modify-write epilogue."""
     N, Hh, W, Cin, Cout = 2, 32, 16, 128, 32
     w = rn(2, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(9 * Cin))
@@ -225,18 +241,18 @@ def test_accumulating_data_gradient(H, monkeypatch):
         dx = base.clone().cuda()
         H.run(H.op_conv_dgrad(c, dyd, wd, dx, accumulate=1, wp_t=wp_t))
         return dx
-    dx_p, dx_q = _both(monkeypatch, run)
+    dx_p, dx_q = _both(monkeypatch, run, kernel)
     assert torch.equal(dx_p, dx_q)
     ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
     assert rel_err(nchw(dx_q) - base.permute(0, 3, 1, 2).double(), ref) < 1e-5
 
 
-def test_large_layers_take_the_new_kernel_by_default(H, monkeypatch):
-    """Routing: with no override a benchmark-sized layer (B=32, 128 x 128, 128 -> 128) runs conv3x3q -- visible as a bit-identical result at a
-    different speed is not testable here, so the eligibility function is asked through the statistics layout instead: conv3x3q numbers the
-    8 x 16 bands row-major over the image, conv3x3p tile by tile; both are permutations of the same per-band sums."""
+def test_large_layers_with_default_routing(H, monkeypatch):
+    """No override: a benchmark-sized layer (B=32, 64 x 64, 128 output channels = 512 tiles of 16 x 16) takes the default route (conv3x3r) and
+    gives the tensor and the partial statistics conv3x3p gives."""
     monkeypatch.delenv("PDAE_P3Q", raising=False)
-    N, Hh, W, C, Cout = 32, 64, 64, 32, 128                     # 256 blocks of 32 x 16 pixels: exactly one round of the chip
+    monkeypatch.delenv("PDAE_P3R", raising=False)
+    N, Hh, W, C, Cout = 32, 64, 64, 32, 128
     x = rn(1, N, C, Hh, W)
     w = rn(2, Cout, C, 3, 3, scale=1.0 / math.sqrt(9 * C)); b = rn(3, Cout, scale=0.2)
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
@@ -248,6 +264,7 @@ def test_large_layers_take_the_new_kernel_by_default(H, monkeypatch):
     for mode in (None, "0"):
         if mode is not None:
             monkeypatch.setenv("PDAE_P3Q", mode)
+            monkeypatch.setenv("PDAE_P3R", mode)
         y = torch.empty(N, Hh, W, Cout, device="cuda"); part = torch.zeros(nbytes // 4, device="cuda")
         H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, wp=wp, stats=part))
         outs.append((y, part.view(N, tpi, Cout // 4, 2)))

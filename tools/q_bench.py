@@ -44,8 +44,8 @@ for (N, S, C0, C1, Cout) in SHAPES:
     for name, op in ops.items():
         t = {}
         for rep in range(2):
-            for mode in ("0", "1"):
-                os.environ["PDAE_P3Q"] = mode
+            for mode, (q_, r_) in (("p", ("0", "0")), ("q", ("2", "0")), ("r", ("0", "2"))):
+                os.environ["PDAE_P3Q"], os.environ["PDAE_P3R"] = q_, r_
                 t[mode] = min(t.get(mode, 1e9), timeit(op))
-        line += f"  {name}: p {t['0']:.3f} ms {fl/t['0']/1e9:5.0f} TF | q {t['1']:.3f} ms {fl/t['1']/1e9:5.0f} TF ({t['0']/t['1']:.2f}x) |"
+        line += f"  {name}: p {t['p']:.3f} ms {fl/t['p']/1e9:4.0f} TF | q {t['q']:.3f} {fl/t['q']/1e9:4.0f} TF | r {t['r']:.3f} {fl/t['r']/1e9:4.0f} TF ({t['p']/t['r']:.2f}x) |"
     print(line, flush=True)
