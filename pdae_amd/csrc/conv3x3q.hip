@@ -414,7 +414,7 @@ template <int NS, bool GN> static int launch_q(const PatchParams& P, hipStream_t
 
 // PDAE_P3Q = 0 routes everything to conv3x3p (A-B aid), 2 ignores the fill heuristic (tests: small shapes through this kernel).  Read per
 // launch -- a getenv costs far less than the launch -- so a test can switch between the two kernels inside one process.
-static int q_mode() { const char* e = getenv("PDAE_P3Q"); return e ? atoi(e) : 1; }
+static int q_mode() { const char* e = getenv("PDAE_P3Q"); return e ? atoi(e) : 0; }      // opt-in: conv3x3r supersedes it on every shape measured (profiles/r03_patch_kernels.txt)
 
 // eligibility of a launch conv3x3p_launch has already planned WITHOUT split-K: fp16 / bf16 formats of at most two planes, 32 x 16 tiles, whole
 // 128-channel output tiles, buffer-addressable sources, and enough tiles that whole rounds of 256 one-block-per-CU workgroups waste little

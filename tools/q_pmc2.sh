@@ -12,8 +12,8 @@ import csv, glob, collections
 info = {}
 for f in glob.glob("$O/${tag}_${n}/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv3x3q" in r["Kernel_Name"]:
-            info[r["Dispatch_Id"]] = (r["Kernel_Name"][5:35], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        if "conv3x3" in r["Kernel_Name"] and "wprep" not in r["Kernel_Name"]:
+            info[r["Dispatch_Id"]] = (r["Kernel_Name"][5:33], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 cnt = collections.defaultdict(dict)
 for f in glob.glob("$O/${tag}_${n}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
