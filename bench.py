@@ -11,10 +11,15 @@ resident in HBM, randomly initialised weights of the FFHQ-128 architecture ([ASS
 hyper-parameters).  Nothing is skipped inside the timed region.
 
 Rank 0 prints ONE JSON line; `value` is whole-job images/s.  Extra objects:
-  roofline     -- the dominant kernel family (igemm_kernel: f32-MFMA implicit-GEMM conv fwd/dgrad/wgrad + dense GEMM):
-                  algorithmic FLOPs of its launches in one step / their summed durations, measured here with HIP events
-                  on the launch stream (per-op event pairs, one extra un-timed step);
-  cpu_baseline -- the CPU oracle (torch fp32, all host threads) running the same step on a bounded sample.
+  roofline     -- the dominant kernel: the 3x3 forward / data-gradient patch kernels (conv3x3r: persistent, deferred epilogue, on the large
+                  layers; conv3x3p on the small ones), split-fp16 MFMA: algorithmic FLOPs of their launches in one step / their summed
+                  durations, measured here with HIP events on the launch stream (per-op event pairs, one extra un-timed step); `wgrad` and
+                  `family` carry the same figures for the 3x3 weight-gradient kernel and for every conv / GEMM launch together;
+  step_mfma_roofline_frac / step_hbm_roofline_frac -- the whole step against the MFMA floor (step FLOPs x 3 products / 2.5 PFLOP/s) and
+                  against the HBM floor SURVEY 8(d) quotes north_star's target on (B x 2.3 GB + 3.0 GB at 8 TB/s);
+  other_legs   -- BASELINE.md section 3 report items: the same step with bf16 operands (enable_amp), and config #2 (CelebA-64, bf16);
+  cpu_baseline -- the CPU oracle (torch fp32, all host threads) running the same step on a bounded sample; ddim100.cpu_baseline the
+                  oracle's decoder forward (what a DDIM step costs on the host cores).
 """
 import argparse
 import json
@@ -46,6 +51,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA
 MFMA_PER_PRODUCT = {"f32": 1, "bf16": 1, "bf16x3": 3, "bf16x6": 6, "f16x3": 3}
 TRAIN_GFLOP_PER_IMG = 481.4         # fwd 258.4 + 2 x 110.7 (shift-branch bwd) + 3 x 0.549 (encoder)
 FWD_GFLOP_PER_IMG = 258.4
+HBM_GB_PER_IMG, HBM_GB_PER_STEP = 2.3, 3.0          # algorithmic HBM bytes of the step = B x 2.3 GB activations + 3.0 GB parameters / optimizer state
+PEAK_HBM_TBS = 8.0
 
 
 def randomize(net, seed):
@@ -128,6 +135,52 @@ def cpu_baseline(batch, steps, warm=3):
     return batch / best, best
 
 
+def cpu_decoder_forward(batch, reps=3):
+    """Seconds per ShiftUNet forward of the CPU oracle at `batch` (one DDIM step = one such forward + an elementwise update)."""
+    from oracle import pdae_oracle as O
+    cfg = dict(load_workload()[1], dropout=0.0)
+    sd = O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=512), 2)
+    x, t, z = torch.randn(batch, 3, 128, 128), torch.randint(0, 1000, (batch,)), torch.randn(batch, 512)
+    ts = []
+    with torch.no_grad():
+        for _ in range(reps + 1):
+            t0 = time.perf_counter()
+            O.shift_unet_forward(sd, cfg, x, t, z)
+            ts.append(time.perf_counter() - t0)
+    return sorted(ts[1:])[len(ts[1:]) // 2]
+
+
+def train_leg(config_file, math, steps, dev, batch=None):
+    """images/s of the fused representation-learning step of another shipped config / arithmetic (BASELINE.md section 3 report items)."""
+    import copy
+    from pdae_amd.model.representation_learning import decoder as decoder_module, encoder as encoder_module
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from pdae_amd.trainer.fused_step import FusedRLStep
+    from pdae_amd.utils import load_yaml
+    c = load_yaml(os.path.join(ROOT, config_file))
+    ddpm = load_yaml(os.path.join(ROOT, c["trained_ddpm_config"]))["denoise_fn_config"]
+    size, B = int(c["train_dataset_config"]["image_size"]), batch or int(c["dataloader_config"]["train"]["batch_size"])
+    enc = getattr(encoder_module, c["encoder_config"]["model"])(device=dev, **c["encoder_config"])
+    dec = getattr(decoder_module, c["decoder_config"]["model"])(device=dev, latent_dim=c["decoder_config"]["latent_dim"], **ddpm)
+    randomize(enc, 11); randomize(dec, 12)
+    enc.train(); dec.set_train_mode()
+    oc, rc = c["optimizer_config"], c["runner_config"]
+    st = FusedRLStep(GaussianDiffusion(c["diffusion_config"], dev), enc, dec, copy.deepcopy(enc), copy.deepcopy(dec), B, size, size, lr=float(oc["lr"]),
+                     betas=eval(oc["adam_betas"]), eps=float(oc["adam_eps"]), weight_decay=float(oc["weight_decay"]), ema_decay=float(rc["ema_decay"]),
+                     ema_every=int(rc["ema_every"]), num_iterations=int(rc["num_iterations"]), math=math)
+    x0 = torch.rand(B, 3, size, size, device=dev) * 2 - 1
+    for _ in range(2):
+        st.step(x0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        st.step(x0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"config": config_file, "math": math or "f16x3", "per_gpu_batch": B, "image": f"3x{size}x{size}", "ms_per_step": round(dt * 1e3, 3),
+            "images_per_sec": round(B / dt, 2), "final_loss": round(st.last_loss, 6), "steps": steps}
+
+
 def host_cores():
     """Usable host cores: min(affinity mask, cgroup CPU quota) -- the GPU box advertises 256 logical CPUs under a 16-CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -179,6 +232,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ddim-batch", type=int, default=100, help="batch of the DDIM-100 measurement (sampler/autoencoding_eval.py:125 uses 100)")
     ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other_legs object (F128 with bf16 operands, CelebA-64 bf16)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--bucket-mb", type=float, default=0, help="gradient bucket size of the data-parallel all-reduce; 0 = sweep 16/48/96 MB in the "
                                                              "warm-up phase and keep the fastest")
@@ -330,8 +384,7 @@ def main():
                       "params_trainable": int(sum(p.numel() for p in dec.P.values() if p.requires_grad) + sum(p.numel() for p in enc.P.values()))},
            "images_per_sec_per_gpu": round(value / world, 3), "final_loss": round(loss_val, 6),
            "fp16_window_events": sat[0], "optimizer_steps_discarded": sat[1],
-           "step_tflops_algorithmic": round(TRAIN_GFLOP_PER_IMG * B / ms_step, 3),
-           "step_frac_of_f32_mfma_peak": round(TRAIN_GFLOP_PER_IMG * B / ms_step / PEAK_F32_MFMA_TFLOPS, 4)}
+           "step_tflops_algorithmic": round(TRAIN_GFLOP_PER_IMG * B / ms_step, 3)}
     if comm is not None:
         out["comm"] = comm
     if dry:
@@ -389,7 +442,7 @@ def main():
             return 4.0 * N * (Ho * Wo * Cout + Hi * s_ * Wi * s_ * Cin) + 6.0 * Cout * 9 * Cin
 
         pk = [k for k in range(st.n_bwd) if is_patch(st.plan.arr[k])]
-        kname = "conv3x3p_kernel (3x3 conv forward + data gradient, LDS-patch kernel)"
+        kname = "conv3x3r_kernel + conv3x3p_kernel (3x3 conv forward + data gradient, LDS-patch kernels: persistent / deferred-epilogue form on the large layers)"
         if not pk:                                    # f32 mode: every convolution runs on the generic f32-MFMA implicit GEMM
             pk = [k for k in range(st.n_bwd) if fl[k] > 0 and st.plan.arr[k].kind != H.OP_GEMM]
             kname = "igemm_kernel (generic implicit-GEMM convolution, f32 MFMA)"
@@ -402,14 +455,36 @@ def main():
         traffic, traffic_src = None, None
         try:                                          # PMC counters cannot be read from inside the process: committed rocprofv3 --pmc passes
             prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            pmc_file = next(f for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof, f)))
+            pmc_file = next(f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof, f)))
             pmc = json.load(open(os.path.join(prof, pmc_file)))
-            kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3p_kernel<") and ", 8, false" in k_]   # every non-pair instantiation
+            kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3r_kernel<") or (k_.startswith("void conv3x3p_kernel<") and ", 8, false" in k_)]   # every non-pair instantiation
+            wk_pmc = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3w_kernel<") and "false" in k_]
             if kk and pmc.get("math", "bf16x6") == math:
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kk) / sum(v["dispatches"] for v in kk))
                 traffic_src = f"profiles/{pmc_file}: committed rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE, gfx950 x2 fetch correction) of this command -- PMC counters cannot be read inside the timed process"
         except (OSError, ValueError, KeyError, StopIteration):
             pass
+        # whole step against both floors (north_star quotes its target on the HBM one; the step is compute-bound: DESIGN.md section 5)
+        step_fl = TRAIN_GFLOP_PER_IMG * B * 1e9
+        out["step_mfma_roofline_frac"] = round(step_fl * (npm if math != "f32" else 1) / ((PEAK_BF16_MFMA_TFLOPS if math != "f32" else PEAK_F32_MFMA_TFLOPS) * 1e12) / (ms_step * 1e-3), 4)
+        out["step_hbm_roofline_frac"] = round((HBM_GB_PER_IMG * B + HBM_GB_PER_STEP) / (PEAK_HBM_TBS * 1e3) / (ms_step * 1e-3), 4)
+        out["step_roofline_note"] = (f"floors at B={B}: MFMA {step_fl * npm / PEAK_BF16_MFMA_TFLOPS / 1e9:.1f} ms ({TRAIN_GFLOP_PER_IMG * B / 1e3:.2f} TFLOP x {npm} MFMA products / 2.5 PFLOP/s), "
+                                     f"HBM {(HBM_GB_PER_IMG * B + HBM_GB_PER_STEP) / PEAK_HBM_TBS:.1f} ms ({HBM_GB_PER_IMG * B + HBM_GB_PER_STEP:.1f} GB / 8 TB/s)")
+        # 3x3 weight-gradient kernel: same figures (algorithmic bytes: X and dY read once, dW written once)
+        wk = [k for k in range(st.n_bwd) if st.plan.arr[k].kind == H.OP_CONV_WGRAD and st.plan.arr[k].i[8] == 3 and bool(st.plan.arr[k].p[6])]
+        if wk:
+            w_ms, w_fl = sum(durs[k] for k in wk), sum(fl[k] for k in wk)
+            w_by = sum(4.0 * st.plan.arr[k].i[0] * (st.plan.arr[k].i[1] * st.plan.arr[k].i[2] * (st.plan.arr[k].i[3] + st.plan.arr[k].i[4]) + st.plan.arr[k].i[5] * st.plan.arr[k].i[6] * st.plan.arr[k].i[7])
+                       + 4.0 * st.plan.arr[k].i[7] * 9 * (st.plan.arr[k].i[3] + st.plan.arr[k].i[4]) for k in wk)
+            w_tr = None
+            try:
+                w_tr = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in wk_pmc) / sum(v["dispatches"] for v in wk_pmc)) if wk_pmc else None
+            except NameError:
+                pass
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv3x3w_kernel (3x3 weight gradient, transposing LDS reads)", "achieved": round(w_fl / w_ms / 1e9, 2),
+                                     "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s", "frac": round(w_fl / w_ms / 1e9 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
+                                     "launches_per_step": len(wk), "avg_launch_ms": round(w_ms / len(wk), 4), "kernel_ms_per_step": round(w_ms, 3),
+                                     "algorithmic_bytes_per_launch": round(w_by / len(wk)), "traffic": w_tr}
         out["roofline"] = {"bound": "mfma", "kernel": kname,
                            "math": math, "achieved": round(p_fl / p_ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                            "frac": round(p_fl / p_ms / 1e9 / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
@@ -420,7 +495,7 @@ def main():
                            "frac_of_f32_mfma_peak": round(p_fl / p_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                            "heaviest_launch": {"gflop": round(fl[kbig] / 1e9, 2), "ms": round(durs[kbig], 4),
                                                "tflops": round(fl[kbig] / durs[kbig] / 1e9, 2)},
-                           "family": {"kernels": "conv3x3p + conv3x3w + conv1x1 + igemm(_bf) (every conv fwd/dgrad/wgrad and dense GEMM)",
+                           "family": {"kernels": "conv3x3r + conv3x3p + conv3x3w + conv1x1 + igemm(_bf) (every conv fwd/dgrad/wgrad and dense GEMM)",
                                       "achieved": round(ig_fl / ig_ms / 1e9, 2), "frac": round(ig_fl / ig_ms / 1e9 / fam_peak, 4), "peak": round(fam_peak, 1),
                                       "launches_per_step": n_ig, "algorithmic_gflop_per_step": round(ig_fl / 1e9, 1),
                                       "ms_per_step": round(ig_ms, 3), "all_ops_ms_per_step": round(sum(durs), 3)}}
@@ -448,6 +523,19 @@ def main():
                         out["ddim100"][f"batch_{Bd}"] = rec
                     dec.invalidate_plans()
             log("ddim100 done")
+            if world == 1 and not args.no_cpu_baseline:          # what the same denoising step costs on the host cores (oracle decoder forward)
+                torch.set_num_threads(host_cores())
+                sec = cpu_decoder_forward(2)
+                out["ddim100"]["cpu_baseline"] = {"value": round(2 / (100 * sec), 5), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                                                  "sample": f"oracle ShiftUNet forward at batch 2, median of 3 ({sec:.2f} s) x 100 steps"}
+        if not args.no_legs:
+            # BASELINE.md section 3 report items: bf16 operands (optimizer_config.enable_amp) on the headline config, and config #2 (CelebA-64, bf16)
+            del st
+            dec.invalidate_plans(); enc.invalidate_plans()
+            torch.cuda.empty_cache()
+            out["other_legs"] = [train_leg(CONFIG, "bf16", 6, dev), train_leg("config/celeba64_representation_learning.yml", "bf16", 10, dev),
+                                 train_leg("config/celeba64_representation_learning.yml", None, 10, dev)]
+            log("other legs done")
         if world == 1 and not args.no_cpu_baseline:
             torch.set_num_threads(host_cores())
             log(f"cpu baseline on {host_cores()} host cores")

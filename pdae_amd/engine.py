@@ -586,7 +586,7 @@ class Builder:
         # channel-changing skip: 1x1 conv over the raw (concat) input
         dx0 = dx1 = None
         if r.has_skip:
-            self.conv_bwd_params(r.cs, dout)
+            self.conv_bwd_params(r.cs, dout, amax=dout_amax)          # same dout as conv2: its abs-max is already known
             if need_dx0:
                 dx0 = self.conv_dgrad(r.cs, dout, ci_off=0, ci_cnt=C0, amax=dout_amax)
             if need_dx1:
@@ -660,7 +660,7 @@ class Builder:
         pl = self.p
         N, T, C, heads, ch = a.N, a.T, a.C, a.heads, a.ch
         oq, ok, ov, hs = a.offs
-        self.conv_bwd_params(a.cp, dout)
+        self.conv_bwd_params(a.cp, dout, amax=dout_amax)
         d_o = self.conv_dgrad(a.cp, dout, amax=dout_amax)          # [N,H,W,C]
         dqkv = pl.buf(*a.qkv.shape)
         if a.lse is not None:                                      # fused backward: probabilities recomputed from q, k and the saved log-sum-exp
