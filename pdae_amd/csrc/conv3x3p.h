@@ -1,5 +1,6 @@
-// Shared pieces of the 3x3 "patch" convolution kernels (conv3x3p.hip: 4 / 8 waves of 128 px x 32 ch at two waves per SIMD;
-// conv3x3q.hip: 4 waves of 256 px x 64 ch at one wave per SIMD): operand formats, LDS patch geometry, launch parameters.
+// Shared pieces of the 3x3 "patch" convolution kernels (conv3x3p.hip: 4 / 8 waves of 128 px x 32 ch at two waves per SIMD, one tile per
+// workgroup; conv3x3r.hip: persistent workgroups of 4 waves of 128 px x 64 ch at one wave per SIMD, deferred epilogue): operand formats,
+// LDS patch geometry, launch parameters.
 #pragma once
 #include "common.h"
 
@@ -87,10 +88,6 @@ __device__ __forceinline__ float p_pow2_scale(float amax) {
 // variant evaluates it once per staged element per block, and under the power cap every VALU instruction is paid for in matrix throughput
 __device__ __forceinline__ float p_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
 
-
-// conv3x3q.hip: the one-wave-per-SIMD form for large layers.  conv3x3p_launch fills PatchParams and hands launches that need no split-K over
-bool conv3x3q_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws, int C0, int Cs0, int Cs1);
-int conv3x3q_launch(int math, const PatchParams& P, hipStream_t s);
 
 // conv3x3r.hip: persistent workgroups with a deferred epilogue for layers with at least two 16 x 16 x 128-channel tiles per CU
 bool conv3x3r_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws, int C0, int Cs0, int Cs1);

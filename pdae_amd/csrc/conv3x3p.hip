@@ -531,9 +531,8 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));
   P.stat_part = stat_part; P.stat_tpi = q.tiles_x * q.tiles_y * (q.th / 8);
   if (P.stat_part && (q.splits != 1 || (Nout & 3))) { pdae_set_error("conv3x3p: output statistics requested for a split-K launch"); return PDAE_EINVAL; }
-  // large layers: 256-pixel x 64-channel wave tiles at one wave per SIMD (conv3x3q.hip); same parameters, same results
+  // large layers: persistent workgroups, one wave per SIMD, epilogue of tile i inside tile i+1 (conv3x3r.hip); same parameters, same results
   if (q.splits == 1 && !q.w8 && (!coef || act) && conv3x3r_ok(math, C, H, W, N, Nout, Hs, Ws, P.C0, P.Cs0, P.Cs1)) return conv3x3r_launch(math, P, s);
-  if (q.splits == 1 && !q.w8 && (!coef || act) && conv3x3q_ok(math, C, H, W, N, Nout, Hs, Ws, P.C0, P.Cs0, P.Cs1)) return conv3x3q_launch(math, P, s);
 #define PDAE_P3(NS_)                                                                                                    \
   (coef ? (q.th == 16 ? launch_ns<NS_, 16, false, true>(P, s) : launch_ns<NS_, 8, false, true>(P, s))                    \
         : (q.w8 ? launch_ns<NS_, 8, true>(P, s) : q.th == 16 ? launch_ns<NS_, 16, false>(P, s) : launch_ns<NS_, 8, false>(P, s)))

@@ -1,11 +1,11 @@
 // 3x3 / stride-1 / pad-1 convolution (forward and data-gradient) for gfx950 -- PERSISTENT form of the patch kernel with a DEFERRED epilogue,
 // for layers with at least a chip-full of 16 x 16-pixel x 128-channel tiles.
 //
-// What the counters said about the other two forms (profiles/r03_q_probes.txt): a launch is rounds of {prologue: first patch from HBM,
-// main loop, epilogue: 64 MB of output per round}, every CU in the same phase at the same time.  While the main loops run HBM idles, while
-// the epilogues run the matrix pipes idle and all 256 CUs queue on the write bandwidth: with loads, conversions and weights compiled out the
-// one-block-per-CU kernel (conv3x3q) still needs 1.45x its MFMA time; conv3x3p hides part of it behind a second block per CU and pays
-// with two instruction streams per SIMD (MFMA pipe busy 0.60).  Here each CU keeps ONE 4-wave workgroup for the whole launch and walks a
+// What the counters said about one-tile-per-workgroup forms (profiles/r03_patch_kernels.txt): a launch is rounds of {prologue: first patch
+// from HBM, main loop, epilogue: 64 MB of output per round}, every CU in the same phase at the same time.  While the main loops run HBM idles,
+// while the epilogues run the matrix pipes idle and all 256 CUs queue on the write bandwidth: with loads, conversions and weights compiled
+// out, a one-workgroup-per-CU prototype with 256-pixel x 64-channel wave tiles still needed 1.3x its MFMA time; conv3x3p hides part of it
+// behind a second workgroup per CU and pays with two instruction streams per SIMD (MFMA pipe busy 0.60).  Here each CU keeps ONE 4-wave workgroup for the whole launch and walks a
 // list of tiles; the epilogue of tile i runs INSIDE the main loop of tile i+1:
 //   * wave tile 128 pixels x 64 output channels = 8 accumulators of 32 x 32 (128 registers); TWO sets live in the 256 AGPRs of a one-wave-per-SIMD
 //     kernel: the set being accumulated and the set being drained (acc -> private LDS transpose tile -> float4 + bias / residual -> global,
@@ -323,20 +323,46 @@ __global__ void __launch_bounds__(RTHREADS, 1) conv3x3r_kernel(const PatchParams
 
   // ---- units.  A main chunk = 18 k-steps (tap, k-half) of 2 units; U = unit of the chunk, S = step, all compile-time after unrolling
   // FIRST: first chunk of a tile -- accumulators start from zero, the previous tile drains underneath
+  // timing probes (tools/probe_build.py, WRONG RESULTS by design)
+#ifdef PDAE_R_PROBE_NOA
+#define PDAE_R_PA(X)
+#else
+#define PDAE_R_PA(X) X
+#endif
+#ifdef PDAE_R_PROBE_NOB
+#define PDAE_R_PB(X)
+#else
+#define PDAE_R_PB(X) X
+#endif
+#ifdef PDAE_R_PROBE_NOGLOAD
+#define PDAE_R_PG(X)
+#else
+#define PDAE_R_PG(X) X
+#endif
+#ifdef PDAE_R_PROBE_NOCONV
+#define PDAE_R_PC(X)
+#else
+#define PDAE_R_PC(X) X
+#endif
+#ifdef PDAE_R_PROBE_NODRAIN
+#define PDAE_R_PD(X)
+#else
+#define PDAE_R_PD(X) X
+#endif
 #define PDAE_R_UNIT_MAIN(U, FIRST)                                                                           \
     {                                                                                                       \
       const int s_ = (U) >> 1, u_ = (U) & 1, tap_ = s_ >> 1, kc_ = s_ & 1;                                  \
-      if ((U) < 35) lda(fa[((U) + 1) & 1], ((U) + 1) >> 2, (((U) + 1) >> 1) & 1, ((U) + 1) & 1);            \
-      else lda(fa[0], tap_, kc_, u_);                                                                       \
-      if (u_ == 0) {                                                                                        \
+      PDAE_R_PA(if ((U) < 35) lda(fa[((U) + 1) & 1], ((U) + 1) >> 2, (((U) + 1) >> 1) & 1, ((U) + 1) & 1);  \
+      else lda(fa[0], tap_, kc_, u_);)                                                                      \
+      PDAE_R_PB(if (u_ == 0) {                                                                              \
         if (s_ + 2 < 18) PDAE_R_LDB_MAIN(qb[(s_ + 2) % 3], chunk, s_ + 2, c_nt0);                           \
         else PDAE_R_LDB_AFTER_MAIN(qb[(s_ + 2) % 3], chunk, s_ + 2 - 18)                                    \
-      }                                                                                                     \
-      if ((U) % 6 == 0 && (U) < 24) { _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) gload_one(((U) / 6) * 3 + g_); } \
-      if ((FIRST) && (U) % 4 == 0 && (U) < 32) drain_L((U) / 4);                                            \
+      })                                                                                                    \
+      PDAE_R_PG(if ((U) % 6 == 0 && (U) < 24) { _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) gload_one(((U) / 6) * 3 + g_); }) \
+      PDAE_R_PD(if ((FIRST) && (U) % 4 == 0 && (U) < 32) drain_L((U) / 4);                                  \
       if ((FIRST) && (U) % 4 == 1 && (U) >= 5 && (U) < 37) drain_W(((U) - 5) / 4);                          \
-      if ((FIRST) && (U) % 4 == 2 && (U) >= 6 && (U) < 38) drain_S(((U) - 6) / 4);                          \
-      if ((U) >= RCV0 && (U) < RCV0 + RLD) convert_store((U) - RCV0);                                       \
+      if ((FIRST) && (U) % 4 == 2 && (U) >= 6 && (U) < 38) drain_S(((U) - 6) / 4);)                         \
+      PDAE_R_PC(if ((U) >= RCV0 && (U) < RCV0 + RLD) convert_store((U) - RCV0);)                            \
       mma(fa[(U) & 1], qb[s_ % 3], u_, (FIRST) && s_ == 0);                                                 \
       PDAE_R_PATTERN(5)                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -387,7 +413,7 @@ __global__ void __launch_bounds__(RTHREADS, 1) conv3x3r_kernel(const PatchParams
     PDAE_R_DECODE(tile + G < ntiles ? tile + G : tile, x_img, x_y0, x_x0, x_n0);
     x_nt0 = (x_n0 >> 5) + wn * 2;
     // ---- main chunks.  The first one (zero start, drain underneath) is its own straight-line copy IN FRONT of the loop over the others: a join
-    // of two 432-MFMA bodies inside one loop made the register allocator route the accumulators through VGPRs (seen with conv3x3q)
+    // of two 432-MFMA bodies inside one loop made the register allocator route the accumulators through VGPRs (seen with the one-tile prototype)
 #define PDAE_R_CHUNK(FIRST)                                                                                  \
     {                                                                                                       \
       int pt, ps;                                                                                           \

@@ -1,8 +1,8 @@
-"""GPU: the one-wave-per-SIMD 3x3 patch kernels -- csrc/conv3x3r.hip (persistent workgroups, 128-pixel x 64-channel wave tiles, epilogue of
-tile i deferred into the main loop of tile i+1) and csrc/conv3x3q.hip (256-pixel x 64-channel wave tiles, one tile per workgroup) -- against
-fp64 references AND against the two-waves-per-SIMD kernel they replace on large layers (csrc/conv3x3p.hip).  All three accumulate every
-output element in the same order (chunks, taps, k-halves, products; same epilogue expression), so their results must be BIT-IDENTICAL:
-PDAE_P3R / PDAE_P3Q = 0 keeps a launch away from that kernel, = 2 routes it there regardless of the fill heuristic (read per launch).
+"""GPU: the persistent 3x3 patch kernel csrc/conv3x3r.hip (one wave per SIMD, 128-pixel x 64-channel wave tiles, epilogue of tile i deferred
+into the main loop of tile i+1) against fp64 references AND against the two-waves-per-SIMD kernel it replaces on large layers
+(csrc/conv3x3p.hip).  Both accumulate every output element in the same order (chunks, taps, k-halves, products; same epilogue expression),
+so their results must be BIT-IDENTICAL: PDAE_P3R = 0 keeps a launch on conv3x3p, = 2 routes it to conv3x3r regardless of the fill
+heuristic (read per launch).
 Covers: plain forward with bias / residual (same- and half-resolution) / nearest-upsampled input, fused GroupNorm input (one and two
 sources), fused 1x1 skip chunks (plain and GroupNorm main input, one and two skip sources), output statistics, the data gradient with the
 dynamic fp16 scale, bf16 operands (math 1) and the three-product bf16 split (math 2), multi-tile / multi-image / several 128-channel tiles."""
@@ -37,15 +37,14 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).double().cpu()
 
 
-KERNELS = ["r", "q"]
+KERNELS = ["r"]
 
 
 def _both(monkeypatch, run, kernel):
-    """run() under conv3x3p (both overrides 0) and under conv3x3r / conv3x3q (its override = 2): returns the two results."""
+    """run() under conv3x3p (PDAE_P3R=0) and under conv3x3r (PDAE_P3R=2): returns the two results."""
     out = []
     for on in (False, True):
-        monkeypatch.setenv("PDAE_P3R", "2" if (on and kernel == "r") else "0")
-        monkeypatch.setenv("PDAE_P3Q", "2" if (on and kernel == "q") else "0")
+        monkeypatch.setenv("PDAE_P3R", "2" if on else "0")
         out.append(run())
         torch.cuda.synchronize()
     return out
@@ -73,8 +72,6 @@ def _gn_ref(x, gamma, beta, ss, G=32):
 ])
 def test_forward_bit_identical_to_conv3x3p_and_close_to_fp64(H, monkeypatch, case, math_mode, kernel):
     N, Hh, W, C, Cout, up, res_mode = case
-    if kernel == "q" and Hh % 32:
-        pytest.skip("conv3x3q tiles are 32 rows high")
     if N * Hh * W > 50000 and math_mode != 4:
         pytest.skip("large cases in the default arithmetic only")
     Hs, Ws = (Hh // 2, W // 2) if up else (Hh, W)
@@ -250,7 +247,6 @@ def test_accumulating_data_gradient(H, monkeypatch, kernel):
 def test_large_layers_with_default_routing(H, monkeypatch):
     """No override: a benchmark-sized layer (B=32, 64 x 64, 128 output channels = 512 tiles of 16 x 16) takes the default route (conv3x3r) and
     gives the tensor and the partial statistics conv3x3p gives."""
-    monkeypatch.delenv("PDAE_P3Q", raising=False)
     monkeypatch.delenv("PDAE_P3R", raising=False)
     N, Hh, W, C, Cout = 32, 64, 64, 32, 128
     x = rn(1, N, C, Hh, W)
@@ -263,7 +259,6 @@ def test_large_layers_with_default_routing(H, monkeypatch):
     outs = []
     for mode in (None, "0"):
         if mode is not None:
-            monkeypatch.setenv("PDAE_P3Q", mode)
             monkeypatch.setenv("PDAE_P3R", mode)
         y = torch.empty(N, Hh, W, Cout, device="cuda"); part = torch.zeros(nbytes // 4, device="cuda")
         H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, wp=wp, stats=part))

@@ -1,5 +1,5 @@
-"""Same-box A/B of the two 3x3 patch kernels (conv3x3p: PDAE_P3Q=0, conv3x3q: PDAE_P3Q=1) on the large forward / data-gradient shapes of the
-FFHQ-128 step: ms and algorithmic TFLOP/s per launch, plain and fused-GroupNorm forms.  Usage: python tools/q_bench.py [batch]"""
+"""Same-box A/B of the two 3x3 patch kernels (conv3x3p: PDAE_P3R=0, conv3x3r: PDAE_P3R=2) on the large forward / data-gradient shapes of the
+FFHQ-128 step: ms and algorithmic TFLOP/s per launch, plain and fused-GroupNorm forms.  Usage: python tools/patch_bench.py [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -44,8 +44,8 @@ for (N, S, C0, C1, Cout) in SHAPES:
     for name, op in ops.items():
         t = {}
         for rep in range(2):
-            for mode, (q_, r_) in (("p", ("0", "0")), ("q", ("2", "0")), ("r", ("0", "2"))):
-                os.environ["PDAE_P3Q"], os.environ["PDAE_P3R"] = q_, r_
+            for mode, r_ in (("p", "0"), ("r", "2")):
+                os.environ["PDAE_P3R"] = r_
                 t[mode] = min(t.get(mode, 1e9), timeit(op))
-        line += f"  {name}: p {t['p']:.3f} ms {fl/t['p']/1e9:4.0f} TF | q {t['q']:.3f} {fl/t['q']/1e9:4.0f} TF | r {t['r']:.3f} {fl/t['r']/1e9:4.0f} TF ({t['p']/t['r']:.2f}x) |"
+        line += f"  {name}: p {t['p']:.3f} ms {fl/t['p']/1e9:4.0f} TF | r {t['r']:.3f} {fl/t['r']/1e9:4.0f} TF ({t['p']/t['r']:.2f}x) |"
     print(line, flush=True)

@@ -1,12 +1,12 @@
 #!/bin/bash
-# cycles / clock / wait breakdown of conv3x3q for the product and the probe builds on ONE shape set.  Usage: tools/q_pmc2.sh <tag> [libdirs...]
+# cycles / clock / wait breakdown of the 3x3 patch kernels for the product and probe builds on ONE shape set.  Usage: tools/patch_pmc.sh <tag> [libdirs...]
 tag=$1; shift
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 for lib in product "$@"; do
   n=$(basename $lib)
   [ $lib = product ] && unset PDAE_HIP_LIB || export PDAE_HIP_LIB=$R/$lib/libpdae_hip.so
-  (cd /tmp && timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/${tag}_${n} -- python $R/tools/q_bench.py > $O/${tag}_${n}.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/${tag}_${n} -- python $R/tools/patch_bench.py > $O/${tag}_${n}.log 2>&1)
   python - <<PY
 import csv, glob, collections
 info = {}

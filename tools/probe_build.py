@@ -4,14 +4,14 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pdae_amd.build import CSRC, LIBDIR, SOURCES, HIPCC, FLAGS
-P3, W3, Q3 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3q.hip"
+P3, W3, R3 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip"
 VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"]), "nostage": (P3, ["-DPDAE_PROBE_NOSTAGE"]),
             "mfma": (P3, ["-DPDAE_PROBE_NOB", "-DPDAE_PROBE_NOA", "-DPDAE_PROBE_NOSTAGE"]), "clustered": (P3, ["-DPDAE_P3_CLUSTERED"]),
             "w3_nomma": (W3, ["-DPDAE_W3_PROBE_NOMMA"]), "w3_nostage": (W3, ["-DPDAE_W3_PROBE_NOSTAGE"]), "w3_noload": (W3, ["-DPDAE_W3_PROBE_NOLOAD"]),
             "w3_mmaonly": (W3, ["-DPDAE_W3_PROBE_NOSTAGE", "-DPDAE_W3_PROBE_NOLOAD"]),
-            "q_burst": (Q3, ["-DPDAE_Q_BURST"]), "q_nogload": (Q3, ["-DPDAE_Q_PROBE_NOGLOAD"]), "q_noconv": (Q3, ["-DPDAE_Q_PROBE_NOCONV"]), "q_noa": (Q3, ["-DPDAE_Q_PROBE_NOA"]),
-            "q_nob": (Q3, ["-DPDAE_Q_PROBE_NOB"]), "q_nostage": (Q3, ["-DPDAE_Q_PROBE_NOGLOAD", "-DPDAE_Q_PROBE_NOCONV"]),
-            "q_mfma": (Q3, ["-DPDAE_Q_PROBE_NOGLOAD", "-DPDAE_Q_PROBE_NOCONV", "-DPDAE_Q_PROBE_NOA", "-DPDAE_Q_PROBE_NOB"])}
+            "r_noa": (R3, ["-DPDAE_R_PROBE_NOA"]), "r_nob": (R3, ["-DPDAE_R_PROBE_NOB"]), "r_nogload": (R3, ["-DPDAE_R_PROBE_NOGLOAD"]),
+            "r_noconv": (R3, ["-DPDAE_R_PROBE_NOCONV"]), "r_nodrain": (R3, ["-DPDAE_R_PROBE_NODRAIN"]),
+            "r_mfma": (R3, ["-DPDAE_R_PROBE_NOA", "-DPDAE_R_PROBE_NOB", "-DPDAE_R_PROBE_NOGLOAD", "-DPDAE_R_PROBE_NOCONV", "-DPDAE_R_PROBE_NODRAIN"])}
 only = sys.argv[1:]
 for name, (src, defs) in VARIANTS.items():
     if only and not any(name.startswith(o) for o in only): continue
