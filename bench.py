@@ -261,10 +261,17 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ["NCCL_DEBUG"] = os.environ.get("PDAE_NCCL_DEBUG", "WARN")      # RCCL's version banner goes to stdout: keep it to the one JSON line
+        # knobs for the CU contention between RCCL's copy kernels and the power-capped MFMA kernels (recorded in `comm`):
+        #   PDAE_RCCL_CHANNELS = n   -> NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = n (each channel is one workgroup per peer direction)
+        #   PDAE_RCCL_CUMASK = hex   -> HSA_CU_MASK-style mask handed to RCCL's streams is not exposed by torch; documented, not applied here
+        if os.environ.get("PDAE_RCCL_CHANNELS"):
+            os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = os.environ["PDAE_RCCL_CHANNELS"]
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("PDAE_COMM_TIMEOUT_S", "300")))      # a wedged collective errors out instead of sitting in the driver's timeout
         if dry:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=tmo)
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=tmo)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     def sync():
@@ -312,10 +319,16 @@ def main():
         dist.all_reduce(ones)
         comm = {"backend": dist.get_backend(), "exchange": "pdae_allreduce_bucket (own RCCL communicator, side stream)" if st.ncomm is not None else "torch.distributed.all_reduce (async)",
                 "rccl_ranks": int(ones.item()), "grad_bytes_per_step": int(4 * (dec.flat_grad.numel() + enc.flat_grad.numel()))}
+        comm["rccl_channels"] = os.environ.get("PDAE_RCCL_CHANNELS", "default")
         sweep = {}
         for mb in ([args.bucket_mb] if args.bucket_mb else [16, 48, 96]):
             st.buckets = st._make_buckets(st._marks, mb)
-            st.step(x0); sync(); dist.barrier()
+            try:
+                st.step(x0); sync(); dist.barrier()
+            except (RuntimeError, Exception) as e:              # noqa: BLE001 -- bucketed exchange failed: FusedRLStep has switched to the post-backward fallback
+                log(f"rank {rank}: bucketed exchange failed during the sweep ({type(e).__name__}); continuing with the fallback all-reduce")
+                comm["fallback"] = f"{type(e).__name__}: {str(e)[:200]}"
+                st.step(x0); sync(); dist.barrier()
             t1 = time.perf_counter()
             for _ in range(3):
                 st.step(x0)

@@ -415,11 +415,16 @@ def encoder_forward(B, name, x):
     return z, NS(ctxs=ctxs, lz=lz, last=h, flat=flat)
 
 
-def encoder_backward(B, ex, dz):
+def encoder_backward(B, ex, dz, mark=None):
+    """mark(prefix): called when every parameter gradient under `prefix` has been emitted (DDP bucket boundaries): the final Linear holds more
+    than half of the encoder's gradient bytes and is final first, so its all-reduce starts under the rest of the encoder backward instead of
+    behind the last backward op."""
     pl = B.p
+    mark = mark or (lambda prefix: None)
     N, Hh, W, C = ex.last.shape
     d_flat = pl.buf(N, C * Hh * W)
     B.linear_bwd(ex.lz, dz, dx=d_flat, dx_acc=0)
+    mark(ex.lz.wname + ".")
     dh = pl.buf(N, Hh, W, C)
     pl.emit(H.op_to_nhwc(d_flat, (C * Hh * W, Hh * W, W, 1), N, C, Hh, W, dh))
     pl.free(d_flat)
@@ -428,10 +433,13 @@ def encoder_backward(B, ex, dz):
         if kind == "gn":
             dprev = pl.buf(c.N, c.H, c.W, c.C0)
             B.gn_bwd(c, dh, 0, dx0=dprev)
+            mark(c.gname + ".")
         elif kind == "attn":
             dprev, _ = B.attention_bwd(c, dh, need_dx=True)
+            mark(c.pre + ".")
         else:
             B.conv_bwd_params(c, dh)
             dprev = B.conv_dgrad(c, dh) if j > 0 else None
+            mark(c.wname + ".")
         pl.free(dh)
         dh = dprev

@@ -103,9 +103,12 @@ class _FusedStep:
                 continue
             cur_hi = net.flat_grad.numel()
             pend_lo = cur_hi
+            # a network smaller than two buckets (the encoder: 15.6 MB, more than half of it in the final Linear whose gradient is final
+            # first) still gets an early bucket: half of its bytes is the threshold
+            limit_net = min(limit, max(net.flat_grad.numel() // 2, 1))
             for op_idx, lo, hi in ranges:                # backward order: descending offsets
                 pend_lo = min(pend_lo, lo)
-                if cur_hi - pend_lo >= limit:
+                if cur_hi - pend_lo >= limit_net:
                     buckets.append((op_idx, net.flat_grad[pend_lo:cur_hi]))
                     cur_hi = pend_lo
             if cur_hi > 0:
@@ -149,7 +152,27 @@ class _FusedStep:
     def backward_with_allreduce(self, run):
         """Issues the forward+backward op list in segments; as soon as a bucket's gradients are final its all-reduce(sum) is
         launched asynchronously (RCCL stream), overlapping with the rest of the backward.  `run(first, last)` issues plan ops.
-        The saturation word travels with the last bucket (MAX) so that every rank takes the same skip decision."""
+        The saturation word travels with the last bucket (MAX) so that every rank takes the same skip decision.
+        A collective that raises (RCCL init / enqueue error) is reported with the rank and the step falls back -- for good -- to ONE
+        all-reduce per flat gradient buffer after the backward, through the same process group: slower, never a silent hang on this side."""
+        if getattr(self, "_comm_fallback", False):
+            run(0, self.n_bwd)
+            for n in self.flat_nets:
+                dist.all_reduce(n.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.guard is not None and self.math_name == "f16x3":
+                dist.all_reduce(self.guard.t[0:1], op=dist.ReduceOp.MAX, group=self.pg)
+            return
+        try:
+            self._bucketed(run)
+        except (RuntimeError, H.PdaeError) as e:            # ProcessGroupNCCL / pdae_allreduce_bucket errors surface as RuntimeError / PdaeError
+            rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
+            print(f"[pdae_amd] rank {rank}: bucketed gradient exchange failed ({type(e).__name__}: {e}); falling back to one all-reduce per "
+                  "gradient buffer after the backward", file=sys.stderr, flush=True)
+            self._comm_fallback, self.ncomm = True, None
+            torch.cuda.synchronize()
+            raise                                             # this step's gradients are in an unknown state: the caller decides (bench: retry)
+
+    def _bucketed(self, run):
         works, cur = [], 0
         ev = self.comm_events
         nc = self.ncomm
@@ -247,7 +270,7 @@ class FusedRLStep(_FusedStep):
         self.z, self.eps, self.shift = z, fx.eps, fx.shift
         # ---- backward, with the op index at which each parameter block's gradients are final
         dz = G.shift_backward(Bd, fx, d_shift, mark=lambda prefix: self._marks.append((len(p.recs), decoder, prefix)))
-        G.encoder_backward(Be, ex, dz)
+        G.encoder_backward(Be, ex, dz, mark=lambda prefix: self._marks.append((len(p.recs), encoder, prefix)))
 
     def load_batch(self, x_0, t=None, noise=None):
         """x_0 / noise: (N,C,H,W) tensors of any strides.  t, noise are drawn like the reference

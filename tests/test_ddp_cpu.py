@@ -47,12 +47,18 @@ def _worker(rank, world, port, q):
         gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device("cpu"))
         st = FusedRLStep(gd, enc, dec, copy.deepcopy(enc), copy.deepcopy(dec), 2, 64, 64, bucket_mb=1)
         assert st.world == world
-        # buckets: cover both flat gradient buffers exactly once, in backward (descending offset) order
-        dec_b = [v for _, v in st.buckets[:-1]]
+        # buckets: cover both flat gradient buffers exactly once, each in backward (descending offset) order; the decoder's come first, the
+        # encoder's final Linear (more than half of its bytes, final first) is released before the end of the backward
+        def inside(v, buf):
+            return buf.data_ptr() <= v.data_ptr() < buf.data_ptr() + buf.numel() * 4
+        dec_b = [v for _, v in st.buckets if inside(v, dec.flat_grad)]
+        enc_b = [(i, v) for i, v in st.buckets if inside(v, enc.flat_grad)]
+        assert len(dec_b) + len(enc_b) == len(st.buckets)
         assert sum(v.numel() for v in dec_b) == dec.flat_grad.numel() and len(dec_b) >= 3
-        ptrs = [v.data_ptr() for v in dec_b]
-        assert ptrs == sorted(ptrs, reverse=True)
-        assert st.buckets[-1][1].data_ptr() == enc.flat_grad.data_ptr()
+        assert sum(v.numel() for _, v in enc_b) == enc.flat_grad.numel() and len(enc_b) >= 2
+        for ptrs in ([v.data_ptr() for v in dec_b], [v.data_ptr() for _, v in enc_b]):
+            assert ptrs == sorted(ptrs, reverse=True)
+        assert enc_b[-1][1].data_ptr() == enc.flat_grad.data_ptr() and enc_b[0][0] < st.n_bwd
         ops_idx = [i for i, _ in st.buckets]
         assert ops_idx == sorted(ops_idx) and st.n_fwd < ops_idx[0] and ops_idx[-1] == st.n_bwd
         # fake "backward": every rank writes rank-dependent gradients, segments are recorded instead of launched
