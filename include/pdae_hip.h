@@ -29,7 +29,7 @@ extern "C" {
 typedef void* pdae_stream_t; /* hipStream_t */
 
 const char* pdae_last_error(void);
-int pdae_abi_version(void);   /* 3: + pdae_conv_stats_* / pdae_gn_coef_from_conv_stats (2: saturation counter, row-coefficient samplers, fused attention, RCCL) */
+int pdae_abi_version(void);   /* 4: + pdae_conv_wprep_job / _group (3: + pdae_conv_stats_* / pdae_gn_coef_from_conv_stats; 2: saturation counter, row-coefficient samplers, fused attention, RCCL) */
 
 /* ---- convolution (F.conv2d / conv1d k=1: module.py:242,265,276,412,420; unet.py:62,174; encoder/ffhq.py:12-30) */
 typedef struct pdae_conv_desc {
@@ -85,6 +85,21 @@ int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, const float* x1
 int pdae_conv2d_fwd_skip_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds);
 size_t pdae_conv_skip_wprep_bytes(const pdae_conv_desc* d, const pdae_conv_desc* ds);
 int pdae_conv_skip_wprep(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_stream_t stream);
+/* Grouped form of pdae_conv_wprep / pdae_conv_skip_wprep for hosts that run the same set of convolutions every step (a training or
+ * sampling plan): describe every prepared copy ONCE with pdae_conv_wprep_job / pdae_conv_skip_wprep_job (same arguments, same decisions;
+ * they only fill `job`, nothing is launched), upload the job table and the prefix table first_block[j] = sum of jobs[0..j).nblocks to the
+ * device, and call pdae_conv_wprep_group(jobs, first_block, njobs, total_blocks) whenever the weights have changed: one launch instead of
+ * one per convolution (134 -> 1 per FFHQ-128 training step).  The pointers inside a job must stay valid; the layout of pdae_wprep_job is
+ * part of the ABI (48 bytes). */
+typedef struct pdae_wprep_job {
+  const float* w; void* wp;          /* fp32 weights, prepared copy */
+  int32_t Nout, C, NT, transposed;   /* GEMM N, GEMM K channels, 32-channel tiles, data-gradient form */
+  int32_t T, ns;                     /* taps of the 3x3 layout (9, 1 for fused skip chunks; 0 = the 1x1 layout), operand format (1..4) */
+  float wscale; int32_t nblocks;     /* power-of-two weight scale (format 4), 256-thread blocks this job needs */
+} pdae_wprep_job;
+int pdae_conv_wprep_job(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_wprep_job* job);
+int pdae_conv_skip_wprep_job(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_wprep_job* job);
+int pdae_conv_wprep_group(const pdae_wprep_job* jobs_dev, const int32_t* first_block_dev, int njobs, int total_blocks, pdae_stream_t stream);
 int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
                          const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps, const float* bias_s, float* y,
                          pdae_stream_t stream);
@@ -268,7 +283,7 @@ enum {
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
   PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
   PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP,
-  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP, PDAE_OP_GN_COEF_FROM_CONV_STATS
+  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP, PDAE_OP_GN_COEF_FROM_CONV_STATS, PDAE_OP_CONV_WPREP_GROUP
 };
 typedef struct pdae_op {
   int32_t kind;

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "igemm.h"
 #include "kernels.h"
+#include "conv3x3p.h"
 
 static thread_local char g_err[512] = "";
 
@@ -19,7 +20,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 3; }
+extern "C" int pdae_abi_version(void) { return 4; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -102,6 +103,38 @@ extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flag
   }
   if (transposed) return conv1x1_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
   return conv1x1_wprep(d->math, w, d->Cout, Cin, 0, (unsigned short*)wp, S(stream));
+}
+
+// ---- grouped weight preparation (wprep.hip): the host fills one job per prepared copy with the SAME decisions pdae_conv_wprep /
+// pdae_conv_skip_wprep take, uploads the table once, and every run of the plan prepares all of them in one launch
+static_assert(sizeof(pdae_wprep_job) == sizeof(WprepJob), "pdae_wprep_job must mirror WprepJob");
+extern "C" int pdae_conv_wprep_job(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_wprep_job* job) {
+  if (int e = check_desc(d)) return e;
+  const int transposed = flags & PDAE_WPREP_TRANSPOSED;
+  PDAE_CHECK_ARG(w && wp && job, "conv_wprep_job: null pointer");
+  WprepJob* j = reinterpret_cast<WprepJob*>(job);
+  if (flags & PDAE_WPREP_GN) {
+    PDAE_CHECK_ARG(!transposed && gn_patch_ok(d, false), "conv_wprep_job: convolution not eligible for the fused-GroupNorm patch kernel");
+    conv3x3p_wprep_job(d->math, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, j);
+    return PDAE_OK;
+  }
+  const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
+  PDAE_CHECK_ARG(kind != 0, "conv_wprep_job: convolution shape not eligible for a prepared-weight kernel");
+  if (kind == 3) {
+    if (transposed) conv3x3p_wprep_job(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, j);
+    else conv3x3p_wprep_job(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, j);
+  } else if (transposed) conv1x1_wprep_job(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, j);
+  else conv1x1_wprep_job(d->math, w, d->Cout, Cin, 0, (unsigned short*)wp, j);
+  return PDAE_OK;
+}
+extern "C" int pdae_conv_skip_wprep_job(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_wprep_job* job) {
+  PDAE_CHECK_ARG(w_skip && wps && job && pdae_conv2d_fwd_skip_ok(d, ds), "conv_skip_wprep_job: not an eligible (conv3x3, skip 1x1) pair");
+  conv3x3p_skip_wprep_job(d->math, w_skip, ds->Cout, ds->C0 + ds->C1, d->C0 + d->C1, (unsigned short*)wps, reinterpret_cast<WprepJob*>(job));
+  return PDAE_OK;
+}
+extern "C" int pdae_conv_wprep_group(const pdae_wprep_job* jobs_dev, const int32_t* first_block_dev, int njobs, int total_blocks, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(njobs >= 0 && total_blocks >= 0 && (njobs == 0 || (jobs_dev && first_block_dev)), "conv_wprep_group: bad arguments");
+  return wprep_group_launch(reinterpret_cast<const WprepJob*>(jobs_dev), first_block_dev, njobs, total_blocks, S(stream));
 }
 
 extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
@@ -606,6 +639,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
       if (p[19]) conv3x3p_arm_stats((float*)p[19]);
       return pdae_conv2d_fwd_skip(&d, F(0), F(1), F(2), (int)i[14], p[3], F(4), &ds, F(5), F(6), p[7], F(8), FM(9), st);
     }
+    case PDAE_OP_CONV_WPREP_GROUP: return pdae_conv_wprep_group((const pdae_wprep_job*)p[0], (const int32_t*)p[1], (int)i[0], (int)i[1], st);
     case PDAE_OP_CONV_SKIP_WPREP: {
       desc_from(i, d);
       pdae_conv_desc ds = d;

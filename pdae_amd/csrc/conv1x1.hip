@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "igemm.h"
+#include "conv3x3p.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -321,32 +322,7 @@ template <int NS>
 __global__ void __launch_bounds__(256) conv1x1_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed, float wscale,
                                                             unsigned short* __restrict__ wp) {
   const size_t nslot = (size_t)(C >> 4) * NT * 64;
-  const size_t plane_stride = nslot * 8;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) {
-    const int lane = (int)(i & 63); size_t r = i >> 6;
-    const int nt = (int)(r % NT); const int s = (int)(r / NT);
-    const int n = nt * 32 + (lane & 31), c = (s << 4) + (lane >> 5) * 8;
-    float e[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = 0.f;
-    if (n < Nout) {
-      if (transposed) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = w[(size_t)(c + j) * Nout + n];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = w[(size_t)n * C + c + j];
-      }
-    }
-    if constexpr (NS == 4) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] *= wscale;
-    }
-    unsigned a[QNPL(NS)], b[QNPL(NS)], cc[QNPL(NS)], d[QNPL(NS)];
-    q_split2<NS>(e[0], e[1], a); q_split2<NS>(e[2], e[3], b); q_split2<NS>(e[4], e[5], cc); q_split2<NS>(e[6], e[7], d);
-#pragma unroll
-    for (int p = 0; p < QNPL(NS); ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
-  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) wprep1_slot<NS>(w, Nout, C, NT, transposed, wscale, wp, i);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,6 +392,13 @@ int conv1x1_wprep(int math, const float* w, int Nrows, int C, int transposed, un
   else if (math == 4) hipLaunchKernelGGL(conv1x1_wprep_kernel<4>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wscale, wp);
   else hipLaunchKernelGGL(conv1x1_wprep_kernel<3>, dim3(grid), dim3(256), 0, s, w, Nrows, C, NT, transposed, wscale, wp);
   return pdae_launch_status("conv1x1_wprep");
+}
+
+void conv1x1_wprep_job(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, WprepJob* j) {
+  math = c1_math(math);
+  j->w = w; j->wp = wp; j->Nout = Nrows; j->C = C; j->NT = (Nrows + 31) / 32; j->transposed = transposed; j->T = 0;      // T = 0: the 1x1 layout
+  j->ns = math; j->wscale = conv1x1_wscale(C);
+  j->nblocks = (int)(((size_t)(C >> 4) * j->NT * 64 + 255) / 256);
 }
 
 int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const unsigned short* wp, int Nrows, int row_off,

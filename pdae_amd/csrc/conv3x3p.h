@@ -89,6 +89,68 @@ __device__ __forceinline__ float p_pow2_scale(float amax) {
 __device__ __forceinline__ float p_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
 
 
+// ---- weight preparation, one fragment slot (8 consecutive k of one output channel) per call; shared by the per-convolution kernels and the
+// grouped launch (wprep.hip).  3x3 layout: wp [NS][C/32][T][2][NT][64][8] (T taps: 9, or 1 for fused 1x1 skip chunks); 1x1 layout:
+// wp [NS][C/16][NT][64][8].  transposed: the data-gradient weights (3x3: w'[n][tap][c] = w[c][T-1-tap][n], w stored [C][T][Nout]).
+template <int NS> __device__ __forceinline__ void wprep_store_slot(float (&e)[8], float wscale, unsigned short* __restrict__ wp, size_t plane_stride, size_t i) {
+  if constexpr (NS == 4) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] *= wscale;
+  }
+  unsigned a[NPL(NS)], b[NPL(NS)], cc[NPL(NS)], d[NPL(NS)];
+  p_split2<NS>(e[0], e[1], a); p_split2<NS>(e[2], e[3], b); p_split2<NS>(e[4], e[5], cc); p_split2<NS>(e[6], e[7], d);
+#pragma unroll
+  for (int p = 0; p < NPL(NS); ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
+}
+template <int NS> __device__ __forceinline__ void wprep3_slot(const float* __restrict__ w, int Nout, int C, int NT, int transposed, float wscale, int T,
+                                                              unsigned short* __restrict__ wp, size_t i) {
+  const size_t plane_stride = (size_t)(C >> 5) * 2 * T * NT * 64 * 8;
+  const int lane = (int)(i & 63); size_t r = i >> 6;
+  const int nt = (int)(r % NT); r /= NT;
+  const int kc = (int)(r & 1); r >>= 1;
+  const int tap = (int)(r % T); const int chunk = (int)(r / T);
+  const int n = nt * 32 + (lane & 31), c = (chunk << 5) + kc * 16 + (lane >> 5) * 8;
+  float e[8];
+  if (n < Nout && transposed) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = w[((size_t)(c + j) * T + (T - 1 - tap)) * Nout + n];
+  } else if (n < Nout) {
+    const float4 v0 = *reinterpret_cast<const float4*>(w + ((size_t)n * T + tap) * C + c);
+    const float4 v1 = *reinterpret_cast<const float4*>(w + ((size_t)n * T + tap) * C + c + 4);
+    e[0] = v0.x; e[1] = v0.y; e[2] = v0.z; e[3] = v0.w; e[4] = v1.x; e[5] = v1.y; e[6] = v1.z; e[7] = v1.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = 0.f;
+  }
+  wprep_store_slot<NS>(e, wscale, wp, plane_stride, i);
+}
+template <int NS> __device__ __forceinline__ void wprep1_slot(const float* __restrict__ w, int Nout, int C, int NT, int transposed, float wscale,
+                                                              unsigned short* __restrict__ wp, size_t i) {
+  const size_t plane_stride = (size_t)(C >> 4) * NT * 64 * 8;
+  const int lane = (int)(i & 63); const size_t r = i >> 6;
+  const int nt = (int)(r % NT); const int s = (int)(r / NT);
+  const int n = nt * 32 + (lane & 31), c = (s << 4) + (lane >> 5) * 8;
+  float e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = 0.f;
+  if (n < Nout) {
+    if (transposed) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = w[(size_t)(c + j) * Nout + n];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = w[(size_t)n * C + c + j];
+    }
+  }
+  wprep_store_slot<NS>(e, wscale, wp, plane_stride, i);
+}
+// one job of the grouped launch (= include/pdae_hip.h: pdae_wprep_job) and how the existing entry points describe theirs
+struct WprepJob { const float* w; unsigned short* wp; int Nout, C, NT, transposed, T, ns; float wscale; int nblocks; };
+void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j);
+void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, WprepJob* j);
+void conv1x1_wprep_job(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, WprepJob* j);
+int wprep_group_launch(const WprepJob* jobs_dev, const int* first_block_dev, int njobs, int total_blocks, hipStream_t s);
+
 // conv3x3r.hip: persistent workgroups with a deferred epilogue for layers with at least two 16 x 16 x 128-channel tiles per CU
 bool conv3x3r_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws, int C0, int Cs0, int Cs1);
 int conv3x3r_launch(int math, const PatchParams& P, hipStream_t s);

@@ -552,34 +552,7 @@ template <int NS>
 __global__ void __launch_bounds__(256) conv3x3p_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed, float wscale,
                                                              int T, unsigned short* __restrict__ wp) {
   const size_t nslot = (size_t)(C >> 5) * 2 * T * NT * 64;          // T taps: 9 (3x3) or 1 (fused 1x1 skip chunks)
-  const size_t plane_stride = nslot * 8;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) {
-    const int lane = (int)(i & 63); size_t r = i >> 6;
-    const int nt = (int)(r % NT); r /= NT;
-    const int kc = (int)(r & 1); r >>= 1;
-    const int tap = (int)(r % T); const int chunk = (int)(r / T);
-    const int n = nt * 32 + (lane & 31), c = (chunk << 5) + kc * 16 + (lane >> 5) * 8;
-    float e[8];
-    if (n < Nout && transposed) {               // GEMM weight w'[n][tap][c] = w[c][8 - tap][n]   (w stored [C][9][Nout])
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = w[((size_t)(c + j) * T + (T - 1 - tap)) * Nout + n];
-    } else if (n < Nout) {
-      const float4 v0 = *reinterpret_cast<const float4*>(w + ((size_t)n * T + tap) * C + c);
-      const float4 v1 = *reinterpret_cast<const float4*>(w + ((size_t)n * T + tap) * C + c + 4);
-      e[0] = v0.x; e[1] = v0.y; e[2] = v0.z; e[3] = v0.w; e[4] = v1.x; e[5] = v1.y; e[6] = v1.z; e[7] = v1.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = 0.f;
-    }
-    if constexpr (NS == 4) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] *= wscale;
-    }
-    unsigned a[NPL(NS)], b[NPL(NS)], cc[NPL(NS)], d[NPL(NS)];
-    p_split2<NS>(e[0], e[1], a); p_split2<NS>(e[2], e[3], b); p_split2<NS>(e[4], e[5], cc); p_split2<NS>(e[6], e[7], d);
-#pragma unroll
-    for (int p = 0; p < NPL(NS); ++p) *reinterpret_cast<uint4*>(wp + p * plane_stride + i * 8) = make_uint4(a[p], b[p], cc[p], d[p]);
-  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) wprep3_slot<NS>(w, Nout, C, NT, transposed, wscale, T, wp, i);
 }
 
 static int wprep_launch(int math, const float* w, int Nout, int C, int transposed, float wscale, int T, unsigned short* wp, hipStream_t s) {
@@ -595,6 +568,17 @@ static int wprep_launch(int math, const float* w, int Nout, int C, int transpose
 
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s) {
   return wprep_launch(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, s);
+}
+static void fill_job3(int math, const float* w, int Nout, int C, int transposed, float wscale, int T, unsigned short* wp, WprepJob* j) {
+  j->w = w; j->wp = wp; j->Nout = Nout; j->C = C; j->NT = (Nout + 31) / 32; j->transposed = transposed; j->T = T;
+  j->ns = math < 1 ? 3 : (math > 4 ? 3 : math); j->wscale = wscale;
+  j->nblocks = (int)(((size_t)(C >> 5) * 2 * T * j->NT * 64 + 255) / 256);
+}
+void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j) {
+  fill_job3(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, j);
+}
+void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, WprepJob* j) {
+  fill_job3(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain) * PASCALE, 1, wp, j);
 }
 
 // weights of a 1x1 skip convolution [Nout][Cs] for the skip chunks of a 3x3 launch whose main input has Cmain channels: same plane

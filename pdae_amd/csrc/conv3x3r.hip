@@ -511,9 +511,10 @@ bool conv3x3r_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws,
   if (r_mode() == 2) return true;
   const long long tiles = (long long)N * (H / RTH) * (W / PTW) * (Nout / RBN);
   const long long rounds = (tiles + 255) / 256;
-  static int min_tiles = -1;                                  // PDAE_P3R_MIN: tuning aid
+  static int min_tiles = -1, min_eff = -1;                    // PDAE_P3R_MIN / PDAE_P3R_EFF: tuning aids
   if (min_tiles < 0) { const char* e = getenv("PDAE_P3R_MIN"); min_tiles = e ? atoi(e) : 512; }
-  return tiles >= min_tiles && tiles * 100 >= rounds * 256 * 85;   // at least two tiles per CU (something to overlap), last round >= 85 % full
+  if (min_eff < 0) { const char* e = getenv("PDAE_P3R_EFF"); min_eff = e ? atoi(e) : 85; }
+  return tiles >= min_tiles && tiles * 100 >= rounds * 256 * min_eff;   // at least two tiles per CU (something to overlap), last round >= 85 % full
 }
 
 int conv3x3r_launch(int math, const PatchParams& P0, hipStream_t s) {

@@ -511,8 +511,15 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H,
                                                            const float* __restrict__ c12, const float* __restrict__ dA, int act, int mode,
                                                            float drop_p, unsigned long long seed, unsigned long long offset,
                                                            const float* __restrict__ add, float* __restrict__ dx0, int acc0,
-                                                           float* __restrict__ dx1, int acc1, unsigned* __restrict__ amax0) {
+                                                           float* __restrict__ dx1, int acc1, unsigned* __restrict__ amax0,
+                                                           const float* __restrict__ pgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_param) {
   __shared__ float wmax[4];
+  // the gamma / beta gradients (sum over samples of the finalize kernel's per-sample contributions) ride in this launch: the blocks of
+  // sample 0 take 256 channels each first -- one launch less per GroupNorm backward (53 per FFHQ-128 step)
+  if (dgamma && blockIdx.y == 0 && (int)(blockIdx.x * 256) < C) {
+    const int cpar = blockIdx.x * 256 + threadIdx.x;
+    if (cpar < C) gn_bwd_param_one(cpar, N, C, pgb, dgamma, dbeta, acc_param);
+  }
   const int n = blockIdx.y, NQ = C >> 2, PL = 256 / NQ, HW = H * W;
   const int t = threadIdx.x, q = t % NQ, pl = t / NQ, c = q * 4;
   float* dbase = nullptr; int accf = 0, Cd = 0, cd = 0;
@@ -677,14 +684,16 @@ int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int
   } else {
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am);
-    if (dgamma)
-      hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, N, C, pgb, dgamma, dbeta, acc_param);
   }
+  int Sa = stream_chunks(HW, C), chunk_a = cdiv(HW, Sa);
+  Sa = cdiv(HW, chunk_a);
+  // parameter gradients: inside the apply launch when it has enough blocks per sample to cover C in slices of 256, else their own launch
+  const bool ride = !ticket && dgamma && (dx0 || dx1) && Sa * 256 >= C;
+  if (!ticket && dgamma && !ride)
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, N, C, pgb, dgamma, dbeta, acc_param);
   if (dx0 || dx1) {
-    int Sa = stream_chunks(HW, C), chunk_a = cdiv(HW, Sa);
-    Sa = cdiv(HW, chunk_a);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(Sa, N), dim3(256), 0, st, s, N, H, W, C, chunk_a, coef, c12, dA, act, mode, drop_p, seed, offset,
-                       add, dx0, acc0, dx1, acc1, am);
+                       add, dx0, acc0, dx1, acc1, am, pgb, ride ? dgamma : nullptr, dbeta, acc_param);
   }
   return pdae_launch_status("gn_bwd");
 }

@@ -40,6 +40,8 @@ class Plan:
         self.watch = []         # modules whose _frozen_version gates a re-run of the init ops
         self.seen = None
         self._tickets = None    # zeroed uint32 words for the "last block finishes" GroupNorm kernels (one stream runs a plan: shared by all its ops)
+        self.wprep_jobs = []    # prepared copies of TRAINABLE conv weights: refreshed by ONE grouped launch at the head of every run (compile)
+        self.pre_arr = None
 
     def tickets(self, n):
         """>= n + 1 zero-initialised ticket words (pdae_gn_stats_coef / pdae_gn_bwd) with PDAE_GN_TICKETS=1, else None (default).
@@ -101,6 +103,10 @@ class Plan:
         self.arr = H.ops_array(self.recs)
         self.n = len(self.recs)
         self.init_arr = H.ops_array(self.init_recs) if self.init_recs else None
+        if self.wprep_jobs:
+            jt, ft, tot = H.wprep_group_tables(self.wprep_jobs, self.device)
+            self.live.extend([jt, ft])
+            self.pre_arr = H.ops_array([H.op_conv_wprep_group(jt, ft, len(self.wprep_jobs), tot)])
         for idx, ws_slot, wsb_slot in self.ws_patch:
             self.arr[idx].p[ws_slot] = self.ws.data_ptr()
             if wsb_slot is not None:
@@ -117,6 +123,8 @@ class Plan:
             if cur != self.seen:
                 H.run_ops(self.init_arr, len(self.init_recs), stream)
                 self.seen = cur
+        if first == 0 and self.pre_arr is not None:    # the trainable weights may have changed since the last run: all prepared copies, one launch
+            H.run_ops(self.pre_arr, 1, stream)
         if os.environ.get("PDAE_DEBUG_SYNC"):          # one op at a time, synchronised, index printed first
             import sys
             for k in range(first, last):
@@ -167,6 +175,7 @@ class Builder:
         self.fuse_stats = os.environ.get("PDAE_FUSE_GN_STATS", "1") != "0"
         self._ystats = {}         # id(tensor) -> (tensor, partial sums, wave-tiles per image)
         self.fuse_attn = os.environ.get("PDAE_FUSE_ATTN", "1") != "0"  # QK^T -> softmax -> PV (and its backward) as one kernel (pdae_attn_fwd / _bwd)
+        self.group_wprep = os.environ.get("PDAE_GROUP_WPREP", "1") != "0"   # prepared copies of trainable weights: one grouped launch per run (Plan.pre_arr)
         self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
         self._frozen_wp = {}
         self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
@@ -247,6 +256,13 @@ class Builder:
                 self.p.bytes_alloc += wp.numel() * 4
                 self.p.emit_init(H.op_conv_wprep(c, w, transposed, wp), self.frozen_of)
                 self._frozen_wp[key] = wp
+            return NoFree(wp)
+        if self.group_wprep and self.p.device.type == "cuda":
+            # persistent copy, refreshed at the head of every plan run together with all others (they change once per optimizer step)
+            wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)
+            self.p.live.append(wp)
+            self.p.bytes_alloc += wp.numel() * 4
+            self.p.wprep_jobs.append(H.wprep_job(c, w, transposed, wp))
             return NoFree(wp)
         wp = self.p.buf((nbytes + 3) // 4)
         self.p.emit(H.op_conv_wprep(c, w, transposed, wp))
@@ -419,6 +435,12 @@ class Builder:
                 self.p.bytes_alloc += wps.numel() * 4
                 self.p.emit_init(H.op_conv_skip_wprep(c, cs, ws, wps), self.frozen_of)
                 self._frozen_wp[key] = wps
+            wps = NoFree(wps)
+        elif self.group_wprep and self.p.device.type == "cuda":
+            wps = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)
+            self.p.live.append(wps)
+            self.p.bytes_alloc += wps.numel() * 4
+            self.p.wprep_jobs.append(H.skip_wprep_job(c, cs, ws, wps))
             wps = NoFree(wps)
         else:
             wps = self.p.buf((nbytes + 3) // 4)

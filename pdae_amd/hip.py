@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PDAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpdae
 (OP_CONV_FWD, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_GEMM, OP_GN_STATS, OP_GN_COEF, OP_GN_APPLY, OP_GN_BWD, OP_TEMB, OP_SILU,
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
  OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX,
- OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD, OP_LINEAR_BWD_GROUP, OP_GN_COEF_FROM_CONV_STATS) = range(1, 43)
+ OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD, OP_LINEAR_BWD_GROUP, OP_GN_COEF_FROM_CONV_STATS, OP_CONV_WPREP_GROUP) = range(1, 44)
 
 
 class PdaeOp(ctypes.Structure):
@@ -103,7 +103,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_bwd_group", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
@@ -300,6 +300,47 @@ def op_amax(x, n, out):
 def op_conv_wprep(c, w, transposed, wp):
     """Pre-split w into the MFMA-fragment-ordered bf16 planes the patch kernel reads (pdae_conv_wprep)."""
     return make_op(OP_CONV_WPREP, [w, wp], c.fields() + [transposed])
+
+
+class WprepJob(ctypes.Structure):
+    """pdae_wprep_job (include/pdae_hip.h): one prepared-weight copy of the grouped launch."""
+    _fields_ = [("w", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("Nout", ctypes.c_int32), ("C", ctypes.c_int32), ("NT", ctypes.c_int32),
+                ("transposed", ctypes.c_int32), ("T", ctypes.c_int32), ("ns", ctypes.c_int32), ("wscale", ctypes.c_float), ("nblocks", ctypes.c_int32)]
+
+
+def wprep_job(c, w, flags, wp):
+    """Job record of pdae_conv_wprep(c, w, flags, wp) for the grouped launch (pdae_conv_wprep_job: filled by the library, nothing runs)."""
+    d, j = c.cdesc(), WprepJob()
+    rc = lib().pdae_conv_wprep_job(ctypes.byref(d), ctypes.c_void_p(_ptr(w)), int(flags), ctypes.c_void_p(_ptr(wp)), ctypes.byref(j))
+    if rc != 0:
+        raise PdaeError(f"pdae_conv_wprep_job failed ({rc}): {lib().pdae_last_error().decode()}")
+    return j
+
+
+def skip_wprep_job(c, cs, w_skip, wps):
+    d, ds, j = c.cdesc(), cs.cdesc(), WprepJob()
+    rc = lib().pdae_conv_skip_wprep_job(ctypes.byref(d), ctypes.byref(ds), ctypes.c_void_p(_ptr(w_skip)), ctypes.c_void_p(_ptr(wps)), ctypes.byref(j))
+    if rc != 0:
+        raise PdaeError(f"pdae_conv_skip_wprep_job failed ({rc}): {lib().pdae_last_error().decode()}")
+    return j
+
+
+def wprep_group_tables(jobs, device):
+    """(job table, prefix table, total blocks) on `device` for op_conv_wprep_group."""
+    import torch
+    raw = b"".join(bytes(j) for j in jobs)
+    first, tot = [], 0
+    for j in jobs:
+        first.append(tot)
+        tot += int(j.nblocks)
+    jt = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    ft = torch.tensor(first, dtype=torch.int32).to(device)
+    return jt, ft, tot
+
+
+def op_conv_wprep_group(jobs_t, first_t, njobs, total_blocks):
+    """Every prepared-weight copy of a plan in one launch (pdae_conv_wprep_group)."""
+    return make_op(OP_CONV_WPREP_GROUP, [jobs_t, first_t], [njobs, total_blocks])
 
 
 def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0, db=None, dy_amax=None):

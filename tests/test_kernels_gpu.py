@@ -788,3 +788,43 @@ def test_grouped_linear_forward_and_backward(H):
         assert rel_err(dW[i], ref_w) < 1e-6 and rel_err(db[i], ref_b) < 1e-6, i
     assert rel_err(dxa, dys[0].double() @ Ws[0].double() + 2.0) < 1e-6
     assert rel_err(dxb, dys[2].double() @ Ws[2].double()) < 1e-6
+
+
+def test_grouped_weight_preparation_equals_the_single_launches(H):
+    """pdae_conv_wprep_group: every prepared-weight form the engine uses (3x3 forward, fused-GroupNorm two-source, data-gradient in the exact
+    and the fp16-gradient format, 1x1 forward / data gradient, fused skip chunks; bf16 and split formats) written by ONE launch from a job
+    table equals, bit for bit, what pdae_conv_wprep / pdae_conv_skip_wprep write one launch at a time."""
+    jobs, singles, keep = [], [], []                # a job holds raw pointers: the weights must outlive the grouped launch
+
+    def add(c, w, flags, nbytes):
+        keep.append(w)
+        a = torch.full((nbytes // 4,), float("nan"), device="cuda"); b = torch.full((nbytes // 4,), float("nan"), device="cuda")
+        H.run(H.op_conv_wprep(c, w, flags, a))
+        jobs.append(H.wprep_job(c, w, flags, b)); singles.append((a, b))
+
+    for math_mode in (4, 1, 3):
+        c3 = H.Conv(2, 16, 16, 64, 0, 96, k=3, math=math_mode)
+        w3 = (rn(1, 96, 3, 3, 64) * 0.05).cuda()
+        add(c3, w3, 0, c3.wprep_bytes(0, force=True))
+        add(c3, w3, 1, c3.wprep_bytes(1, force=True))
+        if math_mode == 4:
+            add(c3, w3, 1 | 16, c3.wprep_bytes(1, force=True, f16_grad=True))
+        cg = H.Conv(2, 16, 16, 32, 32, 96, k=3, math=math_mode)
+        add(cg, w3, 4, cg.wprep_bytes(0, force=True, gn=True))
+        c1 = H.Conv(3, 16, 16, 128, 64, 96, k=1, math=math_mode)
+        w1 = (rn(2, 96, 1, 1, 192) * 0.05).cuda()
+        add(c1, w1, 0, c1.wprep_bytes(0, force=True))
+        add(c1, w1, 1, c1.wprep_bytes(1, force=True))
+    c = H.Conv(16, 64, 32, 64, 0, 128, k=3, math=4); cs = H.Conv(16, 64, 32, 64, 32, 128, k=1, math=4)
+    assert H.conv_fwd_skip_ok(c, cs)
+    wsk = (rn(3, 128, 1, 1, 96) * 0.05).cuda()
+    nb = H.conv_skip_wprep_bytes(c, cs)
+    a = torch.full((nb // 4,), float("nan"), device="cuda"); b = torch.full((nb // 4,), float("nan"), device="cuda")
+    H.run(H.op_conv_skip_wprep(c, cs, wsk, a))
+    jobs.append(H.skip_wprep_job(c, cs, wsk, b)); singles.append((a, b))
+    jt, ft, tot = H.wprep_group_tables(jobs, "cuda")
+    H.run(H.op_conv_wprep_group(jt, ft, len(jobs), tot))
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(singles):
+        fin = torch.isfinite(a)                     # split-K slab space behind the planes is not written by a preparation
+        assert torch.equal(a[fin].view(torch.int32), b[fin].view(torch.int32)) and torch.equal(fin, torch.isfinite(b)), k
