@@ -326,17 +326,17 @@ extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const
   if (conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout)) {
     float* part = nullptr; int rows = 0;                                  // bias gradient: column sums of dY fall out of the dY staging
     if (int e = conv3x3w_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, dy, d->Cout, dw, accumulate, (float*)ws, wsb, S(stream),
-                                db ? &part : nullptr, db ? &rows : nullptr, dy_amax))
+                                db ? &part : nullptr, db ? &rows : nullptr, dy_amax, db))
       return e;
-    return db ? k_colsum(part, rows, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;
+    return (db && part) ? k_colsum(part, rows, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;      // part == NULL: summed inside the reduce launch
   }
   // three-plane formats do not fit the two-operand LDS tiles of the 1x1 kernel: math 3, and math 4 without a dY scale, stay on the generic kernel
   if (conv1x1w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->up, d->C0, d->C1, Mpix, d->Cout) && d->math != 3 && (d->math != 4 || dy_amax)) {
     float* part = nullptr; int rows = 0;
     if (int e = conv1x1w_launch(d->math, x0, d->C0, x1, d->C1, Mpix, dy, d->Cout, dw, accumulate, (float*)ws, wsb, S(stream), db ? &part : nullptr,
-                                db ? &rows : nullptr, dy_amax))
+                                db ? &rows : nullptr, dy_amax, db))
       return e;
-    return db ? k_colsum(part, rows, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;
+    return (db && part) ? k_colsum(part, rows, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;
   }
   int tile, splits, kchunk;
   wgrad_plan(d, tile, splits, kchunk);

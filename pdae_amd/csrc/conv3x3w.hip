@@ -415,7 +415,7 @@ template <int NS, bool W8 = false> static int launch_w(const WgradParams& P, hip
 }
 
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
-                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax) {
+                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax, float* db) {
   WgradParams P;
   P.dy_amax = dy_amax; P.sat = pdae_sat_counter();
   static const int stagger = [] { const char* e = getenv("PDAE_W3_STAGGER"); return e ? atoi(e) : 0; }();      // off by default: measured +-0 (the kernel is power-bound, not phase-bound)
@@ -434,7 +434,9 @@ int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (w8) e = math == 1 ? launch_w<1, true>(P, s) : (math == 2 ? launch_w<2, true>(P, s) : (math == 4 ? launch_w<4, true>(P, s) : launch_w<3, true>(P, s)));
   else e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : (math == 4 ? launch_w<4>(P, s) : launch_w<3>(P, s)));
   if (e) return e;
-  return igemm_splitk_reduce(ws, dw, (long long)Cout * 9 * C, P.splits, accumulate, s);
+  // the bias gradient's final sum rides in the reduce launch when the caller gave its destination (db_part is then reported as consumed)
+  if (db_part && db) *db_part = nullptr;
+  return igemm_splitk_reduce(ws, dw, (long long)Cout * 9 * C, P.splits, accumulate, s, db ? P.db_part : nullptr, P.splits, Cout, db);
 }
 
 
@@ -656,7 +658,7 @@ template <int NS> static int launch_w1(const Wgrad1Params& P, hipStream_t s) {
 }
 
 int conv1x1w_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const float* dy, int Cout, float* dw, int accumulate,
-                    float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax) {
+                    float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax, float* db) {
   Wgrad1Params P;
   P.dy_amax = dy_amax; P.sat = pdae_sat_counter();
   if (math == 4 && !dy_amax) math = 3;
@@ -670,5 +672,6 @@ int conv1x1w_launch(int math, const float* x0, int C0, const float* x1, int C1, 
   if (!ws || ws_bytes < need) { pdae_set_error("conv1x1w: workspace too small (%zu < %zu)", ws_bytes, need); return PDAE_EINVAL; }
   int e = math == 1 ? launch_w1<1>(P, s) : (math == 2 ? launch_w1<2>(P, s) : (math == 4 ? launch_w1<4>(P, s) : launch_w1<3>(P, s)));
   if (e) return e;
-  return igemm_splitk_reduce(ws, dw, (long long)Cout * P.C, P.splits, accumulate, s);
+  if (db_part && db) *db_part = nullptr;
+  return igemm_splitk_reduce(ws, dw, (long long)Cout * P.C, P.splits, accumulate, s, db ? P.db_part : nullptr, P.splits, Cout, db);
 }

@@ -46,7 +46,9 @@ struct GemmParams {
 int igemm_conv_fwd(const GemmParams& P, int tile, int math, hipStream_t s);
 int igemm_conv_dgrad(const GemmParams& P, int tile, int math, hipStream_t s);
 int igemm_conv_wgrad(const GemmParams& P, int tile, int splits, int math, hipStream_t s);
-int igemm_splitk_reduce(const float* ws, float* out, long long n, int splits, int accumulate, hipStream_t s);
+// db_part / db: optional bias-gradient partial rows [db_rows][C] summed into db[C] (same accumulate flag) by extra blocks of the same launch
+int igemm_splitk_reduce(const float* ws, float* out, long long n, int splits, int accumulate, hipStream_t s, const float* db_part = nullptr,
+                        int db_rows = 0, int C = 0, float* db = nullptr);
 int igemm_dense(int transA, int transB, const GemmParams& P, int zdim, hipStream_t s);
 
 // conv3x3p.hip: 3x3 stride-1 "patch" kernel on the bf16 MFMA pipe (math modes 1..3)
@@ -70,7 +72,7 @@ bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, i
 size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout);
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
                     int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part = nullptr, int* db_rows = nullptr,
-                    const float* dy_amax = nullptr);
+                    const float* dy_amax = nullptr, float* db = nullptr);
 
 // conv1x1.hip: 1x1 convolution (forward / data gradient) on prepared weights, activations staged through LDS
 bool conv1x1_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, int C1, int Nout);
@@ -85,7 +87,7 @@ int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, l
 bool conv1x1w_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, int C1, long long M, int Cout);
 size_t conv1x1w_workspace_bytes(long long M, int C, int Cout);
 int conv1x1w_launch(int math, const float* x0, int C0, const float* x1, int C1, long long M, const float* dy, int Cout, float* dw, int accumulate,
-                    float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax);
+                    float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax, float* db = nullptr);
 int linear_bwd_group_launch(const void* items, const int* first, int n_items, int total_blocks, int M, int K, hipStream_t s);
 int skinny_group_launch(const void* items, const int* first, int n_items, int total, int M, int K, hipStream_t s);
 bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch);

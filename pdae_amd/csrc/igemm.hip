@@ -540,8 +540,32 @@ __global__ void __launch_bounds__(256) igemm_bf_kernel(const GemmParams P) {
 }
 
 // sums split-K slabs: out[i] = (acc ? out[i] : 0) + sum_s ws[s*n + i]   (fixed order => deterministic)
+// Blocks behind the first `nmain` finish the bias gradient that rode in the weight-gradient launch: db[c] (+)= sum over `rows` partial rows
+// (16 columns x 16 lanes per block, fixed order) -- it used to be a launch of its own behind every weight gradient (76 per FFHQ-128 step)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long long n,
-                                                             int splits, int accumulate) {
+                                                             int splits, int accumulate, int nmain, const float* __restrict__ dbp, int rows, int C,
+                                                             float* __restrict__ db) {
+  if ((int)blockIdx.x >= nmain) {
+    __shared__ float red[256];
+    const int t = threadIdx.x, cl = t & 15, lane = t >> 4;
+    const int c = ((int)blockIdx.x - nmain) * 16 + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+      int b = lane;
+      for (; b + 48 < rows; b += 64) {
+        a0 += dbp[(size_t)b * C + c]; a1 += dbp[(size_t)(b + 16) * C + c]; a2 += dbp[(size_t)(b + 32) * C + c]; a3 += dbp[(size_t)(b + 48) * C + c];
+      }
+      for (; b < rows; b += 16) a0 += dbp[(size_t)b * C + c];
+    }
+    red[t] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (lane == 0 && c < C) {
+      float s = 0.f;
+      for (int l = 0; l < 16; ++l) s += red[l * 16 + cl];
+      db[c] = accumulate ? db[c] + s : s;
+    }
+    return;
+  }
   long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
   if (i4 + 3 < n) {
@@ -644,8 +668,10 @@ int igemm_conv_wgrad(const GemmParams& P, int tile, int splits, int math, hipStr
   return launch_tiles<OP_DENSE_OC, false, OP_GATHER_OC, false>(tile, P, splits, s);
 }
 
-int igemm_splitk_reduce(const float* ws, float* out, long long n, int splits, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, s, ws, out, n, splits, accumulate);
+int igemm_splitk_reduce(const float* ws, float* out, long long n, int splits, int accumulate, hipStream_t s, const float* db_part, int db_rows,
+                        int C, float* db) {
+  const int nmain = cdiv(n, 1024), nextra = (db_part && db) ? cdiv(C, 16) : 0;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nmain + nextra), dim3(256), 0, s, ws, out, n, splits, accumulate, nmain, db_part, db_rows, C, db);
   return pdae_launch_status("splitk_reduce");
 }
 
