@@ -48,10 +48,16 @@ def _conv(x, sd, pre, stride=1):
     return F.conv2d(x, w, sd[pre + ".bias"], stride=stride, padding=w.shape[-1] // 2)
 
 
+# Dropout (module.py:263, nn.Dropout between SiLU and the second conv of out_layers): RNG streams cannot match across devices, so parity of
+# the dropout-ON path is defined for INJECTED masks: DROP_MASKS maps a ResBlock prefix to (keep mask [N,C,H,W] of 0/1, p) -- the masks the
+# device path actually drew -- and the block computes silu(h) * mask / (1 - p) like nn.Dropout in training mode.  Empty: identity (p = 0 / eval).
+DROP_MASKS = {}
+
+
 def resblock(sd, pre, x, emb, emb_z=None, up=False, down=False):
     """model/module.py:278-297 (ResBlock.forward) and :361-384 (ResBlockShift.forward).
 
-    Dropout is identity here (parity is defined at p=0 / eval)."""
+    Dropout is identity (parity is defined at p=0 / eval) unless a keep mask was injected for this block (DROP_MASKS)."""
     h = F.silu(_gn(x, sd, pre + ".in_layers.0"))
     if up:          # module.py:279-284: resample between GN-SiLU and the conv, and the skip too
         h = F.interpolate(h, scale_factor=2, mode="nearest")
@@ -67,7 +73,11 @@ def resblock(sd, pre, x, emb, emb_z=None, up=False, down=False):
         ez = F.linear(F.silu(emb_z), sd[pre + ".emb_z_layers.1.weight"], sd[pre + ".emb_z_layers.1.bias"])
         z_scale, z_shift = torch.chunk(ez[:, :, None, None], 2, dim=1)
         h = (1.0 + z_scale) * h + z_shift
-    h = _conv(F.silu(h), sd, pre + ".out_layers.3")
+    h = F.silu(h)
+    if pre in DROP_MASKS:
+        keep, p_drop = DROP_MASKS[pre]
+        h = h * keep / (1.0 - p_drop)
+    h = _conv(h, sd, pre + ".out_layers.3")
     if pre + ".skip_connection.weight" in sd:
         x = _conv(x, sd, pre + ".skip_connection")
     return x + h

@@ -268,6 +268,7 @@ class FusedRLStep(_FusedStep):
                          scale=1.0 / self.num_iterations), ws_slot=9)
         self.n_fwd = len(p.recs)
         self.z, self.eps, self.shift = z, fx.eps, fx.shift
+        self.fx = fx                                      # graph context (saved activations of the shift branch): inspection / tests
         # ---- backward, with the op index at which each parameter block's gradients are final
         dz = G.shift_backward(Bd, fx, d_shift, mark=lambda prefix: self._marks.append((len(p.recs), decoder, prefix)))
         G.encoder_backward(Be, ex, dz, mark=lambda prefix: self._marks.append((len(p.recs), encoder, prefix)))

@@ -21,7 +21,9 @@ from oracle import pdae_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-BF16_TOL = dict(out=5e-2, loss=3e-2, grad=1e-1)       # enable_amp: bf16 operands (2^-9 per product), fp32 accumulate -- vs the fp32-grade path
+# enable_amp: bf16 operands (2^-9 per product), fp32 accumulate -- vs the fp32-grade path.  Measured on MI355X (round 3):
+# eps 7.2e-3, shift 9.1e-3, z 5.0e-3, loss 4.8e-4, worst gradient-norm error 1.3e-2; the gates sit ~3x above so that a regression shows
+BF16_TOL = dict(out=2.5e-2, loss=3e-3, grad=4e-2)
 
 
 def _yaml(path):
@@ -281,3 +283,39 @@ def test_latent_ffhq_yaml_full_topology_step_vs_oracle(gd):
         solid = gr.abs() > 1e-3 * gr.abs().max()
         assert float(diff[solid].max() if solid.any() else 0.0) < 2e-5 and float(diff.max()) < 2.1 * opt["lr"], (k, float(diff.max()))
     assert not torch.equal(ema.flat_train, net.flat_train)
+
+
+def test_f128_train_step_with_dropout_on_vs_oracle_with_the_device_masks(gd):
+    """The benchmark runs with the config's dropout 0.1 while every other parity test switches it off (RNG streams cannot match across
+    devices).  Here the F128 step runs WITH dropout, the keep masks the device drew (Philox2x32 inside gn_apply, regenerated inside
+    gn_bwd) are read back from the saved activations -- a2 = dropout(silu(.)) is zero exactly where an element was dropped -- and injected
+    into the oracle (oracle.DROP_MASKS): loss 1e-4, every trainable gradient 1e-3 in norm.  Pins, at real size, the dropout variants of
+    gn_apply / gn_bwd (same mask in forward and backward, 1/(1-p) scaling) that the speed number exercises."""
+    c, dcfg0, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml", seed_enc=3, seed_dec=5)
+    from pdae_amd.model.representation_learning import decoder as decoder_module
+    p_drop = 0.1
+    dcfg = dict(dcfg0, dropout=p_drop)
+    dec = getattr(decoder_module, c["decoder_config"]["model"])(device=DEV, latent_dim=c["decoder_config"]["latent_dim"], **dcfg)
+    dec.load_state_dict(dec_sd)
+    dec.set_train_mode()
+    x0, t, noise = _batch(2, 3, 128, seed=6)
+    _guard().reset()
+    st, got = _run_rl(gd, enc, dec, 2, 128, x0, t, noise)
+    assert _guard().read()[0] == 0 and len(st.plan.drop_ops) > 0
+    masks = {}
+    for blocks in [st.fx.smid_ctx] + list(st.fx.sout_ctx):
+        for kind, ctx in blocks:
+            if kind == "res":
+                a2 = ctx.g2.y
+                keep = (a2 != 0).permute(0, 3, 1, 2).float().cpu()
+                assert abs(float(keep.mean()) - (1 - p_drop)) < 0.01, (ctx.pre, float(keep.mean()))
+                masks[ctx.pre] = (keep, p_drop)
+    assert len(masks) >= 10
+    O.DROP_MASKS.clear(); O.DROP_MASKS.update(masks)
+    try:
+        z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg0, x0, t, noise)
+    finally:
+        O.DROP_MASKS.clear()
+    assert rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
+    assert abs(got["loss"] - loss) < 1e-4 * abs(loss), (got["loss"], loss)
+    _check_grads(got["grads"], grads, 1e-3)
