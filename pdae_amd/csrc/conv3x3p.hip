@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
   const unsigned lane_d = (unsigned)(((er >> 2) * P.W + (er & 3)) * P.Nout + colc);
   const unsigned lane_d2 = (unsigned)(((er & 3) >> 1) * P.Nout + colc);          // half-resolution residual: pixel (0, (er & 3) >> 1) of the 1 x 2 sub-block
   const size_t row_pair = (size_t)2 * P.W * P.Nout;                                // two output rows
-  const bool want_stat = P.stat_part != nullptr;                                   // wave-uniform
+  const bool want_stat = P.stat_part != nullptr && P.splits == 1;                                  // wave-uniform
   float st1 = 0.f, st2 = 0.f;                                                      // this lane's share of the wave's output statistics
   // the eight lanes that hold the same channel quad (er = lane >> 3) combine; lane er == 0 writes.  Wave-tile index inside its image:
   // ((ty, tx), 128-pixel half wm); the image-pair form flushes after each image of the pair.
@@ -370,41 +370,77 @@ __global__ void __launch_bounds__(PTH * 32, 2) conv3x3p_kernel(const PatchParams
 }
 
 // y = sum of the split slabs (fixed order) + bias + residual (+ y)
+// one output float4 of a split-K launch: slabs summed in slab order, then the epilogue of the unsplit kernel (bias, residual, accumulate)
+__device__ __forceinline__ float4 reduce_one(const PatchParams& P, long long Mtot, long long row, int col) {
+  float4 v = *reinterpret_cast<const float4*>(P.slab + row * P.Nout + col);
+  const float* sl = P.slab + row * P.Nout + col; const long long ss = Mtot * P.Nout;
+  int k = 1;                                  // four slabs in flight, added in slab order (see splitk_reduce_kernel)
+  for (; k + 4 <= P.splits; k += 4) {
+    const float4 u0 = *reinterpret_cast<const float4*>(sl + k * ss), u1 = *reinterpret_cast<const float4*>(sl + (k + 1) * ss);
+    const float4 u2 = *reinterpret_cast<const float4*>(sl + (k + 2) * ss), u3 = *reinterpret_cast<const float4*>(sl + (k + 3) * ss);
+    v.x += u0.x; v.y += u0.y; v.z += u0.z; v.w += u0.w;
+    v.x += u1.x; v.y += u1.y; v.z += u1.z; v.w += u1.w;
+    v.x += u2.x; v.y += u2.y; v.z += u2.z; v.w += u2.w;
+    v.x += u3.x; v.y += u3.y; v.z += u3.z; v.w += u3.w;
+  }
+  for (; k < P.splits; ++k) {
+    const float4 u = *reinterpret_cast<const float4*>(sl + k * ss);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  if (P.bias) { const float4 u = *reinterpret_cast<const float4*>(P.bias + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+  if (P.bias_x) { const float4 u = *reinterpret_cast<const float4*>(P.bias_x + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+  if (P.res_mode) {
+    long long rrow = row;
+    if (P.res_mode == 2) {
+      const int ox = (int)(row % P.W); const long long t2 = row / P.W; const int oy = (int)(t2 % P.H); const long long im = t2 / P.H;
+      rrow = (im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
+    }
+    const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  float4* dst = reinterpret_cast<float4*>(P.y + row * P.Nout + col);
+  if (P.accumulate) { const float4 u = *dst; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+  *dst = v;
+  return v;
+}
+
 __global__ void __launch_bounds__(256) conv3x3p_reduce_kernel(const PatchParams P) {
   const int n4 = P.Nout >> 2;
   const long long Mtot = (long long)P.N * P.H * P.W, total = Mtot * n4;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long row = i / n4; const int col = (int)(i - row * n4) * 4;
-    float4 v = *reinterpret_cast<const float4*>(P.slab + row * P.Nout + col);
-    const float* sl = P.slab + row * P.Nout + col; const long long ss = Mtot * P.Nout;
-    int k = 1;                                  // four slabs in flight, added in slab order (see splitk_reduce_kernel)
-    for (; k + 4 <= P.splits; k += 4) {
-      const float4 u0 = *reinterpret_cast<const float4*>(sl + k * ss), u1 = *reinterpret_cast<const float4*>(sl + (k + 1) * ss);
-      const float4 u2 = *reinterpret_cast<const float4*>(sl + (k + 2) * ss), u3 = *reinterpret_cast<const float4*>(sl + (k + 3) * ss);
-      v.x += u0.x; v.y += u0.y; v.z += u0.z; v.w += u0.w;
-      v.x += u1.x; v.y += u1.y; v.z += u1.z; v.w += u1.w;
-      v.x += u2.x; v.y += u2.y; v.z += u2.z; v.w += u2.w;
-      v.x += u3.x; v.y += u3.y; v.z += u3.z; v.w += u3.w;
-    }
-    for (; k < P.splits; ++k) {
-      const float4 u = *reinterpret_cast<const float4*>(sl + k * ss);
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
-    if (P.bias) { const float4 u = *reinterpret_cast<const float4*>(P.bias + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-    if (P.bias_x) { const float4 u = *reinterpret_cast<const float4*>(P.bias_x + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-    if (P.res_mode) {
-      long long rrow = row;
-      if (P.res_mode == 2) {
-        const int ox = (int)(row % P.W); const long long t2 = row / P.W; const int oy = (int)(t2 % P.H); const long long im = t2 / P.H;
-        rrow = (im * (P.H >> 1) + (oy >> 1)) * (P.W >> 1) + (ox >> 1);
-      }
-      const float4 u = *reinterpret_cast<const float4*>(P.res + rrow * P.Nout + col); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
-    float4* dst = reinterpret_cast<float4*>(P.y + row * P.Nout + col);
-    if (P.accumulate) { const float4 u = *dst; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-    *dst = v;
+    reduce_one(P, Mtot, row, col);
   }
 }
+
+// The same reduction, leaving the GroupNorm partial statistics of the stored tensor behind like the unsplit kernel does: block = (image, run of
+// tp pixels), threads = channel quads x pixel lanes; stat_part[image][stat_tpi runs][Nout / 4] x (sum, sum of squares) over tp pixels x 4
+// channels, unshifted fp32 (at most 64 values each), combined in fp64 by pdae_gn_coef_from_conv_stats.  The split layers are the small ones
+// (8^2 .. 32^2): a statistics pass over their output cost a launch of its own plus a finalize launch -- 10 + 5 us, ~70 times per step.
+__global__ void __launch_bounds__(256) conv3x3p_reduce_stats_kernel(const PatchParams P, int tp) {
+  __shared__ float2 red[256];
+  const int NQ = P.Nout >> 2, PL = 256 / NQ, HW = P.H * P.W, t = threadIdx.x, q = t % NQ, pl = t / NQ;
+  const int n = blockIdx.x / P.stat_tpi, run = blockIdx.x - n * P.stat_tpi;
+  const long long Mtot = (long long)P.N * HW;
+  const int p1 = min(HW, (run + 1) * tp);
+  float s1 = 0.f, s2 = 0.f;
+  if (pl < PL) {
+    for (int p = run * tp + pl; p < p1; p += PL) {
+      const float4 v = reduce_one(P, Mtot, (long long)n * HW + p, q * 4);
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    red[pl * NQ + q] = make_float2(s1, s2);
+  }
+  __syncthreads();
+  if (t < NQ) {
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < PL; ++l) { const float2 v = red[l * NQ + t]; a += v.x; b += v.y; }
+    reinterpret_cast<float2*>(P.stat_part)[((size_t)n * P.stat_tpi + run) * NQ + t] = make_float2(a, b);
+  }
+}
+
+// pixels per block of conv3x3p_reduce_stats_kernel: 16, or 8 when 16 would leave the chip half empty
+static int reduce_stats_tp(int N, int HW) { return (long long)N * ((HW + 15) / 16) >= 512 ? 16 : 8; }
 
 template <int NS, int PTH, bool W8, bool GN = false> static int launch_ns(const PatchParams& P, hipStream_t s) {
   constexpr int NPIX = (PTH + 2) * PPW;
@@ -423,7 +459,8 @@ template <int NS, int PTH, bool W8, bool GN = false> static int launch_ns(const 
   if (P.splits > 1) {
     const long long total = (long long)P.N * P.H * P.W * (P.Nout >> 2);
     long long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(conv3x3p_reduce_kernel, dim3((int)nb), dim3(256), 0, s, P);
+    if (P.stat_part) hipLaunchKernelGGL(conv3x3p_reduce_stats_kernel, dim3(P.N * P.stat_tpi), dim3(256), 0, s, P, reduce_stats_tp(P.N, P.H * P.W));
+    else hipLaunchKernelGGL(conv3x3p_reduce_kernel, dim3((int)nb), dim3(256), 0, s, P);
   }
   return pdae_launch_status("conv3x3p");
 }
@@ -507,8 +544,9 @@ size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip
   if (Nout & 3) return 0;
   PatchPlan q = patch_plan(C + 32 * fused_skip_chunks, H, W, N, Nout);
   if (fused_skip_chunks) q.splits = 1;
-  if (q.splits != 1) return 0;
-  const int t = q.tiles_x * q.tiles_y * (q.th / 8);
+  static const int split_stats = []() { const char* e = getenv("PDAE_SPLIT_STATS"); return e ? atoi(e) : 1; }();       // 0: split launches leave none (A/B aid)
+  if (q.splits != 1 && (Nout > 1024 || !split_stats)) return 0;
+  const int t = q.splits != 1 ? (H * W + reduce_stats_tp(N, H * W) - 1) / reduce_stats_tp(N, H * W) : q.tiles_x * q.tiles_y * (q.th / 8);
   if (tpi) *tpi = t;
   return (size_t)N * t * (Nout >> 2) * 2 * sizeof(float);
 }
@@ -529,8 +567,9 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (coef && (q.w8 || (x1 && (C0 & 31)))) { pdae_set_error("conv3x3p: fused GroupNorm input needs W %% 16 == 0 and C0 %% 32 == 0"); return PDAE_EINVAL; }
   P.tiles_x = q.tiles_x; P.tiles_y = q.tiles_y; P.tiles_n = q.tiles_n; P.splits = q.splits; P.cps = q.cps;
   P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));
-  P.stat_part = stat_part; P.stat_tpi = q.tiles_x * q.tiles_y * (q.th / 8);
-  if (P.stat_part && (q.splits != 1 || (Nout & 3))) { pdae_set_error("conv3x3p: output statistics requested for a split-K launch"); return PDAE_EINVAL; }
+  P.stat_part = stat_part;
+  P.stat_tpi = q.splits != 1 ? (H * W + reduce_stats_tp(N, H * W) - 1) / reduce_stats_tp(N, H * W) : q.tiles_x * q.tiles_y * (q.th / 8);
+  if (P.stat_part && ((Nout & 3) || (q.splits != 1 && Nout > 1024))) { pdae_set_error("conv3x3p: output statistics requested for Nout = %d", Nout); return PDAE_EINVAL; }
   // large layers: persistent workgroups, one wave per SIMD, epilogue of tile i inside tile i+1 (conv3x3r.hip); same parameters, same results
   if (q.splits == 1 && !q.w8 && (!coef || act) && conv3x3r_ok(math, C, H, W, N, Nout, Hs, Ws, P.C0, P.Cs0, P.Cs1)) return conv3x3r_launch(math, P, s);
 #define PDAE_P3(NS_)                                                                                                    \
