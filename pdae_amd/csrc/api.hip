@@ -137,6 +137,9 @@ extern "C" int pdae_conv_wprep_group(const pdae_wprep_job* jobs_dev, const int32
   return wprep_group_launch(reinterpret_cast<const WprepJob*>(jobs_dev), first_block_dev, njobs, total_blocks, S(stream));
 }
 
+// PDAE_EDGE=0: the 3-channel edge layers stay on the fp32 FMA head kernels / the generic implicit GEMM (A/B aid; read per call)
+static bool edge_on() { const char* e = getenv("PDAE_EDGE"); return !e || atoi(e) != 0; }
+
 extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
                                const float* res, int res_mode, float* y, int tile, pdae_stream_t stream) {
   float* const stat = conv3x3p_take_stats();            // consumed here whatever happens below: a failed call never leaves the request armed
@@ -144,8 +147,12 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd: res_mode 2 needs even output");
+  if (tile == 0 && res_mode == 0 && !stat && edge_on() && edge_head_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
+    return edge_head_fwd(x0, d->N, d->Hi, d->Wi, d->C0, w, d->Cout, bias, y, S(stream));
   if (tile == 0 && res_mode == 0 && !stat && convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
     return convhead_fwd(x0, d->N, d->Hi, d->Wi, d->C0, w, d->Cout, bias, y, S(stream));
+  if (tile == 0 && res_mode == 0 && !stat && !wp && edge_on() && edge_in_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout))
+    return edge_in_conv(x0, d->N, d->Hi, d->Wi, d->C0, w, 0, d->Cout, bias, y, 0, S(stream));
   const int kind = wp ? fast_kind(d, 0, false) : 0;
   PDAE_CHECK_ARG(!wp || (tile == 0 && kind != 0), "conv2d_fwd: wp given but the convolution is not eligible for a prepared-weight kernel");
   if (kind == 3)
@@ -249,6 +256,8 @@ extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const
   PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
   PDAE_CHECK_ARG(d->stride == 1 || (Hl == 2 * d->Ho && Wl == 2 * d->Wo), "conv2d_dgrad: stride 2 needs even input");
+  if (tile == 0 && !wp_t && ci_off == 0 && ci_cnt == Cin && edge_on() && edge_in_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->Cout, Cin))
+    return edge_in_conv(dy, d->N, d->Ho, d->Wo, d->Cout, w, 1, Cin, nullptr, dx, accumulate, S(stream));
   const int kind = wp_t ? fast_kind(d, 1, false) : 0;
   PDAE_CHECK_ARG(!wp_t || (tile == 0 && ((kind == 3 && ci_off == 0 && ci_cnt == Cin) || (kind == 1 && (ci_off & 31) == 0 && (ci_cnt & 3) == 0))),
                  "conv2d_dgrad: wp_t given but the convolution / channel range is not eligible for a prepared-weight kernel");
@@ -319,6 +328,10 @@ extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const
                  "conv2d_wgrad: workspace too small for the bias gradient (%zu < pdae_conv2d_wgrad_workspace_bytes)", ws_bytes);
   float* cws = ws ? (float*)((char*)ws + pb) : nullptr;                 // column-sum scratch
   const size_t wsb = ws_bytes < pb ? ws_bytes : pb;                     // what the weight-gradient path may use
+  if (edge_on() && edge_head_wgrad_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout)) {
+    if (int e = edge_head_wgrad(x0, d->N, d->Hi, d->Wi, d->C0, dy, d->Cout, dw, accumulate, (float*)ws, wsb, S(stream))) return e;
+    return db ? k_colsum(dy, Mpix, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;
+  }
   if (convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout)) {
     if (int e = convhead_wgrad(x0, d->N, d->Hi, d->Wi, d->C0, dy, d->Cout, dw, accumulate, (float*)ws, wsb, S(stream))) return e;
     return db ? k_colsum(dy, Mpix, d->Cout, db, accumulate, cws, S(stream)) : PDAE_OK;

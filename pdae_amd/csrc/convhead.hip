@@ -156,7 +156,8 @@ int convhead_fwd(const float* x, int N, int H, int W, int C, const float* w, int
 
 // workspace: per-block partials [blocks][Cout*9*C] + the column-sum scratch
 size_t convhead_wgrad_workspace_bytes(int N, int H, int W, int C, int Cout) {
-  const long long blocks = (long long)N * ((W + HT - 1) / HT) * ((H + HT - 1) / HT);
+  long long blocks = (long long)N * ((W + HT - 1) / HT) * ((H + HT - 1) / HT);
+  if (blocks < 4) blocks = 4;                      // convedge.hip: up to four partial rows (one per wave) from a single tile
   return ((size_t)blocks * Cout * 9 * C + k_colsum_workspace_floats(blocks, Cout * 9 * C)) * sizeof(float);
 }
 

@@ -94,6 +94,15 @@ bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long lo
 int skinny_launch(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, const float* bias, int M, int N, int K,
                   int accumulate, hipStream_t s);
 
+// convedge.hip: the 3-channel edges of the U-Nets on the matrix cores (head forward as 1x1 conv to 9 Cout virtual channels + shifted sum)
+bool edge_head_ok(int KH, int KW, int stride, int pad, int up, int C1, int C, int Cout);
+int edge_head_fwd(const float* x, int N, int H, int W, int C, const float* w, int Cout, const float* bias, float* y, hipStream_t s);
+bool edge_head_wgrad_ok(int KH, int KW, int stride, int pad, int up, int C1, int C, int Cout);
+int edge_head_wgrad(const float* x, int N, int H, int W, int C, const float* dy, int Cout, float* dw, int accumulate, float* ws, size_t ws_bytes,
+                    hipStream_t s);
+bool edge_in_ok(int KH, int KW, int stride, int pad, int up, int C1, int Cin, int Nout);
+int edge_in_conv(const float* x, int N, int H, int W, int Cin, const float* w, int transposed, int Nout, const float* bias, float* y, int accumulate,
+                 hipStream_t s);
 // convhead.hip: 3x3 convolutions with Cout <= 4 (image heads) as exact fp32 FMA kernels
 bool convhead_ok(int KH, int KW, int stride, int pad, int up, int C1, int C, int Cout);
 int convhead_fwd(const float* x, int N, int H, int W, int C, const float* w, int Cout, const float* bias, float* y, hipStream_t s);
