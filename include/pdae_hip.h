@@ -29,7 +29,7 @@ extern "C" {
 typedef void* pdae_stream_t; /* hipStream_t */
 
 const char* pdae_last_error(void);
-int pdae_abi_version(void);   /* 4: + pdae_conv_wprep_job / _group (3: + pdae_conv_stats_* / pdae_gn_coef_from_conv_stats; 2: saturation counter, row-coefficient samplers, fused attention, RCCL) */
+int pdae_abi_version(void);   /* 5: + pdae_subsample2 / pdae_zero_insert2; 4: + pdae_conv_wprep_job / _group (3: + pdae_conv_stats_* / pdae_gn_coef_from_conv_stats; 2: saturation counter, row-coefficient samplers, fused attention, RCCL) */
 
 /* ---- convolution (F.conv2d / conv1d k=1: module.py:242,265,276,412,420; unet.py:62,174; encoder/ffhq.py:12-30) */
 typedef struct pdae_conv_desc {
@@ -192,6 +192,10 @@ int pdae_mlp_modln_bwd(const float* u, const float* e, const float* gamma, const
 int pdae_timestep_embedding(const int64_t* t, const float* freqs, int N, int dim, float* out, pdae_stream_t stream); /* module.py:66-84 */
 int pdae_silu(const float* x, float* y, size_t n, pdae_stream_t stream);
 int pdae_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int accumulate, pdae_stream_t stream);
+/* dense-grid form of a stride-2 3x3 convolution (encoder/ffhq.py:18-31 `nn.Conv2d(.., 3, 2, 1)`): the stride-1 convolution on the patch kernels
+ * plus y[n,oy,ox,:] = x[n,2oy,2ox,:] (forward) / dY scattered onto the even grid of a zero tensor (backward).  NHWC, H and W even, C % 4 == 0. */
+int pdae_subsample2(const float* x, int N, int H, int W, int C, float* y, pdae_stream_t stream);
+int pdae_zero_insert2(const float* x, int N, int Ho, int Wo, int C, float* y, pdae_stream_t stream);
 int pdae_axpby(const float* x, float* y, size_t n, float alpha, float beta, pdae_stream_t stream);
 int pdae_embedding(const float* table, const int64_t* idx, int N, int D, float* out, int accumulate, pdae_stream_t stream); /* unet.py:190-192 */
 int pdae_embedding_bwd(const float* dout, const int64_t* idx, int N, int D, float* dtable, pdae_stream_t stream);
@@ -283,7 +287,8 @@ enum {
   PDAE_OP_FROM_NHWC, PDAE_OP_Q_SAMPLE, PDAE_OP_LOSS, PDAE_OP_DDIM_STEP, PDAE_OP_DDPM_STEP, PDAE_OP_ADAM_EMA, PDAE_OP_SOFTMAX,
   PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
   PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP,
-  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP, PDAE_OP_GN_COEF_FROM_CONV_STATS, PDAE_OP_CONV_WPREP_GROUP
+  PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP, PDAE_OP_GN_COEF_FROM_CONV_STATS, PDAE_OP_CONV_WPREP_GROUP,
+  PDAE_OP_SUBSAMPLE2, PDAE_OP_ZERO_INSERT2
 };
 typedef struct pdae_op {
   int32_t kind;

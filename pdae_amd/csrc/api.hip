@@ -20,7 +20,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 4; }
+extern "C" int pdae_abi_version(void) { return 5; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -456,6 +456,14 @@ extern "C" int pdae_amax(const float* x, size_t n, float* out, pdae_stream_t str
   return k_amax(x, n, out, S(stream));
 }
 extern "C" int pdae_silu(const float* x, float* y, size_t n, pdae_stream_t stream) { return k_silu(x, y, n, S(stream)); }
+extern "C" int pdae_subsample2(const float* x, int N, int H, int W, int C, float* y, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x && y && N >= 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && C > 0 && !(C & 3), "subsample2: need even H, W and C %% 4 == 0");
+  return k_subsample2(x, N, H, W, C, y, S(stream));
+}
+extern "C" int pdae_zero_insert2(const float* x, int N, int Ho, int Wo, int C, float* y, pdae_stream_t stream) {
+  PDAE_CHECK_ARG(x && y && N >= 0 && Ho > 0 && Wo > 0 && C > 0 && !(C & 3), "zero_insert2: need C %% 4 == 0");
+  return k_zero_insert2(x, N, Ho, Wo, C, y, S(stream));
+}
 extern "C" int pdae_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int acc, pdae_stream_t stream) {
   return k_silu_bwd(x, dy, dx, n, acc, S(stream));
 }
@@ -652,6 +660,8 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
       if (p[19]) conv3x3p_arm_stats((float*)p[19]);
       return pdae_conv2d_fwd_skip(&d, F(0), F(1), F(2), (int)i[14], p[3], F(4), &ds, F(5), F(6), p[7], F(8), FM(9), st);
     }
+    case PDAE_OP_SUBSAMPLE2: return pdae_subsample2(F(0), (int)i[0], (int)i[1], (int)i[2], (int)i[3], FM(1), st);
+    case PDAE_OP_ZERO_INSERT2: return pdae_zero_insert2(F(0), (int)i[0], (int)i[1], (int)i[2], (int)i[3], FM(1), st);
     case PDAE_OP_CONV_WPREP_GROUP: return pdae_conv_wprep_group((const pdae_wprep_job*)p[0], (const int32_t*)p[1], (int)i[0], (int)i[1], st);
     case PDAE_OP_CONV_SKIP_WPREP: {
       desc_from(i, d);

@@ -449,3 +449,40 @@ int k_amax(const float* x, size_t n, float* out, hipStream_t st) {
   return pdae_launch_status("amax");
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Dense-grid form of the stride-2 3x3 convolutions (encoder): the stride-1 convolution on the 3x3 patch kernels plus one of these passes.
+//   subsample2  : y[n, oy, ox, :] = x[n, 2 oy, 2 ox, :]                       (forward: the stride-2 output is the even grid of the stride-1 output)
+//   zero_insert2: y[n, 2 oy, 2 ox, :] = x[n, oy, ox, :], zero elsewhere        (backward: dY on the stride-1 grid)
+// One thread per float4 of the larger tensor's even rows / of the output.
+// ----------------------------------------------------------------------------------------------
+__global__ void subsample2_kernel(const float* __restrict__ x, int H, int W, int C4, float* __restrict__ y, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int Wo = W >> 1, Ho = H >> 1;
+  const int c = (int)(i % C4); size_t r = i / C4;
+  const int ox = (int)(r % Wo); r /= Wo;
+  const int oy = (int)(r % Ho); const size_t n = r / Ho;
+  reinterpret_cast<float4*>(y)[i] = reinterpret_cast<const float4*>(x)[((n * H + 2 * oy) * W + 2 * ox) * C4 + c];
+}
+__global__ void zero_insert2_kernel(const float* __restrict__ x, int Ho, int Wo, int C4, float* __restrict__ y, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int W = Wo * 2, H = Ho * 2;
+  const int c = (int)(i % C4); size_t r = i / C4;
+  const int px = (int)(r % W); r /= W;
+  const int py = (int)(r % H); const size_t n = r / H;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (((px | py) & 1) == 0) v = reinterpret_cast<const float4*>(x)[((n * Ho + (py >> 1)) * Wo + (px >> 1)) * C4 + c];
+  reinterpret_cast<float4*>(y)[i] = v;
+}
+int k_subsample2(const float* x, int N, int H, int W, int C, float* y, hipStream_t st) {
+  const size_t n4 = (size_t)N * (H >> 1) * (W >> 1) * (C >> 2);
+  if (n4) hipLaunchKernelGGL(subsample2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, H, W, C >> 2, y, n4);
+  return pdae_launch_status("subsample2");
+}
+int k_zero_insert2(const float* x, int N, int Ho, int Wo, int C, float* y, hipStream_t st) {
+  const size_t n4 = (size_t)N * Ho * 2 * Wo * 2 * (C >> 2);
+  if (n4) hipLaunchKernelGGL(zero_insert2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, Ho, Wo, C >> 2, y, n4);
+  return pdae_launch_status("zero_insert2");
+}

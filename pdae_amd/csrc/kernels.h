@@ -26,6 +26,8 @@ int k_mlp_modln_bwd(const float* u, const float* e, const float* gamma, const fl
                     int R, int C, int norm, int act, float* du, float* de, float* tg, float* tb, hipStream_t st);
 int k_amax(const float* x, size_t n, float* out, hipStream_t st);
 int k_silu(const float* x, float* y, size_t n, hipStream_t st);
+int k_subsample2(const float* x, int N, int H, int W, int C, float* y, hipStream_t st);
+int k_zero_insert2(const float* x, int N, int Ho, int Wo, int C, float* y, hipStream_t st);
 int k_silu_bwd(const float* x, const float* dy, float* dx, size_t n, int acc, hipStream_t st);
 int k_axpby(const float* x, float* y, size_t n, float alpha, float beta, hipStream_t st);
 int k_embedding(const float* table, const long long* idx, int N, int D, float* out, int acc, hipStream_t st);
