@@ -1,7 +1,7 @@
 """GPU: the fused attention core (pdae_attn_fwd / pdae_attn_bwd, csrc/attention.hip) against an fp64 torch restatement of
 QKVAttentionLegacy / QKVAttention (model/module.py:431-488) and its autograd, at the shapes of the path: (T, head width, heads) =
 (64, 512, 1) and (256, 384, 1) of the FFHQ-128 decoder, (256, 64, 4) of the encoders, plus both channel orders at small widths.
-Tolerance 1e-5 relative (exact-fp32 MFMA; the reference itself is fp32)."""
+Tolerance 1e-5 relative (three bf16 planes x six products with fp32 accumulation: fp32-grade; the reference itself is fp32)."""
 import math
 
 import numpy as np

@@ -4,13 +4,15 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pdae_amd.build import CSRC, LIBDIR, SOURCES, HIPCC, FLAGS
-P3, W3, R3 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip"
+P3, W3, R3, AT = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip", "attention.hip"
 VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"]), "nostage": (P3, ["-DPDAE_PROBE_NOSTAGE"]),
             "mfma": (P3, ["-DPDAE_PROBE_NOB", "-DPDAE_PROBE_NOA", "-DPDAE_PROBE_NOSTAGE"]), "clustered": (P3, ["-DPDAE_P3_CLUSTERED"]),
             "w3_nomma": (W3, ["-DPDAE_W3_PROBE_NOMMA"]), "w3_nostage": (W3, ["-DPDAE_W3_PROBE_NOSTAGE"]), "w3_noload": (W3, ["-DPDAE_W3_PROBE_NOLOAD"]),
             "w3_mmaonly": (W3, ["-DPDAE_W3_PROBE_NOSTAGE", "-DPDAE_W3_PROBE_NOLOAD"]),
             "r_noa": (R3, ["-DPDAE_R_PROBE_NOA"]), "r_nob": (R3, ["-DPDAE_R_PROBE_NOB"]), "r_nogload": (R3, ["-DPDAE_R_PROBE_NOGLOAD"]),
             "r_noconv": (R3, ["-DPDAE_R_PROBE_NOCONV"]), "r_nodrain": (R3, ["-DPDAE_R_PROBE_NODRAIN"]),
+            "at_nonn": (AT, ["-DPDAE_AT_PROBE_NONN"]), "at_nont": (AT, ["-DPDAE_AT_PROBE_NONT"]), "at_nnnoload": (AT, ["-DPDAE_AT_PROBE_NNNOLOAD"]),
+            "at_nnnomma": (AT, ["-DPDAE_AT_PROBE_NNNOMMA"]), "at_nosched": (AT, ["-DPDAE_AT_PROBE_NOSCHED"]),
             "r_mfma": (R3, ["-DPDAE_R_PROBE_NOA", "-DPDAE_R_PROBE_NOB", "-DPDAE_R_PROBE_NOGLOAD", "-DPDAE_R_PROBE_NOCONV", "-DPDAE_R_PROBE_NODRAIN"])}
 only = sys.argv[1:]
 for name, (src, defs) in VARIANTS.items():
