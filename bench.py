@@ -413,7 +413,8 @@ def main():
         # ---- roofline of the dominant kernel family, live, with HIP events (one extra, un-timed step)
         st.load_batch(x0)
         durs = profile_plan(st.plan, 0, st.n_bwd)
-        fl = [op_flops(st.plan.arr[k]) for k in range(st.n_bwd)]
+        # algorithmic FLOPs: a stride-2 convolution run in the dense-grid form (engine.Builder._dense_grid_desc) executes 4x its products
+        fl = [op_flops(st.plan.arr[k]) * (0.25 if k in getattr(st.plan, "dense_grid", ()) else 1.0) for k in range(st.n_bwd)]
         ig_ms = sum(d for d, f in zip(durs, fl) if f > 0)
         ig_fl = sum(fl)
         n_ig = sum(1 for f in fl if f > 0)
@@ -454,7 +455,8 @@ def main():
             s_ = 2 if up else 1
             return 4.0 * N * (Ho * Wo * Cout + Hi * s_ * Wi * s_ * Cin) + 6.0 * Cout * 9 * Cin
 
-        pk = [k for k in range(st.n_bwd) if is_patch(st.plan.arr[k])]
+        dense = getattr(st.plan, "dense_grid", set())    # stride-2 convs run as stride-1 launches on a 75 %-zero grid: not part of the kernel's roofline set
+        pk = [k for k in range(st.n_bwd) if is_patch(st.plan.arr[k]) and k not in dense]
         kname = "conv3x3r_kernel + conv3x3p_kernel (3x3 conv forward + data gradient, LDS-patch kernels: persistent / deferred-epilogue form on the large layers)"
         if not pk:                                    # f32 mode: every convolution runs on the generic f32-MFMA implicit GEMM
             pk = [k for k in range(st.n_bwd) if fl[k] > 0 and st.plan.arr[k].kind != H.OP_GEMM]
@@ -484,7 +486,7 @@ def main():
         out["step_roofline_note"] = (f"floors at B={B}: MFMA {step_fl * npm / PEAK_BF16_MFMA_TFLOPS / 1e9:.1f} ms ({TRAIN_GFLOP_PER_IMG * B / 1e3:.2f} TFLOP x {npm} MFMA products / 2.5 PFLOP/s), "
                                      f"HBM {(HBM_GB_PER_IMG * B + HBM_GB_PER_STEP) / PEAK_HBM_TBS:.1f} ms ({HBM_GB_PER_IMG * B + HBM_GB_PER_STEP:.1f} GB / 8 TB/s)")
         # 3x3 weight-gradient kernel: same figures (algorithmic bytes: X and dY read once, dW written once)
-        wk = [k for k in range(st.n_bwd) if st.plan.arr[k].kind == H.OP_CONV_WGRAD and st.plan.arr[k].i[8] == 3 and bool(st.plan.arr[k].p[6])]
+        wk = [k for k in range(st.n_bwd) if st.plan.arr[k].kind == H.OP_CONV_WGRAD and st.plan.arr[k].i[8] == 3 and bool(st.plan.arr[k].p[6]) and k not in dense]
         if wk:
             w_ms, w_fl = sum(durs[k] for k in wk), sum(fl[k] for k in wk)
             w_by = sum(4.0 * st.plan.arr[k].i[0] * (st.plan.arr[k].i[1] * st.plan.arr[k].i[2] * (st.plan.arr[k].i[3] + st.plan.arr[k].i[4]) + st.plan.arr[k].i[5] * st.plan.arr[k].i[6] * st.plan.arr[k].i[7])

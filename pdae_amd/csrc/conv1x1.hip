@@ -332,12 +332,16 @@ static PointPlan point_plan(long long M, int C, int Nout) {
   q.tiles_m = (int)((M + 127) / 128); q.tiles_n = (Nout + 127) / 128;
   const long long base = (long long)q.tiles_m * q.tiles_n;
   const int nstage = (C + 63) >> 6;                      // 64-channel stages
+  static const double slab_w = []() { const char* e = getenv("PDAE_C1_SLAB"); return e ? atof(e) : 1.0; }();      // 0: the round-2 plan (A/B aid)
   long long best = -1; int best_s = 1;
   for (int sN = 1; sN <= nstage && sN <= 16; ++sN) {     // minimise rounds(grid) x stages-per-block (+1 for prologue / epilogue)
     const int per = (nstage + sN - 1) / sN, sp = (nstage + per - 1) / per;
     if (sp != sN) continue;
     const long long rounds = (base * sp + 511) / 512;
-    const long long cost = rounds * (per + 1);
+    // + the slabs: sp x M x Nout floats written and read again by the reduce launch, in stage times (~1.2 us) at ~5 TB/s.  Without this term
+    // the 16x16 attention projections (M = 8192, Nout = 1152) were split in two: 150 MB of slab traffic around a 12 us GEMM
+    const long long slab = sp > 1 ? (long long)(slab_w * 2.0 * sp * (double)M * Nout * 4.0 / 6.0e6) : 0;
+    const long long cost = rounds * (per + 1) + slab;
     if (best < 0 || cost < best) { best = cost; best_s = sN; }
   }
   const int per = (nstage + best_s - 1) / best_s;

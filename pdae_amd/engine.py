@@ -39,6 +39,7 @@ class Plan:
         self.init_arr = None
         self.watch = []         # modules whose _frozen_version gates a re-run of the init ops
         self.seen = None
+        self.dense_grid = set()   # indices of conv records that run a stride-2 convolution in the dense-grid form (4x the algorithmic products: bench.py)
         self._tickets = None    # zeroed uint32 words for the "last block finishes" GroupNorm kernels (one stream runs a plan: shared by all its ops)
         self.wprep_jobs = []    # prepared copies of TRAINABLE conv weights: refreshed by ONE grouped launch at the head of every run (compile)
         self.pre_arr = None
@@ -238,6 +239,7 @@ class Builder:
             # -- the generic implicit GEMM runs them as <= 128 workgroups with a serial K loop of 2304 (130 us for 0.6 GFLOP)
             yf = self.p.buf(N, Hh, W, c.Cout)
             wp = self._wprep(c1, w, 0)
+            self.p.dense_grid.add(len(self.p.recs))
             self.p.emit(H.op_conv_fwd(c1, x0, None, w, b, yf, wp=wp))
             if wp is not None:
                 self.p.free(wp)
@@ -348,6 +350,7 @@ class Builder:
             c = self._bwd_desc(cx.c1)
             amax = self.dy_amax(c, dy) if amax is None else amax            # max|dY| of the small tensor: the zeros do not change it
             dy = self._dense_dy(cx, dy)
+            self.p.dense_grid.add(len(self.p.recs))
         if gw is not None:
             wsb = c.wgrad_ws_bytes()
             self.p.need_ws(wsb)
@@ -376,6 +379,7 @@ class Builder:
             am = self.dy_amax(c, dy) if amax is None else amax
             dyf = self._dense_dy(cx, dy)
             wp_t = self._wprep(c, w, 1, f16_grad=am is not None)
+            self.p.dense_grid.add(len(self.p.recs))
             self.p.emit(H.op_conv_dgrad(c, dyf, w, dx, accumulate=accumulate, wp_t=wp_t, dy_amax=am))
             self.p.free(wp_t, dyf)
             self._dyf = None
