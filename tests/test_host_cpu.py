@@ -112,3 +112,41 @@ def test_trainers_and_sampler_hand_their_rank_to_the_dataset(monkeypatch):
                 n += 1
     assert n >= 5
     assert TR.DATA_SEED == TG.DATA_SEED == TL.DATA_SEED
+
+
+def test_encoder_plan_runs_stride2_convolutions_in_the_dense_grid_form(monkeypatch):
+    """engine.Builder._dense_grid_desc: with the default switches the planned FFHQ encoder pass (B = 32) scatters dY of every eligible stride-2
+    3x3 convolution onto the stride-1 grid once (pdae_zero_insert2), runs its weight / data gradient (and the forward of the small layers) as
+    stride-1 records and marks those records for bench.py; PDAE_S2_DENSE=0 leaves only stride-2 records.  Plans are built on the CPU (records
+    only, nothing is launched)."""
+    import torch
+    from pdae_amd import hip as H
+    from pdae_amd.engine import Builder, Plan
+    from pdae_amd.model import graph as G
+    from pdae_amd.model.representation_learning.encoder import FFHQEncoder
+
+    def build(flag):
+        monkeypatch.setenv("PDAE_S2_DENSE", flag)
+        enc = FFHQEncoder(device="cpu", latent_dim=512)
+        enc.train()
+        p = Plan("cpu")
+        B = Builder(p, enc.P, enc.grads(), save=True, math="f16x3")
+        x = torch.zeros(32, 128, 128, 3)
+        z, ex = G.encoder_forward(B, enc.NAME, x)
+        G.encoder_backward(B, ex, torch.zeros_like(z))
+        return p
+
+    def convs(plan):
+        return [r for r in plan.recs if r.kind in (H.OP_CONV_FWD, H.OP_CONV_DGRAD, H.OP_CONV_WGRAD)]
+
+    on, off = build("1"), build("0")
+    kinds_on, kinds_off = [r.kind for r in on.recs], [r.kind for r in off.recs]
+    assert H.OP_ZERO_INSERT2 not in kinds_off and H.OP_SUBSAMPLE2 not in kinds_off and not off.dense_grid
+    n_s2_off = sum(1 for r in convs(off) if r.i[10] == 2)
+    assert n_s2_off == 5 + 5 + 4                                            # five stride-2 layers: forward + dW each, dX of all but the first
+    nz, ns = kinds_on.count(H.OP_ZERO_INSERT2), kinds_on.count(H.OP_SUBSAMPLE2)
+    assert nz == 4 and ns == 3 and len(on.dense_grid) == 4 + 4 + 3           # Cin = 3 stays generic; outputs of <= 8192 pixels also forward
+    for k in on.dense_grid:
+        r = on.recs[k]
+        assert r.kind in (H.OP_CONV_FWD, H.OP_CONV_DGRAD, H.OP_CONV_WGRAD) and r.i[8] == 3 and r.i[10] == 1      # 3x3, stride 1
+    assert sum(1 for r in convs(on) if r.i[10] == 2) == n_s2_off - len(on.dense_grid)      # each marked record replaces one stride-2 record
