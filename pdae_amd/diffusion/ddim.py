@@ -139,9 +139,11 @@ class DDIM:
                 keep_eps, keep_g = torch.empty_like(p.eps), torch.empty_like(p.shift)
             if trajectory is not None:
                 del trajectory[:]
+            fresh = True                               # first step: loop-invariant prefix (z-only ops) and the weight preparation run too
             for i in steps:
                 p.t.fill_(self._map_host[i])
-                p.run(0, p.n_fwd)
+                p.run(0 if fresh else getattr(p, "n_const", 0), p.n_fwd, prep=fresh)
+                fresh = z_mix is not None              # trajectory interpolation swaps z inside the step: nothing is invariant
                 eps, g = p.eps, (shift if (shift is not None and use_shift(i)) else None)
                 if z_mix is not None:
                     z_2, alpha = z_mix

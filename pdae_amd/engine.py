@@ -39,6 +39,8 @@ class Plan:
         self.init_arr = None
         self.watch = []         # modules whose _frozen_version gates a re-run of the init ops
         self.seen = None
+        self.pinned = set()       # ids of buffers that free() must leave alone: results of the loop-invariant prefix [0, n_const) of a sampling plan
+        self.n_const = 0          # ops [0, n_const) depend only on (z, weights): a sampling loop runs them on its first step only (model/graph.py)
         self.dense_grid = set()   # indices of conv records that run a stride-2 convolution in the dense-grid form (4x the algorithmic products: bench.py)
         self._tickets = None    # zeroed uint32 words for the "last block finishes" GroupNorm kernels (one stream runs a plan: shared by all its ops)
         self.wprep_jobs = []    # prepared copies of TRAINABLE conv weights: refreshed by ONE grouped launch at the head of every run (compile)
@@ -75,7 +77,7 @@ class Plan:
 
     def free(self, *ts):
         for t in ts:
-            if t is not None and not isinstance(t, NoFree):
+            if t is not None and not isinstance(t, NoFree) and id(t) not in self.pinned:
                 self.pool.setdefault((t.numel(), t.dtype), []).append(t)
 
     def need_ws(self, nbytes):
@@ -114,8 +116,14 @@ class Plan:
                 self.arr[idx].i[wsb_slot] = self.ws_bytes
         return self
 
-    def run(self, first=0, last=None, stream=None):
-        """Runs ops[first:last] on the current (or given) stream."""
+    def pin(self, *ts):
+        for t in ts:
+            if t is not None:
+                self.pinned.add(id(t))
+
+    def run(self, first=0, last=None, stream=None, prep=True):
+        """Runs ops[first:last] on the current (or given) stream.  prep=False: the prepared copies of the trainable weights are current (a
+        sampling loop after its first step)."""
         if self.device.type != "cuda":
             raise H.PdaeError("pdae_amd plans only execute on a ROCm device (no CPU fallback)")
         last = self.n if last is None else last
@@ -124,7 +132,7 @@ class Plan:
             if cur != self.seen:
                 H.run_ops(self.init_arr, len(self.init_recs), stream)
                 self.seen = cur
-        if first == 0 and self.pre_arr is not None:    # the trainable weights may have changed since the last run: all prepared copies, one launch
+        if first == 0 and prep and self.pre_arr is not None:    # the trainable weights may have changed since the last run: all prepared copies, one launch
             H.run_ops(self.pre_arr, 1, stream)
         if os.environ.get("PDAE_DEBUG_SYNC"):          # one op at a time, synchronised, index printed first
             import sys

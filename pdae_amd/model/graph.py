@@ -5,6 +5,7 @@ Topology follows the reference constructors (model/unet.py:60-175, model/shift_u
 model/representation_learning/encoder/*.py) and the forward passes (unet.py:177-202,
 shift_unet.py:253-284, encoder/ffhq.py:39-41); nothing here is hard-coded to one resolution or width.
 """
+import os
 from collections import OrderedDict
 from types import SimpleNamespace as NS
 
@@ -224,19 +225,32 @@ def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shif
     pl = B.p
     inputs, middle, outputs = topology(cfg)
     keep_all = B.save
-    tctx = _time_embed(B, cfg, t, freqs, cond)
-    ea = tctx.ea
-    semb = eza = l_lab = None
-    if shift:
-        semb, l_lab = B.linear(z, "label_emb")
-        eza = B.silu(semb)
-    # every ResBlock's emb_layers / emb_z_layers Linear in one launch (they only depend on the embeddings computed above)
     def res_prefixes(pre, blocks):
         return [f"{pre}.{i}.{j}" if isinstance(blocks[0], list) else f"{pre}.{j}" for i, layers in enumerate(blocks if isinstance(blocks[0], list) else [blocks])
                 for j, (kind, d) in enumerate(layers) if kind == "res"]
     plain = res_prefixes("input_blocks", inputs) + res_prefixes("middle_block", middle) + res_prefixes("output_blocks", outputs)
     shifted = (res_prefixes("shift_middle_block", middle) + res_prefixes("shift_output_blocks", outputs)) if shift else []
-    B.prefetch_emb(ea, plain + shifted, eza, shifted)
+    semb = eza = l_lab = None
+    # sampling plans (nothing kept for a backward): everything that depends only on the latent z -- label_emb, its SiLU and the emb_z_layers Linear
+    # of every shift ResBlock -- goes to the head of the op list and its results are pinned, so a denoising loop runs that prefix once, not on
+    # each of its 100 / 1000 steps (ops [0, pl.n_const); diffusion/ddim.py)
+    hoist = shift and not keep_all and not train_shift and len(pl.recs) == 0 and os.environ.get("PDAE_DDIM_HOIST", "1") != "0"
+    if hoist:
+        semb, l_lab = B.linear(z, "label_emb")
+        eza = B.silu(semb)
+        B.prefetch_emb(None, [], eza, shifted)
+        pl.pin(semb, eza, *[y for (y, _) in B._emb.values()])
+        pl.n_const = len(pl.recs)
+    tctx = _time_embed(B, cfg, t, freqs, cond)
+    ea = tctx.ea
+    if shift and not hoist:
+        semb, l_lab = B.linear(z, "label_emb")
+        eza = B.silu(semb)
+    # every ResBlock's emb_layers / emb_z_layers Linear in one launch (they only depend on the embeddings computed above)
+    if hoist:
+        B.prefetch_emb(ea, plain + shifted)
+    else:
+        B.prefetch_emb(ea, plain + shifted, eza, shifted)
     hs, in_ctx = [], []
     h = x
     for i, layers in enumerate(inputs):
