@@ -142,7 +142,7 @@ int pdae_gemm(int transA, int transB, int M, int N, int K, float alpha, const fl
  * ResBlock's emb_layers / emb_z_layers Linear (model/module.py:287-293, 371-380) reads SiLU(emb) / SiLU(shift_emb), which exist before the
  * first block: one call per network pass instead of one launch per block.  items and first_feature are DEVICE arrays; first_feature[i] is
  * the position of item i's first output feature in the concatenated feature list, first_feature[n_items] == total_features. */
-typedef struct pdae_linear_item { const float* x; const float* w; const float* bias; float* y; int32_t n_out; int32_t reserved; } pdae_linear_item;
+typedef struct pdae_linear_item { const float* x; const float* w; const float* bias; float* y; int32_t n_out; int32_t rows; /* 0: M; else 1..32 rows of THIS item (a batch > 32 is a list of row slices) */ } pdae_linear_item;
 int pdae_linear_group(const pdae_linear_item* items, const int32_t* first_feature, int n_items, int total_features, int M, int K, pdae_stream_t stream);
 
 /* Backward of such a family in ONE launch: dw_i (+)= dy_i^T x_i, db_i (+)= column sums of dy_i (acc_w selects "+="), and where dx_i != NULL

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) skinny_group_kernel(const LinearItem* __r
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (first[mid] <= f) lo = mid; else hi = mid - 1; }
   const LinearItem it = items[lo];
   const int n = f - first[lo];
-  skinny_feature(it.x, K, it.w + (long long)n * K, it.y, it.n_out, it.bias, n, M, K, 0, threadIdx.x & 63);
+  skinny_feature(it.x, K, it.w + (long long)n * K, it.y, it.n_out, it.bias, n, it.pad > 0 ? it.pad : M, K, 0, threadIdx.x & 63);      // pad = rows of this item (0: M)
 }
 
 int skinny_group_launch(const void* items, const int* first, int n_items, int total, int M, int K, hipStream_t s) {

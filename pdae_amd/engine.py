@@ -416,7 +416,7 @@ class Builder:
         if not jobs:
             return []
         Nb, K = jobs[0][0].shape
-        fits = Nb <= 32 and K % 8 == 0 and all(x.shape == (Nb, K) for x, _ in jobs) and os.environ.get("PDAE_GROUP_LINEAR", "1") != "0"
+        fits = K % 8 == 0 and all(x.shape == (Nb, K) for x, _ in jobs) and os.environ.get("PDAE_GROUP_LINEAR", "1") != "0"
         if not fits:
             return [self.linear(x, w) for x, w in jobs]
         out, items = [], []
@@ -424,11 +424,15 @@ class Builder:
             w, b = self.P[wname + ".weight"], self.P[wname + ".bias"]
             assert w.numel() == w.shape[0] * K, (wname, tuple(w.shape), K)
             y = self.p.buf(Nb, w.shape[0])
-            items.append((x, w, b, y))
+            if Nb <= 32:
+                items.append((x, w, b, y))
+            else:                                        # sampling batches (100, 128): row slices of 32 as items of the same launch
+                for r0 in range(0, Nb, 32):
+                    items.append((x[r0:r0 + 32], w, b, y[r0:r0 + 32], min(32, Nb - r0)))
             out.append((y, NS(x=x, wname=wname, Nb=Nb, K=K, out=w.shape[0])))
         it, first, total = H.linear_group_tables(items, self.p.device)
         self.p.live.extend([it, first])                  # the device tables live as long as the plan
-        self.p.emit(H.op_linear_group(it, first, len(items), total, Nb, K))
+        self.p.emit(H.op_linear_group(it, first, len(items), total, min(Nb, 32), K))
         return out
 
     def prefetch_emb(self, ea, prefixes, eza=None, z_prefixes=()):

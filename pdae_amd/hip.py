@@ -357,11 +357,13 @@ def op_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=Non
 
 
 def linear_group_tables(items, device):
-    """Device tables of pdae_linear_group for items = [(x, w, bias, y)] (tensors): (items int64 [n,5], first int32 [n+1], total features)."""
+    """Device tables of pdae_linear_group for items = [(x, w, bias, y[, rows])] (tensors): (items int64 [n,5], first int32 [n+1], total features)."""
     rows, first, tot = [], [0], 0
-    for x, w, b, y in items:
+    for it in items:
+        x, w, b, y = it[:4]
+        nrows = int(it[4]) if len(it) > 4 else 0                     # rows of this item (0: the launch's M)
         n_out = int(w.shape[0])
-        rows.append([x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else 0, y.data_ptr(), n_out])     # n_out | reserved<<32 in one int64 (little endian)
+        rows.append([x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else 0, y.data_ptr(), n_out | (nrows << 32)])     # n_out | rows<<32 in one int64 (little endian)
         tot += n_out
         first.append(tot)
     return (torch.tensor(rows, dtype=torch.int64).to(device), torch.tensor(first, dtype=torch.int32).to(device), tot)

@@ -793,6 +793,30 @@ def test_grouped_linear_forward_and_backward(H):
     assert rel_err(dxb, dys[2].double() @ Ws[2].double()) < 1e-6
 
 
+def test_grouped_linear_with_a_sampling_batch_over_32_rows(H):
+    """Builder.linear_group at the evaluator's batch (100 rows): every layer enters the one launch as row slices of <= 32 rows (per-item `rows`
+    of pdae_linear_item); results equal the fp64 product and every output element is written."""
+    from types import SimpleNamespace
+    from pdae_amd.engine import Builder, Plan
+    Nb, K = 100, 512
+    g = torch.Generator().manual_seed(3)
+    P = {}
+    for i, n in enumerate((256, 1024, 36)):
+        P[f"l{i}.weight"] = (torch.randn(n, K, generator=g) / 22).cuda()
+        P[f"l{i}.bias"] = torch.randn(n, generator=g).cuda()
+    x = torch.randn(Nb, K, generator=g).cuda()
+    pl = Plan("cuda")
+    B = Builder(pl, P, None)
+    res = B.linear_group([(x, f"l{i}") for i in range(3)])
+    assert [r.kind for r in pl.recs] == [H.OP_LINEAR_GROUP]
+    for y, _ in res:
+        y.fill_(float("nan"))
+    pl.finalize() if hasattr(pl, "finalize") else None
+    H.run(pl.recs[0])
+    for i, (y, ctx) in enumerate(res):
+        assert ctx.Nb == Nb and rel_err(y, x.double() @ P[f"l{i}.weight"].double().T + P[f"l{i}.bias"].double()) < 1e-6
+
+
 def test_grouped_weight_preparation_equals_the_single_launches(H):
     """pdae_conv_wprep_group: every prepared-weight form the engine uses (3x3 forward, fused-GroupNorm two-source, data-gradient in the exact
     and the fp16-gradient format, 1x1 forward / data gradient, fused skip chunks; bf16 and split formats) written by ONE launch from a job
