@@ -106,7 +106,8 @@ int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* 
 /* GroupNorm statistics of a convolution's OUTPUT, produced by the convolution while it stores the tensor -- the GroupNorm that follows
  * (module.py:241,257: in_layers / out_layers norm of the next stage) then needs no pass over the tensor at all:
  *   bytes = pdae_conv_stats_bytes(d, ds, &tpi)   size of the partial-sum buffer, 0 when the forward convolution of d (with the fused skip
- *                                                convolution ds, or NULL) would not run as ONE launch of the 3x3 patch kernel
+ *                                                convolution ds, or NULL) does not run on the 3x3 patch kernels (split-K launches leave the
+ *                                                sums from their slab reduction: tpi is then pixels / 8 or / 16 per image)
  *   pdae_conv_stats_arm(part)                    one-shot: the NEXT pdae_conv2d_fwd / _fwd_gn / _fwd_skip on this host thread also writes
  *                                                part[N][tpi][Cout/4] x (sum, sum of squares) of its output (in a pdae_op record: p[19])
  *   pdae_gn_coef_from_conv_stats(...)            mean / rstd / coef ([mu | a | b], as pdae_gn_stats_coef) of the virtual concat of one or two such

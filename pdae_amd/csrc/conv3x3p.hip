@@ -535,8 +535,8 @@ size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { re
 
 // One-shot request (pdae_conv_stats_arm): the next forward convolution entry point on this host thread TAKES it -- on entry, before any argument
 // check, so that no return path leaves it armed for a later launch on another tensor -- and hands it to conv3x3p_launch explicitly, which
-// then also writes the GroupNorm partial statistics of its output (the caller sized `part` with conv3x3p_stats_bytes, which is 0 whenever
-// the launch would split K).
+// then also writes the GroupNorm partial statistics of its output (the caller sized `part` with conv3x3p_stats_bytes; a split-K launch
+// leaves them from its slab reduction, conv3x3p_reduce_stats_kernel).
 static thread_local float* g_stat_arm = nullptr;
 void conv3x3p_arm_stats(float* part) { g_stat_arm = part; }
 float* conv3x3p_take_stats() { float* p = g_stat_arm; g_stat_arm = nullptr; return p; }

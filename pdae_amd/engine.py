@@ -202,7 +202,7 @@ class Builder:
 
     # ------------------------------------------------------------------ fused output statistics
     def _stats_buf(self, c, cs=None):
-        """Partial-statistics buffer for the output of forward convolution c (None when it is not a single patch-kernel launch)."""
+        """Partial-statistics buffer for the output of forward convolution c (None when it does not run on the 3x3 patch kernels)."""
         if not self.fuse_stats:
             return None, 0
         nbytes, tpi = H.conv_stats_bytes(c, cs)

@@ -263,7 +263,7 @@ def op_conv_fwd_skip(c, x0, x1, coef, act, wp, bias, cs, s0, s1, wps, bias_s, y,
 
 def conv_stats_bytes(c, cs=None):
     """(bytes, wave-tiles per image) of the GroupNorm partial statistics the forward convolution c (with fused skip cs) can leave behind while
-    it stores its output; (0, 0) when it would not run as one launch of the 3x3 patch kernel (pdae_conv_stats_bytes)."""
+    it stores its output (split-K launches: from their slab reduction); (0, 0) when it does not run on the 3x3 patch kernels (pdae_conv_stats_bytes)."""
     d = c.cdesc()
     tpi = ctypes.c_int32(0)
     if cs is None:
