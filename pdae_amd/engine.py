@@ -277,15 +277,17 @@ class Builder:
         return c1
 
     def _dense_dy(self, cx, dy):
-        """dY of stride-2 conv cx on the stride-1 grid (shared by its weight- and data-gradient launches, freed by the latter)."""
-        if self._dyf is not None and self._dyf[0] is dy:
+        """dY of stride-2 conv cx on the stride-1 grid: shared by its weight- and data-gradient launches when they are emitted back to back (the
+        copy is valid only while no other record has been emitted since conv_bwd_params returned: pooled buffers are recycled OBJECTS, identity
+        of `dy` alone would also match a later tensor), freed by the data gradient or by the next request."""
+        if self._dyf is not None and self._dyf[0] is dy and self._dyf[2] == len(self.p.recs):
             return self._dyf[1]
         if self._dyf is not None:
             self.p.free(self._dyf[1])
         c = cx.c
         dyf = self.p.buf(c.N, c.Hi, c.Wi, c.Cout)
         self.p.emit(H.op_zero_insert2(dy, c.N, c.Ho, c.Wo, c.Cout, dyf))
-        self._dyf = (dy, dyf)
+        self._dyf = (dy, dyf, -1)
         return dyf
 
     def _wprep(self, c, w, transposed, gn=False, f16_grad=False):
@@ -354,10 +356,11 @@ class Builder:
         c = self._bwd_desc(cx.c)
         gw = self.Gr.get(cx.wname + ".weight")
         gb = self.Gr.get(cx.wname + ".bias")
-        if getattr(cx, "c1", None) is not None and gw is not None:
+        dense = getattr(cx, "c1", None) is not None and gw is not None
+        if dense:
             c = self._bwd_desc(cx.c1)
             amax = self.dy_amax(c, dy) if amax is None else amax            # max|dY| of the small tensor: the zeros do not change it
-            dy = self._dense_dy(cx, dy)
+            dy_small, dy = dy, self._dense_dy(cx, dy)
             self.p.dense_grid.add(len(self.p.recs))
         if gw is not None:
             wsb = c.wgrad_ws_bytes()
@@ -375,6 +378,8 @@ class Builder:
             M = c.N * c.Ho * c.Wo
             self.p.need_ws(H.colsum_ws_bytes(M, c.Cout))
             self.p.emit(H.op_colsum(dy, M, c.Cout, gb, None, acc=self.acc), ws_slot=2)
+        if dense:
+            self._dyf = (dy_small, dy, len(self.p.recs))                    # conv_dgrad may take it if it is the very next thing emitted
 
     def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0, amax=None):
         c = self._bwd_desc(cx.c)
@@ -384,8 +389,8 @@ class Builder:
         whole = ci_off == 0 and ci_cnt == c.Cin
         if getattr(cx, "c1", None) is not None and whole:
             c = self._bwd_desc(cx.c1)
+            dyf = self._dense_dy(cx, dy)                                    # first: the shared copy is valid only while nothing else has been emitted
             am = self.dy_amax(c, dy) if amax is None else amax
-            dyf = self._dense_dy(cx, dy)
             wp_t = self._wprep(c, w, 1, f16_grad=am is not None)
             self.p.dense_grid.add(len(self.p.recs))
             self.p.emit(H.op_conv_dgrad(c, dyf, w, dx, accumulate=accumulate, wp_t=wp_t, dy_amax=am))
