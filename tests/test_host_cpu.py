@@ -150,3 +150,33 @@ def test_encoder_plan_runs_stride2_convolutions_in_the_dense_grid_form(monkeypat
         r = on.recs[k]
         assert r.kind in (H.OP_CONV_FWD, H.OP_CONV_DGRAD, H.OP_CONV_WGRAD) and r.i[8] == 3 and r.i[10] == 1      # 3x3, stride 1
     assert sum(1 for r in convs(on) if r.i[10] == 2) == n_s2_off - len(on.dense_grid)      # each marked record replaces one stride-2 record
+
+
+def test_sampling_plan_has_a_pinned_latent_only_prefix(monkeypatch):
+    """model/graph.py unet_forward: in a sampling plan of ShiftUNet the ops that depend only on the latent z (label_emb, its SiLU, the grouped
+    emb_z_layers Linear) come first (Plan.n_const), their results are pinned -- never returned to the buffer pool, so no later op of a step can
+    overwrite what the following steps still read -- and PDAE_DDIM_HOIST=0 restores the flat list.  Built on the CPU: records only."""
+    import torch
+    from pdae_amd import hip as H
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from tests.golden import make_fixtures_cfg as C
+
+    def plan(flag):
+        monkeypatch.setenv("PDAE_DDIM_HOIST", flag)
+        net = ShiftUNet(device="cpu", latent_dim=512, **C.CFG_SHIFT_64)
+        net.set_eval_mode()
+        return net.plan(2, 64, 64, False)
+
+    on, off = plan("1"), plan("0")
+    assert off.n_const == 0 and not off.pinned
+    assert on.n_const >= 3 and len(on.recs) == len(off.recs) + 1                  # same ops reordered, the grouped Linear launch in two (z part, time part)
+    kinds = [r.kind for r in on.recs[:on.n_const]]
+    assert kinds[0] == H.OP_GEMM and H.OP_SILU in kinds and H.OP_LINEAR_GROUP in kinds and H.OP_TEMB not in kinds
+    assert H.OP_TEMB in [r.kind for r in on.recs[on.n_const:on.n_fwd]]             # everything time-dependent runs every step
+    pooled = {id(t) for ts in on.pool.values() for t in ts}
+    assert on.pinned and not (on.pinned & pooled)                                 # pinned buffers were never recycled
+    # the training plan keeps the reference's order: the prefix exists only where nothing is saved for a backward
+    monkeypatch.setenv("PDAE_DDIM_HOIST", "1")
+    net = ShiftUNet(device="cpu", latent_dim=512, **C.CFG_SHIFT_64)
+    net.set_train_mode()
+    assert net.plan(2, 64, 64, True).n_const == 0
