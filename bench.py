@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ddim-batch", type=int, default=100, help="batch of the DDIM-100 measurement (sampler/autoencoding_eval.py:125 uses 100)")
     ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--autoencode", action="store_true", help="also time the evaluator's whole protocol at the DDIM batch: ddim1000 encode + ddim100 decode "
+                    "(sampler/autoencoding_eval.py:74-78; 1099 decoder passes, ~90 s) -> ddim100.autoencode_1099_steps_seconds")
     ap.add_argument("--no-legs", action="store_true", help="skip the other_legs object (F128 with bf16 operands, CelebA-64 bf16)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--bucket-mb", type=float, default=0, help="gradient bucket size of the data-parallel all-reduce; 0 = sweep 16/48/96 MB in the "
@@ -536,6 +538,19 @@ def main():
                         out["ddim100"].update(rec)                     # headline: the evaluator's batch (100)
                     else:
                         out["ddim100"][f"batch_{Bd}"] = rec
+                    dec.invalidate_plans()
+            if args.autoencode:                       # the evaluator's protocol on one batch: encoder -> 999-step DDIM inversion -> 100-step decode
+                with torch.no_grad():
+                    Bd = args.ddim_batch or B
+                    xa = torch.rand(Bd, 3, size, size, device=dev) * 2 - 1
+                    enc.eval()
+                    gd.representation_learning_autoencoding("ddim10", "ddim10", enc, dec, xa)      # plans
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    gd.representation_learning_autoencoding("ddim1000", "ddim100", enc, dec, xa)
+                    torch.cuda.synchronize()
+                    out["ddim100"]["autoencode_1099_steps_seconds"] = round(time.perf_counter() - t1, 2)
+                    out["ddim100"]["autoencode_batch"] = Bd
                     dec.invalidate_plans()
             log("ddim100 done")
             if world == 1 and not args.no_cpu_baseline:          # what the same denoising step costs on the host cores (oracle decoder forward)
