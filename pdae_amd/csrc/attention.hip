@@ -138,19 +138,24 @@ __device__ __forceinline__ void at_gemm_nt(const float* __restrict__ A, long lon
 
 // dst[this wave's 32 rows][its 32 of every 64 channels] = alpha * M[64][T] (bf16 planes in LDS) * B[T][ch] (global, token-major, row stride ldb).
 // sM must be complete (caller syncs); no barrier inside.  dst already offset to the wave's first row, B / dst to its first channel (colw).
-template <int NB, int CG>               // the block's waves cover CG * 32 channels per chunk
+template <int NB, int CG, int DR = NB * 4>   // the block's waves cover CG * 32 channels per chunk; DR: k-steps of B in flight (divides NB * 4)
 __device__ __forceinline__ void at_gemm_nn(const unsigned short* sM, const float* __restrict__ B, long long ldb, int ch, int colw, float alpha,
                                            float* __restrict__ dst, long long ldd, int row0, int li, int h) {
   constexpr int CW = 32 * CG;                          // channels per chunk
 #ifdef PDAE_AT_PROBE_NONN
   return;
 #endif
-  constexpr int T = NB * 64, KS = NB * 4, LDM = T + AT_PAD, D = KS;      // ring = one whole chunk of k-steps (2 us of work at T = 256) in flight: D = 4 left the product waiting on L2 latency
+  // ring of D k-steps in flight; default one whole chunk (2 us of work at T = 256): D = 4 left the product waiting on L2 latency.  The dV product of
+  // attn_bwd_kv<4, 4> runs with D = 8: dS^T (32 registers) stays live across it and the 16-deep ring spilled 45 VGPRs to scratch (184 bytes per lane)
+  constexpr int T = NB * 64, KS = NB * 4, LDM = T + AT_PAD, D = DR;
+  static_assert(KS % D == 0, "the ring slot of a k-step must be a compile-time constant");
   const int myn = (ch - colw + CW - 1) / CW;            // chunks in which this wave's 32 channels exist
   // buffer loads: one lane offset in a VGPR, everything else ((token, chunk) -> bytes) in the scalar offset -- 64-bit per-load addresses in
   // VGPRs were hoisted out of the chunk loop by the compiler, 256 registers of them
   const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0x7fffffff, 0x00020000);
   const int lane_off = (int)(((long long)(h * 8) * ldb + li) * 4), ldb4 = (int)(ldb * 4);
+  const __amdgpu_buffer_rsrc_t drd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0x7fffffff, 0x00020000);
+  const int dlane_off = (int)(((long long)(h * 4) * ldd + li) * 4), ldd4 = (int)(ldd * 4);
   const unsigned short* pm = sM + (row0 + li) * LDM + h * 8;
   float rb[D][8];
   auto load = [&](int c, int ks, float (&q)[8]) {
@@ -167,25 +172,28 @@ __device__ __forceinline__ void at_gemm_nn(const unsigned short* sM, const float
   for (int i = 0; i < D; ++i) load(0, i, rb[i]);
   // fragments are double buffered: step k's six MFMAs run with the LDS reads, the operand split and the refill loads of step k+1 between them
   bf16x8 Af[2][3], Bf[2][3];
-  auto prep = [&](int cnext, int ks, bf16x8 (&A)[3], bf16x8 (&Bv)[3]) {          // branch-free (one basic block with the MFMAs around it)
+  const int last = myn - 1;
+  // fragments of k-step ks of chunk cb; its ring slot is refilled with the step D further on (same chunk, or the next one -- beyond the last chunk
+  // the last one is reloaded and never consumed)
+  auto prep = [&](int cb, int ks, bf16x8 (&A)[3], bf16x8 (&Bv)[3]) {             // branch-free (one basic block with the MFMAs around it)
 #pragma unroll
     for (int p = 0; p < 3; ++p) A[p] = *reinterpret_cast<const bf16x8*>(pm + p * AT_ROWS * LDM + ks * 16);
-    float (&q)[8] = rb[ks];
+    float (&q)[8] = rb[ks % D];
     at_split8(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], Bv);
-    load(cnext, ks, q);
+    if (ks + D < KS) load(cb, ks + D, q);
+    else load(min(cb + 1, last), ks + D - KS, q);
   };
-  const int last = myn - 1;
-  prep(min(1, last), 0, Af[0], Bf[0]);
+  prep(0, 0, Af[0], Bf[0]);
 #pragma unroll 1
   for (int c = 0; c < myn; ++c) {
-    const int c1 = min(c + 1, last), c2 = min(c + 2, last);      // beyond the last chunk: reload it (never consumed)
+    const int c1 = min(c + 1, last);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) prep(c1, ks + 1, Af[(ks + 1) & 1], Bf[(ks + 1) & 1]);
-      else prep(c2, 0, Af[0], Bf[0]);
+      if (ks + 1 < KS) prep(c, ks + 1, Af[(ks + 1) & 1], Bf[(ks + 1) & 1]);
+      else prep(c1, 0, Af[0], Bf[0]);
 #ifdef PDAE_AT_PROBE_NNNOMMA
       acc[0] += (float)Af[ks & 1][0][0] + (float)Bf[ks & 1][0][0] + (float)Af[ks & 1][1][1] + (float)Bf[ks & 1][1][1] + (float)Af[ks & 1][2][2] + (float)Bf[ks & 1][2][2];
 #else
@@ -202,8 +210,11 @@ __device__ __forceinline__ void at_gemm_nn(const unsigned short* sM, const float
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
+    // buffer stores: one lane offset in a VGPR, (row of the register, chunk) in the scalar offset -- sixteen 64-bit per-lane addresses were hoisted
+    // out of the chunk loop otherwise
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[(long long)acc_row(r, h) * ldd + c * CW + li] = alpha * acc[r];
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, alpha * acc[r]), drd, dlane_off, (((r & 3) + 8 * (r >> 2)) * ldd4) + c * CW * 4, 0);
   }
 }
 
@@ -371,7 +382,7 @@ __global__ void __launch_bounds__(128 * CG) attn_bwd_kv_kernel(const AttnParams 
   float* dq = P.dqkv + ((long long)n * T + k0 + row0) * ld3 + hd * P.hs + cg * 32;
   at_store_planes<NBW, T>(sM, s, row0, colb, li, h);                                                // P^T
   __syncthreads();
-  at_gemm_nn<NB, CG>(sM, dO + cg * 32, P.C, P.ch, cg * 32, 1.0f, dq + P.ov, ld3, row0, li, h);       // dV = P^T dO
+  at_gemm_nn<NB, CG, (NB == 4 ? 8 : NB * 4)>(sM, dO + cg * 32, P.C, P.ch, cg * 32, 1.0f, dq + P.ov, ld3, row0, li, h);       // dV = P^T dO
   __syncthreads();
   at_store_planes<NBW, T>(sM, dp, row0, colb, li, h);                                               // dS^T
   __syncthreads();

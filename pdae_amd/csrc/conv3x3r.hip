@@ -35,7 +35,11 @@
 #define RBN 128
 #define RROWS 384                                           // pixel rows allocated per LDS plane: every staging slot (12 x 32) has a home, no store guard
 #define RPLANE_B (PPLANE(RROWS) * 2)                        // bytes per LDS plane (30720)
-#define RCV0 22                                             // first unit of a main chunk that converts + stores a prefetched float4
+// units of a main chunk that convert + store a prefetched float4: the three loads issued at unit 6 g are converted at units 6 g + 10 .. + 12, so
+// that at most two load groups (24 registers) are live at a time -- with all twelve converted behind the last load (units 22 .. 33) the 48
+// registers of the whole patch were live at once and the fused-GroupNorm instantiation spilled 20 VGPRs to scratch (68 bytes per lane)
+#define RCV_AT(U) ((U) >= 10 && ((U) - 10) % 6 < 3 && ((U) - 10) / 6 < 4)
+#define RCV_SLOT(U) ((((U) - 10) / 6) * 3 + ((U) - 10) % 6)
 #define ROOB 0xFFFFFFF0u                                    // per-lane buffer offset beyond every resource: load -> 0, store -> dropped
 
 typedef unsigned r_u32x4 __attribute__((ext_vector_type(4)));
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(RTHREADS, 1) conv3x3r_kernel(const PatchParams
       PDAE_R_PD(if ((FIRST) && (U) % 4 == 0 && (U) < 32) drain_L((U) / 4);                                  \
       if ((FIRST) && (U) % 4 == 1 && (U) >= 5 && (U) < 37) drain_W(((U) - 5) / 4);                          \
       if ((FIRST) && (U) % 4 == 2 && (U) >= 6 && (U) < 38) drain_S(((U) - 6) / 4);)                         \
-      PDAE_R_PC(if ((U) >= RCV0 && (U) < RCV0 + RLD) convert_store((U) - RCV0);)                            \
+      PDAE_R_PC(if (RCV_AT(U)) convert_store(RCV_SLOT(U));)                            \
       mma(fa[(U) & 1], qb[s_ % 3], u_, (FIRST) && s_ == 0);                                                 \
       PDAE_R_PATTERN(5)                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \

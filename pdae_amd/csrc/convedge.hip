@@ -226,22 +226,28 @@ __global__ void __launch_bounds__(256, 2) edge_in_kernel(const EdgeInParams P) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) { const e_u32x4 q = {w0[p], w1[p], w2[p], w3[p]}; A[s][p] = __builtin_bit_cast(bf16x8, q); }
       }
-      f32x16 acc[NT];
+      // channel tiles in groups of two: accumulate, then store (four live accumulator tiles next to the prefetched patch spilled two VGPRs
+      // in the <3, 4> instantiation; the sums are the same)
+      constexpr int NTG = NT < 2 ? NT : 2;
+#pragma unroll 1
+      for (int ng = 0; ng < NT; ng += NTG) {
+      f32x16 acc[NTG];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
+      for (int ni = 0; ni < NTG; ++ni) {
+        const int nt = ng + ni;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           bf16x8 B[3];
 #pragma unroll
           for (int p = 0; p < 3; ++p) B[p] = __builtin_bit_cast(bf16x8, sB[((nt * 2 + s) * 3 + p) * 64 + l]);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][1], B[1], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][0], B[2], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][2], B[0], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][0], B[1], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][1], B[0], acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][0], B[0], acc[nt], 0, 0, 0);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][1], B[1], acc[ni], 0, 0, 0);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][0], B[2], acc[ni], 0, 0, 0);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][2], B[0], acc[ni], 0, 0, 0);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][0], B[1], acc[ni], 0, 0, 0);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][1], B[0], acc[ni], 0, 0, 0);
+          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s][0], B[0], acc[ni], 0, 0, 0);
         }
       }
       // accumulator row r of this lane = pixel (rtile * 2 + row / 16, row % 16), column = channel: 32 lanes = one 128-byte line.
@@ -250,18 +256,20 @@ __global__ void __launch_bounds__(256, 2) edge_in_kernel(const EdgeInParams P) {
       const unsigned lane_off = (unsigned)((kh * 4 * Nout + ln) * 4);
       const bool full = y0 + ET <= P.H && x0 + ET <= P.W;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
+      for (int ni = 0; ni < NTG; ++ni) {
+        const int nt = ng + ni;
         const float bv = P.bias ? P.bias[n0 + nt * 32 + ln] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dyy = r >> 3, dxu = 8 * ((r >> 2) & 1) + (r & 3);                 // pixel column = dxu + kh * 4
           float* dst = reinterpret_cast<float*>(ub + ((size_t)(dyy * P.W + dxu) * Nout + nt * 32) * 4 + lane_off);
           if (full || (y0 + rtile * 2 + dyy < P.H && x0 + dxu + kh * 4 < P.W)) {
-            float v = acc[nt][r] + bv;
+            float v = acc[ni][r] + bv;
             if (P.accumulate) v += *dst;
             *dst = v;
           }
         }
+      }
       }
     }
     if (more) commit(patch[cur ^ 1]);

@@ -70,19 +70,26 @@ class EpochOrder:
     length by wrapping around) plus the per-image coin of RandomHorizontalFlip (dataset/ffhq.py:22-23).  Pure numpy: the multi-rank behaviour is
     tested on CPU (tests/test_host_cpu.py)."""
 
-    def __init__(self, length, rank=0, world_size=1, seed=0, shuffle=True, flip=True):
+    def __init__(self, length, rank=0, world_size=1, seed=0, shuffle=True, flip=True, drop_tail=False):
         if not (0 <= rank < world_size):
             raise ValueError(f"rank {rank} outside world of {world_size}")
         self.length, self.rank, self.world, self.seed = int(length), int(rank), int(world_size), int(seed)
         self.shuffle, self.flip = bool(shuffle), bool(flip)
-        self.per_rank = (self.length + self.world - 1) // self.world
+        # drop_tail: the TRAINING sampler of the reference is DistributedSampler(drop_last=True) (base_trainer.py:73-78): the len % world tail of the
+        # permutation is dropped, floor(len / world) images per rank, no image twice in an epoch.  The evaluator's sampler
+        # (sampler/autoencoding_eval.py:26-43, drop_last=False) pads by wrapping around: ceil(len / world) per rank, every image visited.
+        self.drop_tail = bool(drop_tail)
+        self.per_rank = self.length // self.world if self.drop_tail else (self.length + self.world - 1) // self.world
 
     def indices(self, epoch):
-        """This rank's image indices of `epoch` (every rank the same count; the union over ranks covers the dataset)."""
+        """This rank's image indices of `epoch` (every rank the same count; the union over ranks covers the dataset, minus the dropped tail)."""
         order = np.random.default_rng([self.seed, epoch]).permutation(self.length) if self.shuffle else np.arange(self.length)
-        pad = self.per_rank * self.world - self.length
-        if pad:
-            order = np.concatenate([order, order[:pad]])
+        if self.drop_tail:
+            order = order[:self.per_rank * self.world]
+        else:
+            pad = self.per_rank * self.world - self.length
+            if pad:
+                order = np.concatenate([order, order[:pad]])
         return order[self.rank::self.world]
 
     def flips(self, epoch, start, count):
@@ -114,7 +121,9 @@ class DeviceImagePipeline:
         self._tabs = [torch.from_numpy(a).to(dev) for a in (kx, bx, ky, by)]
         self._ks = (kx.shape[1], ky.shape[1])
         # shuffling is a property of the split (train: yes, eval / inference: no), the mirror flip of `augmentation` (dataset/ffhq.py:21-23)
-        self.order = EpochOrder(len(self.images), rank, world_size, seed, shuffle=bool(config.get("shuffle", shuffle)), flip=self.augmentation)
+        # drop_last pipelines are the training ones: their sampler also drops the len % world tail (EpochOrder.drop_tail)
+        self.order = EpochOrder(len(self.images), rank, world_size, seed, shuffle=bool(config.get("shuffle", shuffle)), flip=self.augmentation,
+                                drop_tail=self.drop_last)
         self.rank, self.world, self.seed, self.epoch = rank, world_size, seed, 0
         self._batch = None
         self._stream = torch.cuda.Stream(device=dev)
@@ -168,7 +177,7 @@ class DeviceImagePipeline:
         """Next batch of this rank's epoch share: `batch_size` images, or the ragged remainder of the epoch when the pipeline was built with
         drop_last=False (read the size off x_0).  `out`: optional float32 destination (any strides, e.g. the NHWC plan buffer viewed as (B,C,S,S))."""
         if self._thread is None:
-            if batch_size > len(self.order.indices(0)):
+            if batch_size > len(self.order.indices(0)) and self.drop_last:      # without drop_last a short share is served as one ragged batch
                 raise ValueError(f"batch of {batch_size} images but this rank's share of the dataset holds {len(self.order.indices(0))}")
             self._batch = int(batch_size)
             self._slots = self._alloc(batch_size)

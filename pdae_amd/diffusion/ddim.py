@@ -10,6 +10,7 @@ What is different from the reference:
     path with identical arithmetic);
   * loops on planned networks poll the fp16-window guard once at their end and re-run in bf16x6 if it fired (hip.SaturationGuard).
 """
+import os
 import sys
 
 import numpy as np
@@ -51,6 +52,7 @@ class DDIM:
             a = self._host["alphas_cumprod_" + tag]
             self._host["to_" + tag] = np.stack([np.sqrt(a), np.sqrt(np.float32(1.0) - a)], 1).astype(np.float32)
         self._rows = {}
+        self.ops_run = 0          # op records issued by the planned loops of this object (diagnostic: tests count the eps-only steps with it)
 
     @staticmethod
     def extract_coef_at_t(schedule, t, x_shape):
@@ -134,6 +136,9 @@ class DDIM:
             if condition is not None and getattr(p, "cond", None) is not None:
                 p.cond.copy_(condition)
             shift = getattr(p, "shift", None)
+            # steps whose shift term is discarded (use_shift(i) False) run the eps half alone, when the network offers that op list
+            pe = net.plan_eps(N, Hh, W) if (shift is not None and z_mix is None and hasattr(net, "plan_eps") and os.environ.get("PDAE_DDIM_EPS_ONLY", "1") != "0"
+                                            and any(not use_shift(i) for i in steps)) else None
             keep_eps = keep_g = None
             if z_mix is not None:
                 keep_eps, keep_g = torch.empty_like(p.eps), torch.empty_like(p.shift)
@@ -142,7 +147,17 @@ class DDIM:
             fresh = True                               # first step: loop-invariant prefix (z-only ops) and the weight preparation run too
             for i in steps:
                 p.t.fill_(self._map_host[i])
-                p.run(0 if fresh else getattr(p, "n_const", 0), p.n_fwd, prep=fresh)
+                if pe is not None and not use_shift(i):
+                    pe.run(0, pe.n_fwd)                # same x / t buffers; frozen weights only: nothing to prepare per run
+                    self.ops_run += pe.n_fwd
+                    c_shift, ra, rm1, sab, s1ab = self._coefs(i, encode)
+                    ops.ddim_step(p.x, pe.eps, None, c_shift, ra, rm1, sab, s1ab, out=p.x)
+                    if trajectory is not None:
+                        trajectory.append(p.x.clone().permute(0, 3, 1, 2))
+                    continue
+                first = 0 if fresh else getattr(p, "n_const", 0)
+                p.run(first, p.n_fwd, prep=fresh)
+                self.ops_run += p.n_fwd - first
                 fresh = z_mix is not None              # trajectory interpolation swaps z inside the step: nothing is invariant
                 eps, g = p.eps, (shift if (shift is not None and use_shift(i)) else None)
                 if z_mix is not None:

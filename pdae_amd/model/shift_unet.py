@@ -72,6 +72,27 @@ class ShiftUNet(PlannedNet):
         self._plans[key] = p
         return p
 
+    def plan_eps(self, N, Hh, W):
+        """Sampling plan of the frozen half alone: the eps prediction of the pre-trained UNet (time_embed, input_blocks, middle_block,
+        output_blocks, out) on the SAME x / t buffers as plan(N, Hh, W, False), and none of the shift branch's ops.  The last
+        stop_percent * N steps of shift_ddim_sample_loop discard the shift term (diffusion/ddim.py:94-96,115,119 of the reference: the decoder
+        still runs there and `g` is dropped); a DDIM loop on planned networks runs this op list on those steps instead -- 43 % fewer decoder
+        FLOPs on 30 % of the steps of latent_diffusion_sample (gaussian_diffusion.py:415, stop_percent 0.3).  Same kernels on the same
+        shapes as the eps half of the full plan: the eps tensor is bit-identical (tests/test_diffusion_gpu.py)."""
+        key = (N, Hh, W, "eps")
+        pl = self._plans.get(key)
+        if pl is not None:
+            return pl
+        full = self.plan(N, Hh, W, False)
+        p = Plan(self.device)
+        B = Builder(p, self.P, None, save=False, drop_p=0.0, frozen_of=self)
+        fx = G.unet_forward(B, self.cfg, full.x, full.t, self.freqs, shift=False)
+        p.n_fwd = len(p.recs)
+        p.x, p.t, p.z, p.eps, p.shift = full.x, full.t, None, fx.eps, None
+        p.compile()
+        self._plans[key] = p
+        return p
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, time, condition):
         N, _, Hh, W = x.shape

@@ -49,7 +49,10 @@ class Sampler:
             while done < mine:
                 n = min(bs, mine - done)
                 x_0 = self.dataset.batch(bs if order is not None else n, self.device)["x_0"]
-                n = x_0.shape[0]                   # a device pipeline serves its epoch share in batches of bs and a ragged last one
+                # a device pipeline serves its epoch share in batches of bs and a ragged last one; with an explicit num_images the rank stops at
+                # its dispatched share (the last batch is cut, not scored whole)
+                x_0 = x_0[:min(x_0.shape[0], mine - done)]
+                n = x_0.shape[0]
                 rec = self.gaussian_diffusion.representation_learning_autoencoding(encoder_style, decoder_style, self.encoder, self.decoder, x_0)
                 # one fused kernel: (x+1)/2 of both batches, SSIM and MSE per image (autoencoding_eval.py:83-88 + metric/utils.py:35-63)
                 s, m = ssim_mse(x_0, rec, denormalize=True)

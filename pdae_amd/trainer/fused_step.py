@@ -138,7 +138,13 @@ class _FusedStep:
             p.set_dropout(random.getrandbits(31), self.step_count * self.num_iterations + self.micro)   # host RNG: no device sync
         last = self.micro == self.num_iterations - 1
         if last and (self.world > 1 or self.ncomm is not None):
-            self.backward_with_allreduce(p.run)
+            try:
+                self.backward_with_allreduce(p.run)
+            except (RuntimeError, H.PdaeError):
+                if self.num_iterations != 1 or not getattr(self, "_comm_fallback", False):
+                    raise
+                self.comm_retries = getattr(self, "comm_retries", 0) + 1
+                self.backward_with_allreduce(p.run)          # fall-back path: the whole forward + backward again, then one all-reduce per buffer
         else:
             p.run(0, self.n_bwd)
         self.micro += 1
@@ -153,8 +159,12 @@ class _FusedStep:
         """Issues the forward+backward op list in segments; as soon as a bucket's gradients are final its all-reduce(sum) is
         launched asynchronously (RCCL stream), overlapping with the rest of the backward.  `run(first, last)` issues plan ops.
         The saturation word travels with the last bucket (MAX) so that every rank takes the same skip decision.
-        A collective that raises (RCCL init / enqueue error) is reported with the rank and the step falls back -- for good -- to ONE
-        all-reduce per flat gradient buffer after the backward, through the same process group: slower, never a silent hang on this side."""
+        A collective that raises (RCCL init / enqueue error) is reported with the rank, the exchange switches -- for good -- to ONE all-reduce
+        per flat gradient buffer after the backward (same process group), and the exception is RE-RAISED: this step's gradients are partly
+        reduced.  `_run_micro` catches it and re-runs the micro-batch through that fall-back when the plan overwrites its gradients
+        (num_iterations == 1: same batch, same dropout seed, identical gradients); an accumulating plan cannot be repaired and the error
+        reaches the trainer.  Peers of a rank whose enqueue failed leave their outstanding collectives through the process-group timeout
+        (bench.py: PDAE_COMM_TIMEOUT_S) and take the same route; nothing here can unblock them earlier."""
         if getattr(self, "_comm_fallback", False):
             run(0, self.n_bwd)
             for n in self.flat_nets:

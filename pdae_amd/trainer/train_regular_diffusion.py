@@ -45,19 +45,24 @@ class _LoopMixin:
     def _run(self, one_step, samples_per_step):
         rc = self.config["runner_config"]
         display = int(rc["display_steps"])
-        acc = torch.zeros(1, device=self.device)
+        acc, acc_n = torch.zeros(1, device=self.device), 0
         t_top = time.time()
         n_it = int(rc.get("num_iterations", 1))
         while self.max_steps is None or self.step < self.max_steps:
             for _ in range(n_it):                        # micro-batches of one optimizer step (train_regular_diffusion.py:82-110)
                 acc += one_step()
             self.step += 1
+            acc_n += 1
             saving = self.step % int(rc["save_latest_every_steps"]) == 0 or self.step % int(rc["save_checkpoint_every_steps"]) == 0
             if self.step % display == 0 or saving:
                 # fp16-window guard: discarded steps are re-counted, plan -> bf16x6; polled in front of every checkpoint as well
-                self.step -= self.fused.handle_saturation()
-            if self.step % display == 0:
-                loss = float(acc.item()) / display
+                rewound = self.fused.handle_saturation()
+                if rewound:                               # discarded steps: their (possibly non-finite) losses leave the running mean with them
+                    self.step -= rewound
+                    acc.zero_()
+                    acc_n = 0
+            if self.step % display == 0 and acc_n > 0:
+                loss = float(acc.item()) / acc_n
                 if torch.distributed.is_initialized():
                     t = torch.tensor([loss], device=self.device)
                     torch.distributed.all_reduce(t)
@@ -70,6 +75,7 @@ class _LoopMixin:
                     with open(os.path.join(self.run_path, "log.jsonl"), "a") as f:
                         f.write(json.dumps(rec) + "\n")
                 acc.zero_()
+                acc_n = 0
                 t_top = time.time()
             if self.global_rank == 0 and self.step % int(rc["save_latest_every_steps"]) == 0:
                 self.save(os.path.join(self.run_path, "checkpoints", "latest.pt"))

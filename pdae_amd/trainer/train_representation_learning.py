@@ -104,7 +104,7 @@ class RepresentationLearningTrainer:
     def train(self):
         rc = self.config["runner_config"]
         display, n_it = int(rc["display_steps"]), int(rc["num_iterations"])
-        acc = torch.zeros(1, device=self.device)
+        acc, acc_n = torch.zeros(1, device=self.device), 0
         t_top = time.time()
         gen = torch.Generator(device=self.device)
         gen.manual_seed(int(time.time()) + self.global_rank)
@@ -113,14 +113,20 @@ class RepresentationLearningTrainer:
                 batch = self.dataset.batch(self.batch_size, self.device, gen)
                 acc += self.fused.step(batch["x_0"])                    # device-side accumulation: no per-step host sync
             self.step += 1
+            acc_n += 1
             rc_save = (self.step % int(rc["save_latest_every_steps"]) == 0 or self.step % int(rc["save_checkpoint_every_steps"]) == 0
                        or self.step % int(rc["evaluate_every_steps"]) == 0)
             if self.step % display == 0 or rc_save:
                 # fp16-window guard: discarded steps are re-counted, plan -> bf16x6.  Polled at the logging cadence AND in front of every
                 # checkpoint / evaluation, so that no file records a step count or optimizer state that includes a discarded update
-                self.step -= self.fused.handle_saturation()
-            if self.step % display == 0:
-                loss = float(acc.item()) / display
+                rewound = self.fused.handle_saturation()
+                if rewound:
+                    # the discarded steps' losses (possibly inf / nan) are not reported, and the counter was rewound: the running mean restarts
+                    self.step -= rewound
+                    acc.zero_()
+                    acc_n = 0
+            if self.step % display == 0 and acc_n > 0:
+                loss = float(acc.item()) / acc_n
                 if torch.distributed.is_initialized():
                     t = torch.tensor([loss], device=self.device)
                     torch.distributed.all_reduce(t)
@@ -133,6 +139,7 @@ class RepresentationLearningTrainer:
                     with open(os.path.join(self.run_path, "log.jsonl"), "a") as f:
                         f.write(json.dumps(rec) + "\n")
                 acc.zero_()
+                acc_n = 0
                 t_top = time.time()
             if self.global_rank == 0 and self.step % int(rc["save_latest_every_steps"]) == 0:
                 self.save(os.path.join(self.run_path, "checkpoints", "latest.pt"))

@@ -56,6 +56,33 @@ def test_shift_ddim_encode_and_sample_trajectories(setup):
         assert rel_err(x1, g["enc_traj"][0]) < 1e-4
 
 
+def test_stop_percent_steps_run_the_eps_half_alone_bit_identical(setup, monkeypatch):
+    """shift_ddim_sample_loop(stop_percent=0.3) (ddim.py:110-120 of the reference; latent_diffusion_sample, gaussian_diffusion.py:415): on the last
+    30 % of the steps the shift term is discarded.  The planned loop runs the eps half of the decoder alone there (ShiftUNet.plan_eps): the output
+    must be BIT-identical to running the full decoder and dropping g, and exactly 3 of the 10 steps must issue fewer op records."""
+    g, net, gd = setup
+    z, xT = T(g["z"]).to(DEV), T(g["x_T"]).to(DEV)
+    d = gd._ddim("ddim10")
+    with torch.no_grad():
+        monkeypatch.setenv("PDAE_DDIM_EPS_ONLY", "0")
+        before = d.ops_run
+        full = d.shift_ddim_sample_loop(net, z, xT, stop_percent=0.3)
+        ops_full = d.ops_run - before
+        monkeypatch.setenv("PDAE_DDIM_EPS_ONLY", "1")
+        before = d.ops_run
+        tr = []
+        fast = d.shift_ddim_sample_loop(net, z, xT, stop_percent=0.3, trajectory=tr)
+        ops_fast = d.ops_run - before
+        nostop = d.shift_ddim_sample_loop(net, z, xT)
+    assert torch.equal(full, fast)
+    assert len(tr) == 10 and not torch.equal(fast, nostop)
+    p, pe = net.plan(xT.shape[0], xT.shape[2], xT.shape[3], False), net.plan_eps(xT.shape[0], xT.shape[2], xT.shape[3])
+    assert pe.n_fwd < 0.7 * (p.n_fwd - p.n_const), (pe.n_fwd, p.n_fwd, p.n_const)       # the shift branch is ~40 % of the decoder's op records
+    assert ops_full == 10 * (p.n_fwd - p.n_const) + p.n_const
+    assert ops_fast == 7 * (p.n_fwd - p.n_const) + p.n_const + 3 * pe.n_fwd, (ops_fast, ops_full)
+    assert psnr(fast, g["x_rec_stop"]) > 80
+
+
 def test_autoencoding_protocol_ssim_mse_three_decimals(setup):
     """README.md:120 protocol on the tiny net: encode ddim1000 (999 steps) then decode ddim100; SSIM / MSE on (x+1)/2."""
     from pdae_amd.metric import calculate_ssim, calculate_mse

@@ -93,6 +93,13 @@ def test_epoch_order_partitions_every_epoch_across_ranks():
     f0, f1 = EpochOrder(L, 0, W, seed=5).flips(0, 0, 256), EpochOrder(L, 1, W, seed=5).flips(0, 0, 256)
     assert not np.array_equal(f0, f1) and 64 < int(f0.sum()) < 192
     assert int(EpochOrder(L, 0, W, seed=5, flip=False).flips(0, 0, 64).sum()) == 0
+    # training order: DistributedSampler(drop_last=True) of base_trainer.py:73-78 drops the len % world tail -- floor(len / world)
+    # images per rank, no image twice in an epoch; only the evaluator's order pads
+    for epoch in (0, 3):
+        shares = [EpochOrder(L, r, W, seed=5, drop_tail=True).indices(epoch) for r in range(W)]
+        assert all(len(s) == L // W for s in shares) and EpochOrder(L, 0, W, drop_tail=True).per_rank == L // W
+        allidx = np.concatenate(shares)
+        assert len(set(allidx.tolist())) == len(allidx) == (L // W) * W
 
 
 def test_trainers_and_sampler_hand_their_rank_to_the_dataset(monkeypatch):
@@ -180,3 +187,26 @@ def test_sampling_plan_has_a_pinned_latent_only_prefix(monkeypatch):
     net = ShiftUNet(device="cpu", latent_dim=512, **C.CFG_SHIFT_64)
     net.set_train_mode()
     assert net.plan(2, 64, 64, True).n_const == 0
+
+
+def test_eps_only_sampling_plan_shares_the_input_buffers_and_has_no_shift_ops():
+    """ShiftUNet.plan_eps (the steps of shift_ddim_sample_loop whose shift term is discarded, reference diffusion/ddim.py:94-96,115,119): the eps half
+    alone on the x / t buffers of the full sampling plan -- same convolution records as the eps half of the full plan, none of the shift
+    branch's, no latent input, nothing to prepare per run.  Built on the CPU: records only."""
+    from pdae_amd import hip as H
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from tests.golden import make_fixtures_cfg as C
+    net = ShiftUNet(device="cpu", latent_dim=512, **C.CFG_SHIFT_64)
+    net.set_eval_mode()
+    full, pe = net.plan(2, 64, 64, False), net.plan_eps(2, 64, 64)
+    assert pe is net.plan_eps(2, 64, 64) and pe.x is full.x and pe.t is full.t and pe.z is None and pe.shift is None
+    assert pe.n_const == 0 and not pe.wprep_jobs and pe.pre_arr is None          # frozen weights only: prepared once (init ops), never per run
+    conv_kinds = (H.OP_CONV_FWD, H.OP_CONV_FWD_GN, H.OP_CONV_FWD_SKIP)
+    n_full = sum(1 for r in full.recs[:full.n_fwd] if r.kind in conv_kinds)
+    n_eps = sum(1 for r in pe.recs if r.kind in conv_kinds)
+    # the full plan runs trunk + eps branch + shift branch; the shift branch mirrors the eps branch (middle + output blocks + head)
+    assert 0.5 * n_full < n_eps < 0.75 * n_full, (n_eps, n_full)
+    assert pe.n_fwd == len(pe.recs) < 0.75 * (full.n_fwd - full.n_const)
+    # x is an input of both op lists and must never have been handed back to either buffer pool
+    for pl in (full, pe):
+        assert all(t is not full.x and t is not full.t for ts in pl.pool.values() for t in ts)

@@ -1,0 +1,70 @@
+"""CPU: no hot kernel may spill to scratch memory.
+
+hipcc's `-Rpass-analysis=kernel-resource-usage` remarks are the compiler's own account of every kernel of a translation unit (registers,
+spills, scratch bytes per lane).  A spill inside a 432-MFMA chunk body is a scratch load / store on the critical path of kernels that
+run at the chip's power limit; round 3 shipped `conv3x3r_kernel<4, true>` with 68 bytes per lane and
+`attn_bwd_kv_kernel<4, 4>` with 184 without any test noticing.  This test compiles the hot sources exactly as pdae_amd/build.py does and
+asserts `ScratchSize == 0` for every kernel in them (the instantiations the F128 / C64 plans launch are a subset), except the ones listed
+in ALLOWED with the reason.  `tools/kernel_resources.py` prints the same table by hand."""
+import os
+import re
+import subprocess
+import tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from pdae_amd import build as B
+
+HOT = ["conv3x3r.hip", "conv3x3p.hip", "conv3x3w.hip", "conv1x1.hip", "attention.hip", "convedge.hip", "norm.hip", "winograd.hip"]
+# kernel-name regex -> why a scratch allocation is tolerated there
+ALLOWED = {
+    r"conv3x3p_kernelILi3ELi16ELb0ELb1E": "bf16x6 fallback arithmetic (PDAE_CONV_MATH=bf16x6 / after a saturation event), 16-row tiles: 8 bytes, not on the default path",
+}
+
+
+def resource_table(src):
+    """[{name, vgpr, agpr, sgpr_spill, vgpr_spill, scratch, occupancy}] of every kernel in csrc/<src>."""
+    with tempfile.TemporaryDirectory() as td:
+        cmd = [B.HIPCC] + B.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(B.CSRC, src), "-o", os.path.join(td, "o.o")]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows, cur = [], None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark:\s+(.*?) \[-Rpass", line)
+        if not m:
+            continue
+        t = m.group(1).strip()
+        if t.startswith("Function Name:"):
+            cur = {"name": t.split(":", 1)[1].strip()}
+            rows.append(cur)
+        elif cur is not None and ":" in t:
+            k, v = t.split(":", 1)
+            cur[k.strip()] = v.strip()
+    out = []
+    for c in rows:
+        out.append(dict(name=c["name"], vgpr=int(c.get("VGPRs", 0)), agpr=int(c.get("AGPRs", 0)), sgpr_spill=int(c.get("SGPRs Spill", 0)),
+                        vgpr_spill=int(c.get("VGPRs Spill", 0)), scratch=int(c.get("ScratchSize [bytes/lane]", 0)),
+                        occupancy=int(c.get("Occupancy [waves/SIMD]", 0)), lds=int(c.get("LDS Size [bytes/block]", 0))))
+    return out
+
+
+@pytest.mark.timeout(900)
+def test_hot_kernels_use_no_scratch_memory():
+    srcs = [s for s in HOT if os.path.exists(os.path.join(B.CSRC, s))]
+    assert len(srcs) >= 7
+    with ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        tables = dict(zip(srcs, ex.map(resource_table, srcs)))
+    bad, n = [], 0
+    for src, rows in tables.items():
+        assert rows, f"no kernels reported for {src}"
+        for k in rows:
+            n += 1
+            if k["scratch"] > 0 and not any(re.search(p, k["name"]) for p in ALLOWED):
+                bad.append((src, k["name"], k["scratch"], k["vgpr_spill"]))
+    assert n > 60
+    assert not bad, f"kernels with scratch memory (source, kernel, bytes per lane, spilled VGPRs): {bad}"
+    # the instantiations the F128 training / sampling plans launch most (profiles/r03_kernel_stats.txt) must be in the table at all
+    names = " ".join(k["name"] for rows in tables.values() for k in rows)
+    for must in ("conv3x3r_kernelILi4ELb1E", "conv3x3r_kernelILi4ELb0E", "attn_bwd_kv_kernelILi4ELi4E", "conv3x3w_kernelILi4E", "conv1x1_kernelILi4E"):
+        assert must in names, must
