@@ -29,7 +29,7 @@ extern "C" {
 typedef void* pdae_stream_t; /* hipStream_t */
 
 const char* pdae_last_error(void);
-int pdae_abi_version(void);   /* 5: + pdae_subsample2 / pdae_zero_insert2; 4: + pdae_conv_wprep_job / _group (3: + pdae_conv_stats_* / pdae_gn_coef_from_conv_stats; 2: saturation counter, row-coefficient samplers, fused attention, RCCL) */
+int pdae_abi_version(void);   /* 6: + pdae_wino_*; 5: + pdae_subsample2 / pdae_zero_insert2; 4: + pdae_conv_wprep_job / _group (3: + pdae_conv_stats_* / pdae_gn_coef_from_conv_stats; 2: saturation counter, row-coefficient samplers, fused attention, RCCL) */
 
 /* ---- convolution (F.conv2d / conv1d k=1: module.py:242,265,276,412,420; unet.py:62,174; encoder/ffhq.py:12-30) */
 typedef struct pdae_conv_desc {
@@ -103,6 +103,14 @@ int pdae_conv_wprep_group(const pdae_wprep_job* jobs_dev, const int32_t* first_b
 int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
                          const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps, const float* bias_s, float* y,
                          pdae_stream_t stream);
+/* Winograd F(2x2, 3x3) forward convolution for WEIGHT-CONSTANT 3x3 / stride-1 / pad-1 layers in the f16x3 arithmetic (math 4): 16 instead of 36
+ * products per 2 x 2 outputs (F.conv2d of module.py:242,265, unet.py:62,174 where the weights do not change between launches: the frozen trunk
+ * and eps branch of ShiftUNet, every convolution of a sampling pass).  pdae_wino_wprep_bytes: size of the transformed weights
+ * U = G g G^T (two fp16 planes in MFMA-fragment order), or 0 when d is not eligible (single source, C0 % 16 == 0, Ho, Wo % 16 == 0,
+ * Cout % 64 == 0); pdae_wino_wprep writes them from w [Cout][3][3][Cin]; pdae_wino_fwd: y[N,Ho,Wo,Cout] = conv(x) + bias. */
+size_t pdae_wino_wprep_bytes(const pdae_conv_desc* d);
+int pdae_wino_wprep(const pdae_conv_desc* d, const float* w, void* wp, pdae_stream_t stream);
+int pdae_wino_fwd(const pdae_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, pdae_stream_t stream);
 /* GroupNorm statistics of a convolution's OUTPUT, produced by the convolution while it stores the tensor -- the GroupNorm that follows
  * (module.py:241,257: in_layers / out_layers norm of the next stage) then needs no pass over the tensor at all:
  *   bytes = pdae_conv_stats_bytes(d, ds, &tpi)   size of the partial-sum buffer, 0 when the forward convolution of d (with the fused skip

@@ -9,6 +9,7 @@
 #include "igemm.h"
 #include "kernels.h"
 #include "conv3x3p.h"
+#include "winograd.h"
 
 static thread_local char g_err[512] = "";
 
@@ -20,7 +21,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 5; }
+extern "C" int pdae_abi_version(void) { return 6; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -235,6 +236,27 @@ extern "C" size_t pdae_conv_stats_bytes(const pdae_conv_desc* d, const pdae_conv
   if (tiles_per_image) *tiles_per_image = b ? tpi : 0;
   return b;
 }
+// ---- Winograd F(2x2, 3x3) forward convolution of weight-constant layers (winograd.hip)
+static bool wino_desc_ok(const pdae_conv_desc* d) {
+  return wino_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->up, d->C0, d->C1, d->Ho, d->Wo, d->N, d->Cout);
+}
+extern "C" size_t pdae_wino_wprep_bytes(const pdae_conv_desc* d) {
+  if (!d || check_desc(d) || !wino_desc_ok(d)) return 0;
+  return wino_wprep_bytes(d->Cout, d->C0);
+}
+extern "C" int pdae_wino_wprep(const pdae_conv_desc* d, const float* w, void* wp, pdae_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  PDAE_CHECK_ARG(w && wp, "wino_wprep: null pointer");
+  PDAE_CHECK_ARG(wino_desc_ok(d), "wino_wprep: convolution not eligible (3x3 / stride 1 / pad 1, math f16x3, one source, C %% 16 == 0, H, W %% 16 == 0, Cout %% 64 == 0)");
+  return wino_wprep(w, d->Cout, d->C0, (unsigned short*)wp, S(stream));
+}
+extern "C" int pdae_wino_fwd(const pdae_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, pdae_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  PDAE_CHECK_ARG(x && wp && y, "wino_fwd: null pointer");
+  PDAE_CHECK_ARG(wino_desc_ok(d), "wino_fwd: convolution not eligible (pdae_wino_wprep_bytes returned 0)");
+  return wino_fwd(x, d->N, d->Ho, d->Wo, d->C0, (const unsigned short*)wp, d->Cout, bias, y, S(stream));
+}
+
 extern "C" int pdae_conv_stats_arm(float* part) {
   conv3x3p_arm_stats(part);
   return PDAE_OK;

@@ -97,6 +97,12 @@ def lib():
         L.pdae_image_prepare.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 9 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                                                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.pdae_wino_wprep_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.pdae_wino_wprep_bytes.restype = ctypes.c_size_t
+        L.pdae_wino_wprep.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.pdae_wino_wprep.restype = ctypes.c_int
+        L.pdae_wino_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [ctypes.c_void_p] * 5
+        L.pdae_wino_fwd.restype = ctypes.c_int
         L.pdae_set_saturation_counter.argtypes = [ctypes.c_void_p]
         L.pdae_set_saturation_counter.restype = ctypes.c_int
         _lib = L
@@ -104,7 +110,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_wino_wprep_bytes", "pdae_wino_wprep", "pdae_wino_fwd", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_subsample2", "pdae_zero_insert2", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_bwd_group", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
@@ -296,6 +302,28 @@ def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0, wp_
 def op_amax(x, n, out):
     """out[0] = max |x| (device scalar): feeds the power-of-two dY scale of the fp16-format gradient kernels."""
     return make_op(OP_AMAX, [x, out], [n])
+
+
+def wino_wprep_bytes(c):
+    """Size of the Winograd-transformed weights of conv c (0: not eligible; pdae_wino_wprep_bytes)."""
+    d = c.cdesc()
+    return int(lib().pdae_wino_wprep_bytes(ctypes.byref(d)))
+
+
+def wino_wprep(c, w, wp, stream=None):
+    d = c.cdesc()
+    rc = lib().pdae_wino_wprep(ctypes.byref(d), ctypes.c_void_p(_ptr(w)), ctypes.c_void_p(_ptr(wp)), ctypes.c_void_p(current_stream_ptr() if stream is None else stream))
+    if rc != 0:
+        raise PdaeError(f"pdae_wino_wprep failed ({rc}): {lib().pdae_last_error().decode()}")
+
+
+def wino_fwd(c, x, wp, bias, y, stream=None):
+    """y = conv3x3(x) + bias through the Winograd F(2x2, 3x3) kernel (pdae_wino_fwd); wp from wino_wprep."""
+    d = c.cdesc()
+    rc = lib().pdae_wino_fwd(ctypes.byref(d), ctypes.c_void_p(_ptr(x)), ctypes.c_void_p(_ptr(wp)), ctypes.c_void_p(_ptr(bias) if bias is not None else None),
+                             ctypes.c_void_p(_ptr(y)), ctypes.c_void_p(current_stream_ptr() if stream is None else stream))
+    if rc != 0:
+        raise PdaeError(f"pdae_wino_fwd failed ({rc}): {lib().pdae_last_error().decode()}")
 
 
 def op_conv_wprep(c, w, transposed, wp):
