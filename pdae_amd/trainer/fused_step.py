@@ -179,7 +179,8 @@ class _FusedStep:
             print(f"[pdae_amd] rank {rank}: bucketed gradient exchange failed ({type(e).__name__}: {e}); falling back to one all-reduce per "
                   "gradient buffer after the backward", file=sys.stderr, flush=True)
             self._comm_fallback, self.ncomm = True, None
-            torch.cuda.synchronize()
+            if self.flat_nets[0].device.type == "cuda":
+                torch.cuda.synchronize()
             raise                                             # this step's gradients are in an unknown state: the caller decides (bench: retry)
 
     def _bucketed(self, run):

@@ -47,8 +47,18 @@ def test_bench_self_launches_two_ranks_dry():
     assert out["n_gpus"] == 2 and out["dry"] is True and out["steps"] == 2 and out["scaling"] == "weak"
     c = out["comm"]
     assert c["rccl_ranks"] == 2 and c["buckets"] >= 2 and sum(c["bucket_bytes"]) == c["grad_bytes_per_step"]
-    assert set(c["bucket_sweep_ms_per_step"]) == {"16", "48", "96"}
+    # default: a fixed 48 MB bucket and NO sweep (an 8-rank driver run reaches its timed region right behind the warm-up steps);
+    # every rank's own clock is reported, and which exchange path ran
+    assert c["bucket_mb"] == 48.0 and c["bucket_sweep_ms_per_step"] is None
+    assert len(c["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in c["per_rank_ms_per_step"]) and c["exchange_path"].startswith("bucketed")
+    assert abs(out["ms_per_step"] - max(c["per_rank_ms_per_step"])) < 1e-2
     assert out["config"]["global_batch"] == 2 * out["config"]["per_gpu_batch"]
+    # --bucket-mb 0: the sweep over 16 / 48 / 96 MB runs first
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry", "--steps", "1", "--warmup", "1", "--bucket-mb", "0"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["comm"]
+    assert set(c["bucket_sweep_ms_per_step"]) == {"16", "48", "96"} and c["bucket_mb"] in (16.0, 48.0, 96.0)
 
 
 def test_bench_workload_comes_from_the_yaml_files():

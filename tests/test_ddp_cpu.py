@@ -101,3 +101,68 @@ def test_dispatch_num_samples_matches_reference_table():
     assert d(5, 5, 4) == 1 and d(7, 1, 0) == 7
     with pytest.raises(AssertionError):
         d(3, 4, 0)
+
+
+def _retry_worker(q, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from pdae_amd.model.shift_unet import ShiftUNet
+        from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
+        from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+        from pdae_amd.trainer.fused_step import FusedRLStep
+        gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device("cpu"))
+
+        def make(num_iterations):
+            enc = CELEBA64Encoder(device="cpu", latent_dim=512)
+            dec = ShiftUNet(device="cpu", latent_dim=512, **C.CFG_SHIFT_64)
+            dec.set_train_mode()
+            st = FusedRLStep(gd, enc, dec, copy.deepcopy(enc), copy.deepcopy(dec), 2, 64, 64, bucket_mb=1, num_iterations=num_iterations)
+            st.world = 2                                   # take the collective path (the group itself has one rank: all-reduce = identity)
+            runs = []
+            st.plan.run = lambda first=0, last=None, stream=None, prep=True: runs.append((first, last))
+            boom = {"n": 0}
+            orig = st._bucketed
+
+            def failing(run):
+                boom["n"] += 1
+                if boom["n"] == 1:
+                    run(0, 5)                                  # part of the backward has been issued when the collective raises
+                    raise RuntimeError("simulated RCCL enqueue error")
+                return orig(run)
+            st._bucketed = failing
+            return st, runs
+        # num_iterations == 1: the plan overwrites its gradients -> the micro-batch is re-run through the post-backward fallback, nothing raised
+        st, runs = make(1)
+        st._run_micro()
+        assert st._comm_fallback and st.comm_retries == 1 and st.step_count == 1
+        assert (0, st.n_bwd) in runs and runs[-1] == (st.n_bwd, st.plan.n)          # whole forward + backward again, then the optimizer ops
+        st._run_micro()                                                              # later steps stay on the fallback, no further retries
+        assert st.comm_retries == 1 and st.step_count == 2
+        # accumulating plans cannot be repaired: the error reaches the trainer
+        st2, _ = make(2)
+        st2._run_micro()
+        try:
+            st2._run_micro()
+            q.put("accumulating plan did not raise")
+            return
+        except RuntimeError as e:
+            assert "simulated" in str(e)
+        q.put("ok")
+    except Exception:                             # noqa: BLE001
+        import traceback
+        q.put(traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_failed_bucketed_exchange_is_retried_through_the_fallback_when_the_plan_overwrites_its_gradients():
+    """backward_with_allreduce re-raises after switching to the fall-back; _run_micro re-runs the micro-batch through it when
+    num_iterations == 1 (gradients are overwritten, same dropout seed) and lets the error through for accumulating plans."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_retry_worker, args=(q, _free_port()))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res == "ok", res

@@ -188,6 +188,13 @@ def test_two_processes_one_gpu_real_collective_bucketed_step(tmp_path):
     _check_against_single_process(_launch_ranks(tmp_path, "gloo", native=False))
 
 
+def test_four_processes_one_gpu_real_collective_bucketed_step(tmp_path):
+    """World size 4 (bucket boundaries, the 1 / world folded into Adam and the saturation-word MAX with world != 2): four OS
+    processes share GPU 0, one image each, gloo all-reduce per bucket.  Ranks bit-identical; equal to one process on the four-image batch."""
+    res = _launch_ranks(tmp_path, "gloo", native=False, steps=2, per_rank=1, world=4)
+    _check_against_single_process(res, steps=2, n=4)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL places one rank per device)")
 @pytest.mark.parametrize("native", [False, True], ids=["torch_nccl", "native_rccl"])
 def test_two_gpus_rccl_both_exchange_backends(tmp_path, native):
