@@ -94,13 +94,14 @@ extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flag
   PDAE_CHECK_ARG(w && wp, "conv_wprep: null pointer");
   if (flags & PDAE_WPREP_GN) {
     PDAE_CHECK_ARG(!transposed && gn_patch_ok(d, false), "conv_wprep: convolution not eligible for the fused-GroupNorm patch kernel");
-    return conv3x3p_wprep(d->math, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, S(stream));
+    return conv3x3p_wprep(d->math, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, S(stream), d->Ho, d->Wo, d->N);
   }
   const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
+  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;       // the data gradient's output grid
   PDAE_CHECK_ARG(kind != 0, "conv_wprep: convolution shape not eligible for a prepared-weight kernel");
   if (kind == 3) {
-    if (transposed) return conv3x3p_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
-    return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream));
+    if (transposed) return conv3x3p_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream), Hl, Wl, d->N);
+    return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream), d->Ho, d->Wo, d->N);
   }
   if (transposed) return conv1x1_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
   return conv1x1_wprep(d->math, w, d->Cout, Cin, 0, (unsigned short*)wp, S(stream));
@@ -116,21 +117,22 @@ extern "C" int pdae_conv_wprep_job(const pdae_conv_desc* d, const float* w, int 
   WprepJob* j = reinterpret_cast<WprepJob*>(job);
   if (flags & PDAE_WPREP_GN) {
     PDAE_CHECK_ARG(!transposed && gn_patch_ok(d, false), "conv_wprep_job: convolution not eligible for the fused-GroupNorm patch kernel");
-    conv3x3p_wprep_job(d->math, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, j);
+    conv3x3p_wprep_job(d->math, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, j, d->Ho, d->Wo, d->N);
     return PDAE_OK;
   }
   const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
+  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;
   PDAE_CHECK_ARG(kind != 0, "conv_wprep_job: convolution shape not eligible for a prepared-weight kernel");
   if (kind == 3) {
-    if (transposed) conv3x3p_wprep_job(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, j);
-    else conv3x3p_wprep_job(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, j);
+    if (transposed) conv3x3p_wprep_job(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, j, Hl, Wl, d->N);
+    else conv3x3p_wprep_job(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, j, d->Ho, d->Wo, d->N);
   } else if (transposed) conv1x1_wprep_job(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, j);
   else conv1x1_wprep_job(d->math, w, d->Cout, Cin, 0, (unsigned short*)wp, j);
   return PDAE_OK;
 }
 extern "C" int pdae_conv_skip_wprep_job(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_wprep_job* job) {
   PDAE_CHECK_ARG(w_skip && wps && job && pdae_conv2d_fwd_skip_ok(d, ds), "conv_skip_wprep_job: not an eligible (conv3x3, skip 1x1) pair");
-  conv3x3p_skip_wprep_job(d->math, w_skip, ds->Cout, ds->C0 + ds->C1, d->C0 + d->C1, (unsigned short*)wps, reinterpret_cast<WprepJob*>(job));
+  conv3x3p_skip_wprep_job(d->math, w_skip, ds->Cout, ds->C0 + ds->C1, d->C0 + d->C1, (unsigned short*)wps, reinterpret_cast<WprepJob*>(job), d->Ho, d->Wo, d->N);
   return PDAE_OK;
 }
 extern "C" int pdae_conv_wprep_group(const pdae_wprep_job* jobs_dev, const int32_t* first_block_dev, int njobs, int total_blocks, pdae_stream_t stream) {
@@ -207,7 +209,7 @@ extern "C" size_t pdae_conv_skip_wprep_bytes(const pdae_conv_desc* d, const pdae
 
 extern "C" int pdae_conv_skip_wprep(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_stream_t stream) {
   PDAE_CHECK_ARG(w_skip && wps && pdae_conv2d_fwd_skip_ok(d, ds), "conv_skip_wprep: not an eligible (conv3x3, skip 1x1) pair");
-  return conv3x3p_skip_wprep(d->math, w_skip, ds->Cout, ds->C0 + ds->C1, d->C0 + d->C1, (unsigned short*)wps, S(stream));
+  return conv3x3p_skip_wprep(d->math, w_skip, ds->Cout, ds->C0 + ds->C1, d->C0 + d->C1, (unsigned short*)wps, S(stream), d->Ho, d->Wo, d->N);
 }
 
 extern "C" int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp,

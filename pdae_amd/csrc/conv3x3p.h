@@ -144,13 +144,57 @@ template <int NS> __device__ __forceinline__ void wprep1_slot(const float* __res
   }
   wprep_store_slot<NS>(e, wscale, wp, plane_stride, i);
 }
+// Prepared weights of the Winograd-along-x form (conv3x3x.hip): wp [NS][C/32][T][2][NT][64][8] with T = 12 transform taps tp = ky * 4 + c,
+// U[ky][c] = sum_kx G[c][kx] w[ky][kx], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] (exact factors); or T = 2 for fused 1x1 skip chunks: the
+// centre tap's positions c = 1, 2 with G[c][1] = +-1/2.  transposed: the data-gradient weights (taps flipped), as wprep3_slot.
+template <int NS> __device__ __forceinline__ void wprepx_slot(const float* __restrict__ w, int Nout, int C, int NT, int transposed, float wscale, int T,
+                                                              unsigned short* __restrict__ wp, size_t i) {
+  const size_t plane_stride = (size_t)(C >> 5) * 2 * T * NT * 64 * 8;
+  const int lane = (int)(i & 63); size_t r = i >> 6;
+  const int nt = (int)(r % NT); r /= NT;
+  const int kc = (int)(r & 1); r >>= 1;
+  const int tp = (int)(r % T); const int chunk = (int)(r / T);
+  const int n = nt * 32 + (lane & 31), c0 = (chunk << 5) + kc * 16 + (lane >> 5) * 8;
+  float e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = 0.f;
+  if (n < Nout) {
+    if (T == 2) {                                 // skip chunk: w [Nout][C] (1x1)
+      const float g = tp == 0 ? 0.5f : -0.5f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = g * w[(size_t)n * C + c0 + j];
+    } else {
+      const int ky = tp >> 2, cc = tp & 3;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float g = cc == 0 ? (kx == 0 ? 1.f : 0.f) : (cc == 3 ? (kx == 2 ? 1.f : 0.f) : ((cc == 2 && kx == 1) ? -0.5f : 0.5f));
+        if (g == 0.f) continue;
+        const int tap = ky * 3 + kx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = transposed ? w[((size_t)(c0 + j) * 9 + (8 - tap)) * Nout + n] : w[((size_t)n * 9 + tap) * C + c0 + j];
+          e[j] = fmaf(g, v, e[j]);
+        }
+      }
+    }
+  }
+  wprep_store_slot<NS>(e, wscale, wp, plane_stride, i);
+}
+#define PDAE_WPREP_FORM_X 8        // WprepJob.transposed bit: Winograd-along-x layout (wprepx_slot)
+
 // one job of the grouped launch (= include/pdae_hip.h: pdae_wprep_job) and how the existing entry points describe theirs
 struct WprepJob { const float* w; unsigned short* wp; int Nout, C, NT, transposed, T, ns; float wscale; int nblocks; };
-void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j);
-void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, WprepJob* j);
+// (H, W, N: the launch-side output grid and batch -- they decide between the direct and the Winograd-along-x layout, conv3x3p_form)
+void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j, int H, int W, int N);
+void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, WprepJob* j, int H, int W, int N);
 void conv1x1_wprep_job(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, WprepJob* j);
 int wprep_group_launch(const WprepJob* jobs_dev, const int* first_block_dev, int njobs, int total_blocks, hipStream_t s);
 
+// conv3x3x.hip: Winograd F(2, 3) along x (two thirds of the matrix work) on the large layers; conv3x3p_form = 1 when a convolution with these
+// launch-side dimensions is prepared AND launched in that form
+bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout);
+int conv3x3x_launch(int math, const PatchParams& P, hipStream_t s);
+int conv3x3p_form(int math, int C, int H, int W, int N, int Nout);
 // conv3x3r.hip: persistent workgroups with a deferred epilogue for layers with at least two 16 x 16 x 128-channel tiles per CU
 bool conv3x3r_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws, int C0, int Cs0, int Cs1);
 int conv3x3r_launch(int math, const PatchParams& P, hipStream_t s);

@@ -520,10 +520,20 @@ static size_t slab_bytes(int C, int H, int W, int N, int Nout) {
   return q.splits > 1 ? (size_t)q.splits * N * H * W * Nout * sizeof(float) : 0;
 }
 
+// (24 k-halves per chunk: room for the 12 transform taps of the Winograd-along-x layout as well as for the 9 direct ones -- the buffer size does
+// not depend on which form a launch takes)
 static size_t prep_bytes(int math, int Nout, int C) {
   const int NS = math < 1 ? 1 : (math == 4 ? 2 : (math > 3 ? 3 : math));       // planes: math 4 = two fp16 planes
-  const size_t b = (size_t)NS * (C >> 5) * 18 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short);
+  const size_t b = (size_t)NS * (C >> 5) * 24 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short);
   return (b + 255) & ~(size_t)255;
+}
+
+// 1: this convolution (launch-side dimensions) is prepared and launched in the Winograd-along-x form (conv3x3x.hip); 0: direct patch kernels.
+// A pure function of the shape and of PDAE_W1 -- weight preparation and launch call it with the same arguments (fused skip chunks follow
+// their main convolution; a launch the direct plan would split over K keeps the direct form).
+int conv3x3p_form(int math, int C, int H, int W, int N, int Nout) {
+  if (!conv3x3x_ok(math, C, H, W, N, Nout)) return 0;
+  return patch_plan(C, H, W, N, Nout).splits == 1 ? 1 : 0;
 }
 
 // power-of-two scale of the fp16-format prepared weights: trained conv weights are ~ 1/sqrt(fan_in), which would put their low plane
@@ -570,6 +580,12 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   P.stat_part = stat_part;
   P.stat_tpi = q.splits != 1 ? (H * W + reduce_stats_tp(N, H * W) - 1) / reduce_stats_tp(N, H * W) : q.tiles_x * q.tiles_y * (q.th / 8);
   if (P.stat_part && ((Nout & 3) || (q.splits != 1 && Nout > 1024))) { pdae_set_error("conv3x3p: output statistics requested for Nout = %d", Nout); return PDAE_EINVAL; }
+  // Winograd F(2, 3) along x (conv3x3x.hip): two thirds of the MFMAs; the prepared weights are in that form iff conv3x3p_form says so
+  if (!q.w8 && conv3x3p_form(math, C, H, W, N, Nout)) {
+    if (coef && !act) { pdae_set_error("conv3x3p: fused GroupNorm input without SiLU is not built for the Winograd form"); return PDAE_EINVAL; }
+    P.stat_tpi = (H / 16) * (W / 16) * 2;
+    return conv3x3x_launch(math, P, s);
+  }
   // large layers: persistent workgroups, one wave per SIMD, epilogue of tile i inside tile i+1 (conv3x3r.hip); same parameters, same results
   if (q.splits == 1 && !q.w8 && (!coef || act) && conv3x3r_ok(math, C, H, W, N, Nout, Hs, Ws, P.C0, P.Cs0, P.Cs1)) return conv3x3r_launch(math, P, s);
 #define PDAE_P3(NS_)                                                                                                    \
@@ -590,8 +606,11 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
 template <int NS>
 __global__ void __launch_bounds__(256) conv3x3p_wprep_kernel(const float* __restrict__ w, int Nout, int C, int NT, int transposed, float wscale,
                                                              int T, unsigned short* __restrict__ wp) {
-  const size_t nslot = (size_t)(C >> 5) * 2 * T * NT * 64;          // T taps: 9 (3x3) or 1 (fused 1x1 skip chunks)
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) wprep3_slot<NS>(w, Nout, C, NT, transposed, wscale, T, wp, i);
+  const size_t nslot = (size_t)(C >> 5) * 2 * T * NT * 64;          // T taps: 9 (3x3) or 1 (fused 1x1 skip chunks); 12 / 2 in the Winograd-along-x form
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nslot; i += (size_t)gridDim.x * 256) {
+    if (transposed & PDAE_WPREP_FORM_X) wprepx_slot<NS>(w, Nout, C, NT, transposed & 1, wscale, T, wp, i);
+    else wprep3_slot<NS>(w, Nout, C, NT, transposed, wscale, T, wp, i);
+  }
 }
 
 static int wprep_launch(int math, const float* w, int Nout, int C, int transposed, float wscale, int T, unsigned short* wp, hipStream_t s) {
@@ -605,7 +624,8 @@ static int wprep_launch(int math, const float* w, int Nout, int C, int transpose
   return pdae_launch_status("conv3x3p_wprep");
 }
 
-int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s) {
+int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s, int H, int W, int N) {
+  if (conv3x3p_form(math, C, H, W, N, Nout)) return wprep_launch(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, s);
   return wprep_launch(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, s);
 }
 static void fill_job3(int math, const float* w, int Nout, int C, int transposed, float wscale, int T, unsigned short* wp, WprepJob* j) {
@@ -613,19 +633,22 @@ static void fill_job3(int math, const float* w, int Nout, int C, int transposed,
   j->ns = math < 1 ? 3 : (math > 4 ? 3 : math); j->wscale = wscale;
   j->nblocks = (int)(((size_t)(C >> 5) * 2 * T * j->NT * 64 + 255) / 256);
 }
-void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j) {
-  fill_job3(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, j);
+void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j, int H, int W, int N) {
+  if (conv3x3p_form(math, C, H, W, N, Nout)) fill_job3(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, j);
+  else fill_job3(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, j);
 }
-void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, WprepJob* j) {
-  fill_job3(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain) * PASCALE, 1, wp, j);
+void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, WprepJob* j, int H, int W, int N) {
+  if (conv3x3p_form(math, Cmain, H, W, N, Nout)) fill_job3(math, w, Nout, Cs, PDAE_WPREP_FORM_X, conv3x3p_wscale(Cmain) * PASCALE, 2, wp, j);
+  else fill_job3(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain) * PASCALE, 1, wp, j);
 }
 
 // weights of a 1x1 skip convolution [Nout][Cs] for the skip chunks of a 3x3 launch whose main input has Cmain channels: same plane
 // format and (fp16 format) the same power-of-two scale as the main weights
-size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs) {
+size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs) {      // (4 k-halves per chunk: room for the two transform positions of the Winograd-along-x form)
   const int NS = math < 1 ? 1 : (math == 4 ? 2 : (math > 3 ? 3 : math));
-  return (((size_t)NS * (Cs >> 5) * 2 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short)) + 255) & ~(size_t)255;
+  return (((size_t)NS * (Cs >> 5) * 4 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short)) + 255) & ~(size_t)255;
 }
-int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s) {
+int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s, int H, int W, int N) {
+  if (conv3x3p_form(math, Cmain, H, W, N, Nout)) return wprep_launch(math, w, Nout, Cs, PDAE_WPREP_FORM_X, conv3x3p_wscale(Cmain) * PASCALE, 2, wp, s);
   return wprep_launch(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain) * PASCALE, 1, wp, s);      // x PASCALE: the skip chunks' activations are unscaled
 }

@@ -55,7 +55,7 @@ int igemm_dense(int transA, int transB, const GemmParams& P, int zdim, hipStream
 struct PatchSkip { const float* s0; const float* s1; int C0, C1; const unsigned short* wps; const float* bias; };   // fused 1x1 skip conv
 bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout, bool fill);
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N);
-int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s);
+int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s, int H, int W, int N);
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1 = nullptr,
                     int C0 = 0, const float* coef = nullptr, int act = 0, const PatchSkip* sk = nullptr, const float* amax = nullptr,
@@ -64,7 +64,7 @@ void conv3x3p_arm_stats(float* part);          // one-shot request of pdae_conv_
 float* conv3x3p_take_stats();                  // ... taken AND cleared by the next forward entry point, first thing, on every return path
 size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi);
 size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs);
-int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s);
+int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s, int H, int W, int N);
 bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, int Cs0, int Cs1);
 
 // conv3x3w.hip: 3x3 stride-1 weight gradient with transposing LDS reads (math modes 1..3)

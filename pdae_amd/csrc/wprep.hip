@@ -9,7 +9,10 @@
 
 template <int NS> __device__ __forceinline__ void wprep_job_slot(const WprepJob& j, size_t i) {
   if (j.T > 0) {
-    if (i < (size_t)(j.C >> 5) * 2 * j.T * j.NT * 64) wprep3_slot<NS>(j.w, j.Nout, j.C, j.NT, j.transposed, j.wscale, j.T, j.wp, i);
+    if (i < (size_t)(j.C >> 5) * 2 * j.T * j.NT * 64) {
+      if (j.transposed & PDAE_WPREP_FORM_X) wprepx_slot<NS>(j.w, j.Nout, j.C, j.NT, j.transposed & 1, j.wscale, j.T, j.wp, i);
+      else wprep3_slot<NS>(j.w, j.Nout, j.C, j.NT, j.transposed, j.wscale, j.T, j.wp, i);
+    }
   } else {
     if (i < (size_t)(j.C >> 4) * j.NT * 64) wprep1_slot<NS>(j.w, j.Nout, j.C, j.NT, j.transposed, j.wscale, j.wp, i);
   }

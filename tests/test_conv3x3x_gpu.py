@@ -1,0 +1,272 @@
+"""GPU: csrc/conv3x3x.hip -- the 3x3 patch kernel with the Winograd F(2, 3) transform along x (12 instead of 18 products per pixel pair) --
+against fp64 references and against the direct patch kernels on the same operands.  PDAE_W1 = 2 routes every eligible shape to it (prepared
+weights AND launch: both are decided by conv3x3p_form, so each case prepares its weights under the same setting it launches with), 0 keeps the
+direct kernels.  Gates: the direct kernels' own (1e-5 of max |y| in the f16x3 arithmetic, 5e-4 bf16x3, 2e-2 bf16).
+Covers what conv3x3r's tests cover: bias / residual (same- and half-resolution) / nearest-upsampled input, fused GroupNorm input (one and two
+sources, AdaGN), fused 1x1 skip chunks with output statistics, the data gradient with the dynamic fp16 scale, accumulate, multi-tile images
+whose borders put zero padding on every side (and on the ACTIVATED tensor under GroupNorm)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = {1: 2e-2, 2: 5e-4, 4: 1e-5}
+
+
+@pytest.fixture
+def H():
+    from pdae_amd import hip
+    return hip
+
+
+def rn(seed, *shape, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).double().cpu()
+
+
+def _both(monkeypatch, run):
+    """run() = weight preparation + launch, under the direct kernels (PDAE_W1=0) and under the Winograd-along-x form (PDAE_W1=2)."""
+    out = []
+    for on in ("0", "2"):
+        monkeypatch.setenv("PDAE_W1", on)
+        out.append(run())
+        torch.cuda.synchronize()
+    return out
+
+
+def _gn_ref(x, gamma, beta, ss, G=32):
+    N, C = x.shape[:2]
+    xn = F.group_norm(x, G, None, None, 1e-5) * gamma.view(1, C, 1, 1) + beta.view(1, C, 1, 1)
+    if ss is not None:
+        sc, sh = ss[:, :C], ss[:, C:]
+        xn = xn * (1 + sc.view(N, C, 1, 1)) + sh.view(N, C, 1, 1)
+    return F.silu(xn)
+
+
+@pytest.mark.parametrize("math_mode", [4, 1, 2])
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, up, res_mode
+    (2, 32, 16, 32, 128, 0, 0),            # one tile column, one chunk
+    (1, 64, 48, 96, 256, 0, 1),            # 4 x 3 tiles, 3 chunks, two 128-channel tiles, same-resolution residual
+    (3, 32, 32, 64, 128, 1, 2),            # nearest-upsampled input (stored 16 x 16) + half-resolution residual
+    (2, 96, 32, 128, 128, 0, 0),           # interior tile rows see no zero padding at top / bottom
+    (5, 80, 112, 64, 256, 0, 1),           # 350 tiles x 2 channel tiles
+])
+def test_forward_vs_fp64_and_direct(H, monkeypatch, case, math_mode):
+    N, Hh, W, C, Cout, up, res_mode = case
+    if N * Hh * W > 30000 and math_mode != 4:
+        pytest.skip("large cases in the default arithmetic only")
+    Hs, Ws = (Hh // 2, W // 2) if up else (Hh, W)
+    x = rn(1, N, C, Hs, Ws) * 1.3 + 0.2
+    w = rn(2, Cout, C, 3, 3, scale=1.0 / math.sqrt(9 * C)); b = rn(3, Cout, scale=0.2)
+    c = H.Conv(N, Hs, Ws, C, 0, Cout, k=3, up=bool(up), math=math_mode)
+    xl = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    y_ref = F.conv2d(xl.double(), w.double(), b.double(), padding=1)
+    res = None
+    if res_mode == 1:
+        res = rn(4, N, Cout, Hh, W); y_ref = y_ref + res.double()
+    elif res_mode == 2:
+        res = rn(4, N, Cout, Hh // 2, W // 2); y_ref = y_ref + F.interpolate(res, scale_factor=2, mode="nearest").double()
+    xd, wd, bd = nhwc(x).cuda(), nhwc(w).cuda(), b.cuda()
+    resd = nhwc(res).cuda() if res is not None else None
+
+    def run():
+        wp = torch.empty(c.wprep_bytes(0, force=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 0, wp))
+        y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
+        H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, res=resd, res_mode=res_mode, wp=wp))
+        return y
+    y_p, y_x = _both(monkeypatch, run)
+    e_p, e_x = rel_err(nchw(y_p), y_ref), rel_err(nchw(y_x), y_ref)
+    print(f"[conv3x3x fwd math {math_mode}] {case}: vs fp64 {e_x:.2e} (direct {e_p:.2e})")
+    assert e_x < TOL[math_mode], (e_x, e_p)
+    # (a shape the direct plan splits over K keeps the direct form -- conv3x3p_form -- and is then bit-identical; the others differ in rounding)
+    if N * Hh * W * Cout >= 256 * 256 * 128 * 2:
+        assert not torch.equal(y_p, y_x)
+    assert rel_err(y_x, y_p) < 3 * TOL[math_mode]
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, C0, C1, Cout, up, res_mode, AdaGN
+    (2, 32, 32, 64, 0, 128, 0, 1, True),
+    (2, 64, 16, 64, 32, 128, 0, 0, False),     # two-source concat
+    (1, 32, 32, 32, 0, 256, 1, 2, True),       # upsampled input, half-resolution residual
+    (3, 96, 128, 32, 32, 128, 0, 1, True),
+])
+def test_fused_groupnorm_input_vs_fp64(H, monkeypatch, case):
+    N, Hh, W, C0, C1, Cout, up, res_mode, ada = case
+    C, G = C0 + C1, 32
+    Hs, Ws = (Hh // 2, W // 2) if up else (Hh, W)
+    x = rn(1, N, C, Hs, Ws) * 1.5 + 0.7
+    gamma, beta = 1 + 0.2 * rn(2, C), 0.2 * rn(3, C) + 0.5          # beta offset: a wrong zero padding of the ACTIVATED tensor would show
+    ss = 0.3 * rn(4, N, 2 * C) if ada else None
+    w = rn(5, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(6, Cout, scale=0.1)
+    c = H.Conv(N, Hs, Ws, C0, C1, Cout, k=3, up=bool(up), math=4)
+    a_ref = _gn_ref(x.double(), gamma.double(), beta.double(), None if ss is None else ss.double())
+    y_ref = F.conv2d(F.interpolate(a_ref, scale_factor=2, mode="nearest") if up else a_ref, w.double(), b.double(), padding=1)
+    res = None
+    if res_mode == 1:
+        res = rn(7, N, Cout, Hh, W); y_ref = y_ref + res.double()
+    elif res_mode == 2:
+        res = rn(7, N, Cout, Hh // 2, W // 2); y_ref = y_ref + F.interpolate(res, scale_factor=2, mode="nearest").double()
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous(); x1 = xh[..., C0:].contiguous() if C1 else None
+    mean, rstd, coef = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, C, device="cuda")
+    ws = torch.empty(H.gn_ws_bytes(N, C) // 4 + 64, device="cuda")
+    H.run(H.op_gn_stats_coef(x0, C0, x1, C1, N, Hs * Ws, G, 1e-5, gamma.cuda(), beta.cuda(), None if ss is None else ss.cuda(), None, mean, rstd, coef, ws))
+    wd, bd = nhwc(w).cuda(), b.cuda()
+    resd = nhwc(res).cuda() if res is not None else None
+
+    def run():
+        wp = torch.empty(c.wprep_bytes(0, force=True, gn=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 4, wp))
+        y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
+        H.run(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, bd, y, res=resd, res_mode=res_mode))
+        return y
+    y_p, y_x = _both(monkeypatch, run)
+    e_x = rel_err(nchw(y_x), y_ref)
+    print(f"[conv3x3x fused GN] {case}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(y_p), y_ref):.2e})")
+    assert e_x < 1e-5
+
+
+@pytest.mark.parametrize("case", [(16, 64, 32, 64, 64, 32, 128, True), (16, 64, 32, 32, 96, 0, 128, False), (8, 64, 64, 96, 32, 32, 256, False)])
+def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case):
+    """conv3x3(x) + conv1x1([s0 | s1]) in one K loop -- the skip chunks are the centre tap: transform positions 1 and 2 with weights +-w / 2 --
+    and the GroupNorm partial statistics of the output written by the epilogue, after the reader's fp64 combine."""
+    N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
+    Cs, G = Cs0 + Cs1, 32
+    x = rn(1, N, C, Hh, W) * 1.2 + 0.3
+    sx = rn(2, N, Cs, Hh, W) * 2.0
+    w = rn(3, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(4, Cout, scale=0.1)
+    wsk = rn(5, Cout, Cs, 1, 1, scale=1.0 / math.sqrt(Cs)); bsk = rn(6, Cout, scale=0.1)
+    gamma, beta = 1 + 0.2 * rn(7, C), 0.2 * rn(8, C) + 0.4
+    c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
+    cs = H.Conv(N, Hh, W, Cs0, Cs1, Cout, k=1, math=4)
+    if not H.conv_fwd_skip_ok(c, cs):
+        pytest.skip("pair not eligible for the fused launch at this size")
+    a_ref = _gn_ref(x.double(), gamma.double(), beta.double(), None) if use_gn else x.double()
+    y_ref = F.conv2d(a_ref, w.double(), b.double(), padding=1) + F.conv2d(sx.double(), wsk.double(), bsk.double())
+    xd, sh = nhwc(x).cuda(), nhwc(sx).cuda()
+    s0 = sh[..., :Cs0].contiguous(); s1 = sh[..., Cs0:].contiguous() if Cs1 else None
+    wd, wsd = nhwc(w).cuda(), nhwc(wsk).cuda()
+    coef = None
+    if use_gn:
+        mean, rstd, coef = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, C, device="cuda")
+        ws = torch.empty(H.gn_ws_bytes(N, C) // 4 + 64, device="cuda")
+        H.run(H.op_gn_stats_coef(xd, C, None, 0, N, Hh * W, G, 1e-5, gamma.cuda(), beta.cuda(), None, None, mean, rstd, coef, ws))
+    nbytes, tpi = H.conv_stats_bytes(c, cs)
+    assert nbytes > 0
+    g2, b2 = (1 + 0.1 * rn(9, Cout)).cuda(), (0.1 * rn(10, Cout)).cuda()
+
+    def run():
+        wp = torch.empty(c.wprep_bytes(0, force=True, gn=use_gn) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 4 if use_gn else 0, wp))
+        wps = torch.empty(H.conv_skip_wprep_bytes(c, cs) // 4, device="cuda")
+        H.run(H.op_conv_skip_wprep(c, cs, wsd, wps))
+        y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
+        part = torch.full((nbytes // 4,), float("nan"), device="cuda")
+        H.run(H.op_conv_fwd_skip(c, xd, None, coef, 1, wp, b.cuda(), cs, s0, s1, wps, bsk.cuda(), y, stats=part))
+        m, r, k = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, Cout, device="cuda")
+        H.run(H.op_gn_coef_from_conv_stats(N, Hh * W, Cout, 0, G, 1e-5, part, tpi, None, 0, g2, b2, None, None, m, r, k))
+        return y, part, m, r
+    (y_p, part_p, m_p, r_p), (y_x, part_x, m_x, r_x) = _both(monkeypatch, run)
+    e_x = rel_err(nchw(y_x), y_ref)
+    print(f"[conv3x3x fused skip] {case}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(y_p), y_ref):.2e})")
+    assert e_x < 1e-5 and not torch.equal(y_p, y_x)        # fused launches never split: always the Winograd form under PDAE_W1 = 2
+    assert torch.isfinite(part_x).all()
+    yd = y_x.double()
+    mean_ref = yd.view(N, Hh * W, G, Cout // G).mean((1, 3)).flatten()
+    assert (m_x.double() - mean_ref).abs().max() < 5e-6 * max(1.0, float(mean_ref.abs().max()))
+    var_ref = yd.view(N, Hh * W, G, Cout // G).var((1, 3), unbiased=False).flatten()
+    assert rel_err(r_x, (var_ref + 1e-5).rsqrt()) < 2e-5
+
+
+@pytest.mark.parametrize("gscale", [1.0, 3e-7, 2e4])
+@pytest.mark.parametrize("case", [(2, 32, 32, 128, 64), (1, 64, 32, 256, 128), (3, 160, 160, 128, 32)])
+def test_data_gradient_with_dynamic_fp16_scale(H, monkeypatch, case, gscale):
+    """dX of a 3x3 convolution = the same kernel on transposed, tap-flipped prepared weights (wprepx_slot's transposed form) with the
+    per-tensor power-of-two dY scale: Cin of the convolution is the GEMM N here, so it must be a multiple of 128."""
+    N, Hh, W, Cin, Cout = case
+    x = rn(1, N, Cin, Hh, W)
+    w = rn(2, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(9 * Cin))
+    dy = rn(3, N, Cout, Hh, W) * gscale
+    xr = x.double().requires_grad_(True)
+    (F.conv2d(xr, w.double(), None, padding=1) * dy.double()).sum().backward()
+    c = H.Conv(N, Hh, W, Cin, 0, Cout, k=3, math=4)
+    wd, dyd = nhwc(w).cuda(), nhwc(dy).cuda()
+    amax = torch.empty(4, device="cuda")
+    H.run(H.op_amax(dyd, dyd.numel(), amax))
+
+    def run():
+        wp_t = torch.empty(c.wprep_bytes(1, force=True, f16_grad=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 1 | 16, wp_t))
+        dx = torch.full((N, Hh, W, Cin), float("nan"), device="cuda")
+        H.run(H.op_conv_dgrad(c, dyd, wd, dx, wp_t=wp_t, dy_amax=amax))
+        return dx
+    dx_p, dx_x = _both(monkeypatch, run)
+    e_x = rel_err(nchw(dx_x), xr.grad)
+    print(f"[conv3x3x dgrad] {case} x{gscale}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(dx_p), xr.grad):.2e})")
+    assert e_x < 1e-5
+
+
+def test_accumulating_data_gradient(H, monkeypatch):
+    """accumulate = 1 (a second consumer's gradient joins the buffer): read-modify-write epilogue."""
+    N, Hh, W, Cin, Cout = 2, 32, 16, 128, 32
+    w = rn(2, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(9 * Cin))
+    dy = rn(3, N, Cout, Hh, W)
+    base = rn(4, N, Hh, W, Cin)
+    c = H.Conv(N, Hh, W, Cin, 0, Cout, k=3, math=4)
+    wd, dyd = nhwc(w).cuda(), nhwc(dy).cuda()
+
+    def run():
+        wp_t = torch.empty(c.wprep_bytes(1, force=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 1, wp_t))
+        dx = base.clone().cuda()
+        H.run(H.op_conv_dgrad(c, dyd, wd, dx, accumulate=1, wp_t=wp_t))
+        return dx
+    dx_p, dx_x = _both(monkeypatch, run)
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    assert rel_err(nchw(dx_x) - base.permute(0, 3, 1, 2).double(), ref) < 1e-5
+
+
+def test_grouped_weight_preparation_uses_the_same_form(H, monkeypatch):
+    """pdae_conv_wprep_job / pdae_conv_wprep_group (one launch for every prepared copy of a plan) must write the same Winograd-form planes as
+    pdae_conv_wprep: forward, data-gradient (transposed, fp16 gradient format) and fused-skip jobs."""
+    monkeypatch.setenv("PDAE_W1", "2")
+    N, Hh, W, C, Cout, Cs = 2, 32, 32, 64, 128, 96
+    w = nhwc(rn(1, Cout, C, 3, 3, scale=0.05)).cuda()
+    wsk = nhwc(rn(2, Cout, Cs, 1, 1, scale=0.1)).cuda()
+    c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
+    cd = H.Conv(N, Hh, W, Cout, 0, C, k=3, math=4)       # its data gradient has GEMM N = Cout of this descriptor... use a 128-input-channel conv
+    cs = H.Conv(N, Hh, W, Cs, 0, Cout, k=1, math=4)
+    wd2 = nhwc(rn(3, C, Cout, 3, 3, scale=0.05)).cuda()  # weights of cd: (Cout = C, Cin = Cout)
+    singles, jobs = [], []
+    for (cc, ww, flags) in ((c, w, 0), (c, w, 4), (cd, wd2, 1 | 16)):
+        a = torch.zeros(cc.wprep_bytes(flags & 1, force=True, gn=bool(flags & 4), f16_grad=bool(flags & 16)) // 4, device="cuda")
+        b = torch.zeros_like(a)
+        H.run(H.op_conv_wprep(cc, ww, flags, a))
+        singles.append(a); jobs.append((H.wprep_job(cc, ww, flags, b), b))
+    a = torch.zeros(H.conv_skip_wprep_bytes(c, cs) // 4, device="cuda"); b = torch.zeros_like(a)
+    H.run(H.op_conv_skip_wprep(c, cs, wsk, a))
+    singles.append(a); jobs.append((H.skip_wprep_job(c, cs, wsk, b), b))
+    jt, ft, tot = H.wprep_group_tables([j for j, _ in jobs], torch.device("cuda"))
+    H.run(H.op_conv_wprep_group(jt, ft, len(jobs), tot))
+    torch.cuda.synchronize()
+    for s_, (_, g_) in zip(singles, jobs):
+        assert torch.equal(s_, g_) and float(s_.abs().max()) > 0
+    monkeypatch.setenv("PDAE_W1", "0")
+    a0 = torch.zeros_like(singles[0])
+    H.run(H.op_conv_wprep(c, w, 0, a0))
+    assert not torch.equal(a0, singles[0])               # the direct layout differs
