@@ -388,8 +388,13 @@ __global__ void __launch_bounds__(RTHREADS, 1) conv3x3r_kernel(const PatchParams
       __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
   // the 36 units of a main chunk written out: LLVM refuses to fully unroll a loop of this size even under "#pragma unroll" (pragma-unroll-threshold)
+#ifdef PDAE_R_PROBE_24U      // timing probe (WRONG RESULTS): 24 of the 36 units of a main chunk = the matrix work of a Winograd F(2, 3)-along-x form in this structure
+#define PDAE_R_36(M, F) M(0, F) M(1, F) M(2, F) M(3, F) M(4, F) M(5, F) M(6, F) M(7, F) M(8, F) M(9, F) M(10, F) M(11, F) M(12, F) M(13, F) M(14, F) M(15, F) M(16, F) M(17, F) \
+    M(18, F) M(19, F) M(20, F) M(21, F) M(22, F) M(23, F)
+#else
 #define PDAE_R_36(M, F) M(0, F) M(1, F) M(2, F) M(3, F) M(4, F) M(5, F) M(6, F) M(7, F) M(8, F) M(9, F) M(10, F) M(11, F) M(12, F) M(13, F) M(14, F) M(15, F) M(16, F) M(17, F) \
     M(18, F) M(19, F) M(20, F) M(21, F) M(22, F) M(23, F) M(24, F) M(25, F) M(26, F) M(27, F) M(28, F) M(29, F) M(30, F) M(31, F) M(32, F) M(33, F) M(34, F) M(35, F)
+#endif
   // position of the prefetch pipeline after (tile, slot)
   auto advance = [&](int tile, int slot, int& ntile, int& nslot) {
     const bool last = slot + 1 >= nmain + nxp;

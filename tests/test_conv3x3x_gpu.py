@@ -184,7 +184,9 @@ def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case):
     (y_p, part_p, m_p, r_p), (y_x, part_x, m_x, r_x) = _both(monkeypatch, run)
     e_x = rel_err(nchw(y_x), y_ref)
     print(f"[conv3x3x fused skip] {case}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(y_p), y_ref):.2e})")
-    assert e_x < 1e-5 and not torch.equal(y_p, y_x)        # fused launches never split: always the Winograd form under PDAE_W1 = 2
+    assert e_x < 1e-5
+    if case[0] * case[1] * case[2] >= 8 * 64 * 64:        # (a main convolution the direct plan would split over K keeps the direct form, skip chunks included)
+        assert not torch.equal(y_p, y_x)
     assert torch.isfinite(part_x).all()
     yd = y_x.double()
     mean_ref = yd.view(N, Hh * W, G, Cout // G).mean((1, 3)).flatten()
@@ -245,7 +247,7 @@ def test_grouped_weight_preparation_uses_the_same_form(H, monkeypatch):
     """pdae_conv_wprep_job / pdae_conv_wprep_group (one launch for every prepared copy of a plan) must write the same Winograd-form planes as
     pdae_conv_wprep: forward, data-gradient (transposed, fp16 gradient format) and fused-skip jobs."""
     monkeypatch.setenv("PDAE_W1", "2")
-    N, Hh, W, C, Cout, Cs = 2, 32, 32, 64, 128, 96
+    N, Hh, W, C, Cout, Cs = 16, 64, 32, 64, 128, 96
     w = nhwc(rn(1, Cout, C, 3, 3, scale=0.05)).cuda()
     wsk = nhwc(rn(2, Cout, Cs, 1, 1, scale=0.1)).cuda()
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)

@@ -32,14 +32,46 @@ for k, v in sorted(o["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_la
     lines.append(f"{k[:70]:70s} {v['dispatches']:6d} {v['fetch_size_kib_avg']:12.1f} {v['write_size_kib_avg']:12.1f} {v['hbm_bytes_per_launch'] / 1e6:14.1f}")
 open(os.path.join(P, f"{rnd}_pmc_traffic.txt"), "w").write("\n".join(lines) + "\n")
 
+# ---- registers / scratch / LDS per kernel: from the COMPILER's resource remarks (tests/test_kernel_resources_cpu.resource_table), not from the
+# kernel trace -- rocprofv3 reports Accum_VGPR_Count = 0 and LDS_Block_Size = 0 for kernels with a unified register file / dynamic LDS (round 3's
+# table showed AGPR 0 and LDS 0 for conv3x3r, which hid a 68-byte-per-lane spill)
+import subprocess
+sys.path.insert(0, ROOT)
+from tests.test_kernel_resources_cpu import HOT, resource_table
+from pdae_amd import build as _B
+RES = {}
+for src in HOT:
+    if not os.path.exists(os.path.join(_B.CSRC, src)):
+        continue
+    for k in resource_table(src):
+        name = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.strip()
+        RES[name] = k
+# dynamic LDS of the kernels that size it at launch (bytes per workgroup; launch code of the respective .hip file)
+DYN_LDS = {"conv3x3r_kernel<4": 2 * 2 * 30720 + 4 * 32 * 36 * 4, "conv3x3r_kernel<1": 2 * 1 * 30720 + 4 * 32 * 36 * 4, "conv3x3r_kernel<2": 2 * 2 * 30720 + 4 * 32 * 36 * 4,
+           "conv3x3p_kernel<4, 8": 2 * 200 * 80, "conv3x3p_kernel<4, 16": 2 * 360 * 80, "conv3x3w_kernel<4, false": (2 * 180 * 32 + 2 * 128 * 64) * 2 + 256 * 16, "conv3x3w_kernel<4, true": (2 * 200 * 32 + 2 * 128 * 64) * 2 + 256 * 16,
+           "conv1x1_kernel<4": 2 * 128 * 72 * 2, "wino8_kernel": 162176, "wino_kernel": 162176, "conv3x3x_kernel<4": 2 * 51840}
+
+
+def res_of(kname):
+    r = RES.get(kname)
+    if r is None:
+        return None
+    lds = r["lds"]
+    for pre, b in DYN_LDS.items():
+        if kname.startswith("void " + pre):
+            lds = max(lds, b)
+    return r["vgpr"], r["agpr"], r["scratch"], lds
+
+
 # ---- SQ counters of the MFMA kernels
 A = json.load(open(os.path.join(G, tag + "_pmcA.json")))
 B = json.load(open(os.path.join(G, tag + "_pmcB.json")))
 hdr = ["# rocprofv3 --pmc <8 SQ counters + GRBM_GUI_ACTIVE> --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-ddim   (two passes)",
        "# per-launch means.  MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)  [busy cycles = 32 per 32x32x16 MFMA];",
        "# WAIT_ANY = parked in s_waitcnt / barrier, WAIT_INST_ANY = issue stalls (MFMA pipe / dependencies), ACTIVE = instruction issue -- fractions of SQ_WAVE_CYCLES;",
-       "# LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; resources from the kernel trace (VGPR incl. AGPR, LDS bytes / workgroup)",
-       f"{'kernel':58s} {'disp':>5s} {'MFMAutil':>8s} {'WAIT_ANY':>8s} {'WAIT_INST':>9s} {'ACTIVE':>7s} {'LDSconf':>7s} {'VALU/MFMA':>9s} {'LDS/MFMA':>8s} {'VGPR':>5s} {'AGPR':>5s} {'LDS':>7s} {'WG':>4s}"]
+       "# LDS conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; VGPR / AGPR / scratch bytes per lane / LDS bytes per workgroup (static + dynamic) from hipcc's",
+       "# -Rpass-analysis=kernel-resource-usage remarks of the shipped sources (the kernel trace reports 0 for AGPRs and dynamic LDS); '-' = not a hot source",
+       f"{'kernel':58s} {'disp':>5s} {'MFMAutil':>8s} {'WAIT_ANY':>8s} {'WAIT_INST':>9s} {'ACTIVE':>7s} {'LDSconf':>7s} {'VALU/MFMA':>9s} {'LDS/MFMA':>8s} {'VGPR':>5s} {'AGPR':>5s} {'scr':>4s} {'LDS':>7s} {'WG':>4s}"]
 for k, v in sorted(A.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0) * kv[1]["dispatches"]):
     if v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) <= 0:
         continue
@@ -48,9 +80,11 @@ for k, v in sorted(A.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLE
     util = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * v["GRBM_GUI_ACTIVE"] / 8.0)
     nm = max(b.get("SQ_INSTS_MFMA", 0.0), 1.0)
     r = v["resources"]
+    cr = res_of(k)
+    cols = (f"{cr[0]:5d} {cr[1]:5d} {cr[2]:4d} {cr[3]:7d}" if cr else f"{'-':>5s} {'-':>5s} {'-':>4s} {'-':>7s}")
     hdr.append(f"{k[:58]:58s} {v['dispatches']:5d} {util:8.3f} {v['SQ_WAIT_ANY'] / wc:8.3f} {v['SQ_WAIT_INST_ANY'] / wc:9.3f} {v['SQ_ACTIVE_INST_ANY'] / wc:7.3f} "
                f"{v['SQ_LDS_BANK_CONFLICT'] / max(v['SQ_LDS_IDX_ACTIVE'], 1):7.3f} {(b.get('SQ_INSTS_VALU', 0) - nm) / nm:9.2f} {b.get('SQ_INSTS_LDS', 0) / nm:8.2f} "
-               f"{r['VGPR_Count']:>5s} {r['Accum_VGPR_Count']:>5s} {r['LDS_Block_Size']:>7s} {r['Workgroup_Size']:>4s}")
+               f"{cols} {r['Workgroup_Size']:>4s}")
 open(os.path.join(P, f"{rnd}_pmc_sq.txt"), "w").write("\n".join(hdr) + "\n")
 print("\n".join(hdr[4:12]))
 

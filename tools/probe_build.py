@@ -19,6 +19,7 @@ VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"])
             "wn_nostore": (WN, ["-DPDAE_WN_PROBE_NOSTORE"]), "wn_loads": (WN, ["-DPDAE_WN_PROBE_NORAW", "-DPDAE_WN_PROBE_NOB"]),
             "x_noa": (X3, ["-DPDAE_X_PROBE_NOA"]), "x_nob": (X3, ["-DPDAE_X_PROBE_NOB"]), "x_nostage": (X3, ["-DPDAE_X_PROBE_NOSTAGE"]),
             "x_mfma": (X3, ["-DPDAE_X_PROBE_NOA", "-DPDAE_X_PROBE_NOB", "-DPDAE_X_PROBE_NOSTAGE"]),
+            "r_24u": (R3, ["-DPDAE_R_PROBE_24U"]),
             "r_mfma": (R3, ["-DPDAE_R_PROBE_NOA", "-DPDAE_R_PROBE_NOB", "-DPDAE_R_PROBE_NOGLOAD", "-DPDAE_R_PROBE_NOCONV", "-DPDAE_R_PROBE_NODRAIN"])}
 only = sys.argv[1:]
 for name, (src, defs) in VARIANTS.items():
