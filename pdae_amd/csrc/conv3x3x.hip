@@ -400,6 +400,11 @@ int conv3x3x_launch(int math, const PatchParams& P0, hipStream_t s) {
   const int smax = P.Cs0 > P.Cs1 ? P.Cs0 : P.Cs1;
   if ((unsigned long long)P.N * P.H * P.W * (unsigned long long)smax * 4ull >= lim) { pdae_set_error("conv3x3x: skip tensor beyond 4 GB"); return PDAE_EINVAL; }
   if (P.x1 && (P.C0 & 31)) { pdae_set_error("conv3x3x: two-source input needs C0 %% 32 == 0"); return PDAE_EINVAL; }
+  // launches without fused skip chunks: the one-wave-per-SIMD persistent form (conv3x3y.hip) unless PDAE_W1_KERNEL=x
+  {
+    const char* e = getenv("PDAE_W1_KERNEL");
+    if (P.nx == 0 && !(P.res_mode && P.accumulate) && !(e && e[0] == 'x')) return conv3x3y_launch(math, P, s);
+  }
 #define PDAE_X3(NS_) (P.coef ? launch_x<NS_, true>(P, s) : launch_x<NS_, false>(P, s))
   if (math == 1) return PDAE_X3(1);
   if (math == 2) return PDAE_X3(2);

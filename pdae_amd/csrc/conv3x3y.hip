@@ -1,0 +1,521 @@
+// Winograd F(2, 3)-along-x 3x3 convolution (forward / data gradient) for gfx950 in the PERSISTENT one-wave-per-SIMD structure of conv3x3r.hip --
+// the register budget the form needs (conv3x3x.hip, the two-waves-per-SIMD attempt, had 256 registers per wave: operands single-buffered, U
+// fragments one 6-MFMA step ahead, 0.75-0.9x of the default routing; profiles/r04_winograd_probe.txt).  The probe build of conv3x3r with 24 of
+// its 36 units per chunk -- exactly this form's matrix work -- runs 0.598 vs 0.857 ms on 128x128 256->128, B = 32.
+//
+//   * 4 waves, one per SIMD, 512 registers: wave (wm, wn) = 8 rows x 8 pixel pairs x 64 output channels, accumulators acc[c][a2][ct] = 16 tiles of
+//     32 x 32 in the 256 AGPRs (transform position c, pair half a2, channel tile ct).  No second accumulator set: the epilogue is NOT deferred, it
+//     runs between tiles (output transform lane-local, then conv3x3r's transposition + float4 stores, through the patch buffer the last chunk freed).
+//   * chunk = 16 input channels = one k-step per (ky, c): 12 units of 12 MFMAs (2 halves x 2 channel tiles x 3 products, a dependent pair 4 issues
+//     apart); U fragments: ring of four units (requested three units = 36 MFMAs ahead), patch fragments: ring of two.
+//   * LDS patch in the transform domain, double buffered: 18 rows x 36 positions (c * 8 + pair) x 48-byte rows (16 channels + pad: 36 * 48 = 192
+//     (mod 256) keeps every ds_read_b128 fragment conflict-free) x planes = 62 KB per buffer.  The raw input of chunk s + 2 is loaded while chunk s
+//     is multiplied and transformed / split / stored into the other buffer while chunk s + 1 is: per thread two items (patch row, pair, channel
+//     quad: own pixel pair + one edge pixel, the neighbours' pixels across lanes) and one quarter item of patch rows 16, 17 (one position of a
+//     pair: two loads); each item's conversion is spread over three units.
+//   * everything inside a unit is branch-free (absent operands = empty buffer resources / out-of-range offsets, as in conv3x3r).
+// Prepared weights: the Winograd-along-x layout of conv3x3x.hip (wprepx_slot, 12 taps x 2 k halves per 32-channel chunk).  Fused skip chunks are
+// not built here: such launches stay on conv3x3x.
+#include <stdlib.h>
+
+#include "common.h"
+#include "igemm.h"
+#include "conv3x3p.h"
+
+#define YTHREADS 256
+#define YPW 36
+#define YROWB 48u
+#define YNPOS (18 * YPW)
+#define YPLANE_B ((unsigned)YNPOS * YROWB)         // 31104
+#define YOOB 0xFFFFFFF0u
+#define YALL 0xFFFFFFEFu
+
+typedef unsigned y_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned y_u32x2 __attribute__((ext_vector_type(2)));
+typedef float y_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const y_u32x4* y_lds_u4;
+typedef __attribute__((address_space(3))) y_u32x2* y_lds_u2;
+typedef __attribute__((address_space(3))) float* y_lds_f;
+typedef __attribute__((address_space(3))) const y_f32x4* y_lds_f4;
+
+#define PDAE_Y_PATTERN(NV)                                                                                  \
+  _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x006, NV, 0);                                                    \
+    if (i_ < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                     \
+    if (i_ >= 4) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                        \
+    __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);                                                     \
+  }
+
+template <int NS, bool GN>
+__global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams P, const int stagger) {
+  constexpr int NP = NPL(NS);
+  constexpr unsigned BUF_B = NP * YPLANE_B;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, h = lane >> 5;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int C = P.C, C1 = C - P.C0, nk = C >> 4;
+  const int ntiles = P.N * P.tiles_y * P.tiles_x * P.tiles_n, G = gridDim.x;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const float ascale = NS == 4 ? (P.amax ? p_pow2_scale(*P.amax) : PASCALE) : 1.0f;
+  float sat_hit = 0.f;
+  const int up_sh = P.up ? 1 : 0;
+  const float* const x1_ = P.x1 ? P.x1 : P.x;
+
+#define Y_DECODE(TILE, IMG, Y0, X0, N0)                                                                       \
+  { int tl_ = (TILE); const int tn_ = tl_ % P.tiles_n; tl_ /= P.tiles_n; const int tx_ = tl_ % P.tiles_x; tl_ /= P.tiles_x;   \
+    const int ty_ = tl_ % P.tiles_y; tl_ /= P.tiles_y; IMG = tl_; Y0 = ty_ * 16; X0 = tx_ * 16; N0 = tn_ * 128; }
+
+  // ---- staging roles.  Items l = 0, 1: (patch row (t >> 5) + 8 l, pair (t >> 2) & 7, channel quad t & 3): own pixels b = 1, 2 and, for the first / last
+  // pair of the row, the edge pixel.  Quarter item (patch rows 16, 17): (row 16 + (t >> 7), pair (t >> 4) & 7, quad (t >> 2) & 3, position t & 3): the
+  // two pixels that position needs (c = 0: b = 0, 2; c = 1, 2: b = 1, 2; c = 3: b = 1, 3).
+  const int qd = t & 3, wt = (t >> 2) & 7, r8 = t >> 5;
+  const int q_c = t & 3, q_qd = (t >> 2) & 3, q_wt = (t >> 4) & 7, q_row = 16 + (t >> 7);
+  const int q_ba = q_c == 0 ? 0 : 1, q_bb = q_c == 3 ? 3 : 2;
+  // per-tile pixel bookkeeping of the tile whose raw data is being LOADED (ld_*): source pixel index of b = 1 per item + validity bits
+  int ld_pb[2], ld_qa = 0, ld_qb = 0;
+  unsigned ld_vm = 0u;                           // bits 0, 1: items' rows valid; 2, 3: items' edge pixels valid; 4, 5: quarter item's two pixels valid
+  // the neighbours' pixels come across lanes with DPP row shifts (16-lane rows = 4 pairs x 4 quads): the first / last pair of each 4-pair segment
+  // loads its outer pixel itself (the tile's edge pixel for pairs 0 and 7, a pixel of the neighbouring segment for pairs 3 and 4)
+  const bool seg_lo = (wt & 3) == 0, seg_hi = (wt & 3) == 3;
+  const int eb = seg_lo ? 0 : 3;
+  const int ob2 = P.up ? 0 : 1, obe = seg_lo ? -1 : (P.up ? 1 : 2);
+#define Y_LD_TILE(IMG, Y0, X0, LIVE)                                                                          \
+  {                                                                                                           \
+    ld_vm = 0u;                                                                                               \
+    _Pragma("unroll") for (int l = 0; l < 2; ++l) {                                                           \
+      const int ly = (Y0) - 1 + r8 + 8 * l, lx1 = (X0) + 2 * wt;                                              \
+      const bool rok = (LIVE) && (unsigned)ly < (unsigned)P.H;                                                \
+      ld_pb[l] = ((IMG) * P.Hs + (ly >> up_sh)) * P.Ws + (lx1 >> up_sh);                                      \
+      if (rok) ld_vm |= 1u << l;                                                                              \
+      if (rok && (seg_lo || seg_hi) && (unsigned)(lx1 - 1 + eb) < (unsigned)P.W) ld_vm |= 4u << l;            \
+    }                                                                                                         \
+    {                                                                                                         \
+      const int ly = (Y0) - 1 + q_row, lxa = (X0) - 1 + 2 * q_wt + q_ba, lxb = (X0) - 1 + 2 * q_wt + q_bb;    \
+      const bool rok = (LIVE) && (unsigned)ly < (unsigned)P.H;                                                \
+      ld_qa = ((IMG) * P.Hs + (ly >> up_sh)) * P.Ws + (lxa >> up_sh);                                         \
+      ld_qb = ((IMG) * P.Hs + (ly >> up_sh)) * P.Ws + (lxb >> up_sh);                                         \
+      if (rok && (unsigned)lxa < (unsigned)P.W) ld_vm |= 16u;                                                 \
+      if (rok && (unsigned)lxb < (unsigned)P.W) ld_vm |= 32u;                                                 \
+    }                                                                                                         \
+  }
+  // validity of the data being CONVERTED (one step behind the loads): a copy taken when the load position moves on
+  unsigned cv_vm = 0u;
+  // source of the chunk being loaded: pointer, bytes per pixel, byte offset of the chunk's channels
+  const float* ld_ptr = P.x; unsigned ld_ldb = 0, ld_cb = 0;
+#define Y_LD_SRC(K)                                                                                           \
+  { const int c_ = (K) << 4; const bool first_ = c_ < P.C0;                                                   \
+    ld_ptr = first_ ? P.x : x1_; ld_ldb = (unsigned)(first_ ? P.C0 : C1) * 4u; ld_cb = (unsigned)(first_ ? c_ : c_ - P.C0) * 4u; }
+#define Y_RS(PTR) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((const void*)(PTR)), 0, (int)YALL, 0x00020000)
+  float4 apre[2][3], qpre[2];
+  auto gload_item = [&](int l) {
+    const unsigned v1 = (unsigned)ld_pb[l] * ld_ldb + (unsigned)(qd * 16);
+    const bool rok = (ld_vm >> l) & 1u, eok = (ld_vm >> (2 + l)) & 1u;
+    apre[l][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RS(ld_ptr), (int)(rok ? v1 : YOOB), (int)ld_cb, 0));
+    apre[l][1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RS(ld_ptr), (int)(rok ? v1 + (unsigned)ob2 * ld_ldb : YOOB), (int)ld_cb, 0));
+    apre[l][2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RS(ld_ptr), (int)(eok ? v1 + (unsigned)obe * ld_ldb : YOOB), (int)ld_cb, 0));
+  };
+  auto gload_quarter = [&]() {
+    const unsigned va = (unsigned)ld_qa * ld_ldb + (unsigned)(q_qd * 16), vb = (unsigned)ld_qb * ld_ldb + (unsigned)(q_qd * 16);
+    qpre[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RS(ld_ptr), (int)((ld_vm & 16u) ? va : YOOB), (int)ld_cb, 0));
+    qpre[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RS(ld_ptr), (int)((ld_vm & 32u) ? vb : YOOB), (int)ld_cb, 0));
+  };
+  // GroupNorm coefficients of the chunk being converted (this thread's quad for the items, and for the quarter item)
+  float4 gmu, gsc, gsh, hmu, hsc, hsh;
+  auto coef_load = [&](int img, int k) {
+    if constexpr (GN) {
+      const size_t NC = (size_t)P.N * C;
+      const float* cf = P.coef + (size_t)img * C + (k << 4);
+      gmu = *reinterpret_cast<const float4*>(cf + qd * 4); gsc = *reinterpret_cast<const float4*>(cf + NC + qd * 4); gsh = *reinterpret_cast<const float4*>(cf + 2 * NC + qd * 4);
+      hmu = *reinterpret_cast<const float4*>(cf + q_qd * 4); hsc = *reinterpret_cast<const float4*>(cf + NC + q_qd * 4); hsh = *reinterpret_cast<const float4*>(cf + 2 * NC + q_qd * 4);
+    }
+  };
+  auto gn_map = [&](float4 v, bool on, const float4& mu, const float4& sc_, const float4& sh_) {
+    float4 m;
+    m.x = sc_.x * (v.x - mu.x) + sh_.x; m.y = sc_.y * (v.y - mu.y) + sh_.y; m.z = sc_.z * (v.z - mu.z) + sh_.z; m.w = sc_.w * (v.w - mu.w) + sh_.w;
+    m.x = p_silu(m.x); m.y = p_silu(m.y); m.z = p_silu(m.z); m.w = p_silu(m.w);      // act == 1 (launch check)
+    v.x = on ? m.x : v.x; v.y = on ? m.y : v.y; v.z = on ? m.z : v.z; v.w = on ? m.w : v.w;      // padding pixels stay zero AFTER the map
+    return v;
+  };
+  unsigned cur = 0;
+  // LDS store bases (into buffer cur ^ 1): items: row r8 + 8 l, position c * 8 + wt, quad qd; quarter item: row q_row, position q_c * 8 + q_wt
+  const unsigned w_item = lds0 + (unsigned)((r8 * YPW + wt) * YROWB + qd * 8);
+  const unsigned w_quar = lds0 + (unsigned)((q_row * YPW + q_c * 8 + q_wt) * YROWB + q_qd * 8);
+  // conversion of an item in three parts (one per unit): A = map + window tracking of the own pixels, B = edge pixel, neighbours, transform, C = split + store
+  float4 sv[4];
+  auto conv_A = [&](int l) {
+    if constexpr (GN) {
+      const bool rok = (cv_vm >> l) & 1u;
+      apre[l][0] = gn_map(apre[l][0], rok, gmu, gsc, gsh); apre[l][1] = gn_map(apre[l][1], rok, gmu, gsc, gsh);
+    }
+    if constexpr (NS == 4) { pdae_f16_amax4(apre[l][0], 2.0f * ascale, sat_hit); pdae_f16_amax4(apre[l][1], 2.0f * ascale, sat_hit); }
+  };
+  auto conv_B = [&](int l) {
+    float4 de = apre[l][2];
+    if constexpr (GN) de = gn_map(de, (cv_vm >> (2 + l)) & 1u, gmu, gsc, gsh);
+    if constexpr (NS == 4) pdae_f16_amax4(de, 2.0f * ascale, sat_hit);
+    const float4 d1 = apre[l][0], d2 = apre[l][1];
+#define Y_SHR4(V) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x114, 0xf, 0xf, true))      /* row_shr:4: lane - 4 */
+#define Y_SHL4(V) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x104, 0xf, 0xf, true))      /* row_shl:4: lane + 4 */
+    float4 d0 = make_float4(Y_SHR4(d2.x), Y_SHR4(d2.y), Y_SHR4(d2.z), Y_SHR4(d2.w));
+    float4 d3 = make_float4(Y_SHL4(d1.x), Y_SHL4(d1.y), Y_SHL4(d1.z), Y_SHL4(d1.w));
+#undef Y_SHR4
+#undef Y_SHL4
+    if (seg_lo) d0 = de;
+    if (seg_hi) d3 = de;
+#define Y_F4(OP, A_, B_) make_float4(A_.x OP B_.x, A_.y OP B_.y, A_.z OP B_.z, A_.w OP B_.w)
+    sv[0] = Y_F4(-, d0, d2); sv[1] = Y_F4(+, d1, d2); sv[2] = Y_F4(-, d2, d1); sv[3] = Y_F4(-, d1, d3);
+  };
+  auto conv_C = [&](int l, int c0) {               // positions c0, c0 + 1
+    const unsigned dst0 = w_item + (cur ^ 1u) * BUF_B + (unsigned)(l * 8 * YPW) * YROWB;
+#pragma unroll
+    for (int c = c0; c < c0 + 2; ++c) {
+      unsigned a[NP], b2[NP];
+      p_split2<NS>(sv[c].x, sv[c].y, a, ascale);
+      p_split2<NS>(sv[c].z, sv[c].w, b2, ascale);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { const y_u32x2 w2 = {a[p], b2[p]}; *(y_lds_u2)(size_t)(dst0 + (unsigned)(c * 8) * YROWB + (unsigned)p * YPLANE_B) = w2; }
+    }
+  };
+  auto conv_quarter = [&]() {
+    float4 da = qpre[0], db = qpre[1];
+    if constexpr (GN) { da = gn_map(da, (cv_vm >> 4) & 1u, hmu, hsc, hsh); db = gn_map(db, (cv_vm >> 5) & 1u, hmu, hsc, hsh); }
+    if constexpr (NS == 4) { pdae_f16_amax4(da, 2.0f * ascale, sat_hit); pdae_f16_amax4(db, 2.0f * ascale, sat_hit); }
+    // c = 0: d0 - d2; c = 1: d1 + d2; c = 2: d2 - d1; c = 3: d1 - d3   (da = first, db = second pixel of the position)
+    const float sg = q_c == 1 ? 1.0f : -1.0f;
+    float4 s = q_c == 2 ? Y_F4(-, db, da) : make_float4(fmaf(sg, db.x, da.x), fmaf(sg, db.y, da.y), fmaf(sg, db.z, da.z), fmaf(sg, db.w, da.w));
+#undef Y_F4
+    unsigned a[NP], b2[NP];
+    p_split2<NS>(s.x, s.y, a, ascale);
+    p_split2<NS>(s.z, s.w, b2, ascale);
+    const unsigned dst = w_quar + (cur ^ 1u) * BUF_B;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { const y_u32x2 w2 = {a[p], b2[p]}; *(y_lds_u2)(size_t)(dst + (unsigned)p * YPLANE_B) = w2; }
+  };
+
+  // ---- fragments
+  const unsigned a_lane = lds0 + (unsigned)(((wm * 8 + (li >> 2)) * YPW + (li & 3)) * YROWB + h * 16);
+  unsigned abase = a_lane;
+  uint4 fa[2][2][NP];                              // [ring][a2][plane]
+  unsigned abase_n = a_lane;                       // the other buffer: unit 0 of the NEXT step is fetched during unit 11, behind the step's barrier
+  auto lda = [&](uint4 (&af)[2][NP], unsigned base, int u) {      // unit u: ky = u >> 2, c = u & 3
+    const unsigned off = (unsigned)(((u >> 2) * YPW + (u & 3) * 8) * YROWB);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) af[a][p] = __builtin_bit_cast(uint4, *(y_lds_u4)(size_t)(base + off + (unsigned)(a * 4) * YROWB + (unsigned)p * YPLANE_B));
+  };
+  // U fragments of unit u of 16-channel chunk k: prepared layout [p][k >> 1][tp = u][kc = k & 1][nt][lane][8]
+  const size_t plane_main = (size_t)(C >> 5) * 24 * P.NT * 512;
+  const unsigned ps2 = (unsigned)(plane_main * 2);
+  const int lane16 = lane * 16;
+  const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.wp), 0, 0x7fffffff, 0x00020000);
+  uint4 qb[4][2][NP];                              // [unit mod 4][ct][plane]
+  auto ldb = [&](uint4 (&bq)[2][NP], int k, int u, int nt0) {
+    const unsigned soff = (unsigned)((((((k >> 1) * 12 + u) << 1) + (k & 1)) * P.NT + nt0) * 1024);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) bq[ct][p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, lane16, (int)(soff + ct * 1024 + p * ps2), 0));
+  };
+  f32x16 acc[4][2][2];                             // [c][a2][ct]
+  auto mma = [&](const uint4 (&af)[2][NP], const uint4 (&bq)[2][NP], int c, bool zc) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#define PDAE_YA(P_) __builtin_bit_cast(bf16x8, af[a][P_])
+#define PDAE_YB(P_) __builtin_bit_cast(bf16x8, bq[ct][P_])
+#define PDAE_YAH(P_) __builtin_bit_cast(f16x8, af[a][P_])
+#define PDAE_YBH(P_) __builtin_bit_cast(f16x8, bq[ct][P_])
+#define PDAE_Y_EACH(STMT) _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) { STMT; }
+    if constexpr (NS == 4) {
+      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(0), PDAE_YBH(1), zc ? zero : acc[c][a][ct], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(1), PDAE_YBH(0), acc[c][a][ct], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(0), PDAE_YBH(0), acc[c][a][ct], 0, 0, 0))
+    } else if constexpr (NS == 2) {
+      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(1), zc ? zero : acc[c][a][ct], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(1), PDAE_YB(0), acc[c][a][ct], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(0), acc[c][a][ct], 0, 0, 0))
+    } else {
+      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(0), zc ? zero : acc[c][a][ct], 0, 0, 0))
+    }
+#undef PDAE_Y_EACH
+#undef PDAE_YA
+#undef PDAE_YB
+#undef PDAE_YAH
+#undef PDAE_YBH
+  };
+
+  // ---- the pipeline.  Steps of this workgroup in order: step = (tile, k), k = 16-channel chunk.  At the top of an iteration the LDS buffer `cur`
+  // holds the CONVERTED step m (being multiplied), the registers hold the RAW data of step m + 1 (validity bits cv_vm, GroupNorm coefficients
+  // loaded), qb[0..2] hold the U fragments of units 0..2 of step m.  During the iteration: step m + 1 is converted into the other buffer, step
+  // m + 2 (the load position l_*) is loaded into the freed registers, its coefficients at unit 11.
+  int m_tile = blockIdx.x;
+  if (m_tile >= ntiles) return;
+  // Phase stagger: every workgroup has the same work, so without it all 256 reach their (exposed) epilogues together and the output of a whole
+  // round -- 16 x 16 x 128 floats per CU, 33 MB -- queues on the HBM write path while every matrix pipe idles.  Four phase groups per XCD, each
+  // `stagger` x 1024 cycles behind the previous one: a group drains its quarter of the round while the other three multiply.
+  if (stagger > 0) {
+    const int g = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < g * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  int m_img, m_y0, m_x0, m_n0, m_k = 0;
+  Y_DECODE(m_tile, m_img, m_y0, m_x0, m_n0)
+  auto advance = [&](int tile, int k, int& tile2, int& k2) { const bool last = k + 1 >= nk; tile2 = last ? tile + G : tile; k2 = last ? 0 : k + 1; };
+  int l_tile = m_tile, l_k = 0, l_img = m_img, l_y0 = m_y0, l_x0 = m_x0, l_n0 = m_n0;
+  // the load position moves one step ahead: new source, and at a tile boundary the pixel bookkeeping of the new tile (beyond the last step: nothing valid)
+#define PDAE_Y_LD_NEXT()                                                                                      \
+  {                                                                                                           \
+    int t2_, k2_;                                                                                             \
+    advance(l_tile, l_k, t2_, k2_);                                                                           \
+    if (t2_ != l_tile) {                                                                                      \
+      const bool live_ = t2_ < ntiles;                                                                        \
+      if (live_) Y_DECODE(t2_, l_img, l_y0, l_x0, l_n0)                                                       \
+      Y_LD_TILE(l_img, l_y0, l_x0, live_)                                                                     \
+    }                                                                                                         \
+    l_tile = t2_; l_k = k2_;                                                                                  \
+    Y_LD_SRC(l_k)                                                                                             \
+  }
+  // prologue: step 0 converted into buffer 0, step 1 raw in the registers with its coefficients
+  Y_LD_TILE(l_img, l_y0, l_x0, true)
+  Y_LD_SRC(0)
+  gload_item(0); gload_item(1); gload_quarter();
+  coef_load(l_img, 0);
+  cv_vm = ld_vm;
+  cur = 1;                                         // the conversions write buffer cur ^ 1 = 0
+  conv_A(0); conv_B(0); conv_C(0, 0); conv_C(0, 2);
+  conv_A(1); conv_B(1); conv_C(1, 0); conv_C(1, 2);
+  conv_quarter();
+  cur = 0;
+  PDAE_Y_LD_NEXT()
+  gload_item(0); gload_item(1); gload_quarter();
+  coef_load(l_img, l_k);
+  {
+    const int nt0 = (m_n0 >> 5) + wn * 2;
+    ldb(qb[0], 0, 0, nt0); ldb(qb[1], 0, 1, nt0); ldb(qb[2], 0, 2, nt0);
+  }
+  int n_k, n_n0;                                   // chunk / first output channel of step m + 1 (its U fragments are requested from unit 9 on)
+  {
+    int t2;
+    advance(m_tile, 0, t2, n_k);
+    n_n0 = m_n0;
+    if (t2 != m_tile && t2 < ntiles) { int i_, y_, x_; Y_DECODE(t2, i_, y_, x_, n_n0) (void)i_; (void)y_; (void)x_; }
+  }
+  __syncthreads();
+  lda(fa[0], a_lane, 0);
+
+  // timing probes (tools/probe_build.py; WRONG RESULTS by design)
+#ifdef PDAE_Y_PROBE_NOA
+#define PDAE_Y_DO_A(...)
+#else
+#define PDAE_Y_DO_A(...) __VA_ARGS__
+#endif
+#ifdef PDAE_Y_PROBE_NOB
+#define PDAE_Y_DO_B(...)
+#else
+#define PDAE_Y_DO_B(...) __VA_ARGS__
+#endif
+#ifdef PDAE_Y_PROBE_NOCONV
+#define PDAE_Y_CV(...) asm volatile("" :: "v"(apre[0][0].x), "v"(apre[1][0].x), "v"(qpre[0].x), "v"(apre[0][2].w), "v"(apre[1][2].w), "v"(qpre[1].w), "v"(apre[0][1].y), "v"(apre[1][1].y));
+#else
+#define PDAE_Y_CV(...) __VA_ARGS__
+#endif
+#ifdef PDAE_Y_PROBE_NOGLOAD
+#define PDAE_Y_GL(...)
+#else
+#define PDAE_Y_GL(...) __VA_ARGS__
+#endif
+#ifdef PDAE_Y_PROBE_NOSTAGE
+#define PDAE_Y_DO_STAGE(...)
+#else
+#define PDAE_Y_DO_STAGE(...) __VA_ARGS__
+#endif
+  // One unit: patch fragments of the next unit, U fragments of the unit three ahead (into the ring slot the previous unit has freed), one piece
+  // of staging work, the unit's 12 MFMAs.
+#define PDAE_Y_UNIT(U, FIRST, WORK)                                                                           \
+  {                                                                                                           \
+    PDAE_Y_DO_A(if ((U) < 11) lda(fa[((U) + 1) & 1], abase, (U) + 1); else lda(fa[0], abase_n, 0);)           \
+    PDAE_Y_DO_B(if ((U) + 3 < 12) ldb(qb[((U) + 3) & 3], m_k, (U) + 3, m_nt0);                                \
+                else ldb(qb[((U) + 3) & 3], n_k, (U) + 3 - 12, n_nt0);)                                       \
+    PDAE_Y_DO_STAGE(WORK)                                                                                     \
+    mma(fa[(U) & 1], qb[(U) & 3], (U) & 3, (FIRST) && (U) < 4);                                               \
+    PDAE_Y_PATTERN(5)                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  }
+#define PDAE_Y_STEP(FIRST)                                                                                    \
+  {                                                                                                           \
+    const int m_nt0 = (m_n0 >> 5) + wn * 2, n_nt0 = (n_n0 >> 5) + wn * 2;                                     \
+    cv_vm = ld_vm;                                  /* validity of the raw data in the registers (step m + 1) */ \
+    PDAE_Y_LD_NEXT()                                /* the loads of this iteration: step m + 2 */              \
+    abase = a_lane + cur * BUF_B; abase_n = a_lane + (cur ^ 1u) * BUF_B;                                      \
+    asm volatile("" : "+v"(abase), "+v"(abase_n));                                                            \
+    PDAE_Y_UNIT(0, FIRST, PDAE_Y_CV(conv_A(0);))                                                              \
+    PDAE_Y_UNIT(1, FIRST, PDAE_Y_CV(conv_B(0);))                                                              \
+    PDAE_Y_UNIT(2, FIRST, PDAE_Y_CV(conv_C(0, 0);))                                                           \
+    PDAE_Y_UNIT(3, FIRST, PDAE_Y_CV(conv_C(0, 2);))                                                           \
+    PDAE_Y_UNIT(4, FIRST, PDAE_Y_CV(conv_A(1);))                                                              \
+    PDAE_Y_UNIT(5, FIRST, PDAE_Y_CV(conv_B(1);))                                                              \
+    PDAE_Y_UNIT(6, FIRST, PDAE_Y_CV(conv_C(1, 0);))                                                           \
+    PDAE_Y_UNIT(7, FIRST, PDAE_Y_CV(conv_C(1, 2);) PDAE_Y_GL(gload_item(0);))                                 \
+    PDAE_Y_UNIT(8, FIRST, PDAE_Y_CV(conv_quarter();) PDAE_Y_GL(gload_item(1);))                               \
+    PDAE_Y_UNIT(9, FIRST, PDAE_Y_GL(gload_quarter();))                                                        \
+    PDAE_Y_UNIT(10, FIRST, )                                                                                  \
+    __syncthreads();       /* every conversion into the other buffer is done (unit 8), every read of this one is issued (unit 10) */ \
+    PDAE_Y_UNIT(11, FIRST, coef_load(l_img, l_k);)                                                            \
+    cur ^= 1u;                                                                                                \
+  }
+
+  // after a step: the next step of this tile becomes the one being multiplied (the tile change is handled behind the epilogue)
+#define PDAE_Y_NEXT_K()                                                                                       \
+  {                                                                                                           \
+    m_k += 1;                                                                                                 \
+    int t3_;                                                                                                  \
+    advance(m_tile, m_k, t3_, n_k);                                                                           \
+    n_n0 = m_n0;                                                                                              \
+    if (t3_ != m_tile && t3_ < ntiles) { int i_, y_, x_; Y_DECODE(t3_, i_, y_, x_, n_n0) (void)i_; (void)y_; (void)x_; } \
+  }
+  // The first chunk of a tile (accumulators start from zero) is its own straight-line copy IN FRONT of the loop over the others: a join of two
+  // 144-MFMA bodies inside one loop makes the register allocator route the accumulators through VGPRs (conv3x3r.hip)
+  for (;;) {
+    PDAE_Y_STEP(true)
+    for (int kk = 1; kk < nk; ++kk) {
+      PDAE_Y_NEXT_K()
+      PDAE_Y_STEP(false)
+    }
+#ifdef PDAE_Y_PROBE_NOEPI
+    {
+      f32x16 sm = acc[0][0][0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) sm += acc[i >> 2][(i >> 1) & 1][i & 1];
+      float z = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z += sm[r];
+      if (z == 123.456f) P.y[t] = z;
+    }
+#else
+    {
+      // ---- epilogue of the finished tile, straight-line (conv3x3r's drain, not deferred): block b = (channel tile ct, pair half a2) in three stages
+      //   L(b): residual / previous contents of both output columns (8 float4; a possibly EMPTY resource: zeros), two blocks ahead, because the
+      //         vector-memory path returns in order and a load queued behind the previous block's stores waits for their acknowledgements;
+      //   W(b): the four transform-domain accumulators are read once, both output columns (j = 0: M0 + M1 + M2, j = 1: M1 - M2 - M3) go into the
+      //         wave's two private transposition tiles (a dedicated LDS region behind the patch buffers: no barrier on either side of the epilogue);
+      //   S(b): float4 rows back, * scale + bias + residual, stored, statistics summed.
+      const float oscale = NS == 4 ? P.woscale / ascale : 1.0f;
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));               // nothing of the epilogue's per-lane addressing may be hoisted in front of the chunk loop (it was: 34 spilled registers per tile)
+      constexpr unsigned TWB = 32u * EPW * 4u;
+      const unsigned tw = lds0 + 2u * BUF_B + (unsigned)wv * 2u * TWB;
+      const int er = lane_e >> 3, ec = (lane_e & 7) * 4;
+      const unsigned tw_w = tw + (unsigned)((4 * (lane_e >> 5) * EPW + (lane_e & 31)) * 4), tw_r = tw + (unsigned)((er * EPW + ec) * 4);
+      const int y0a = m_y0 + wm * 8, n0w = m_n0 + wn * 64;
+      const int rsh = P.res_mode == 2 ? 1 : 0;             // half-resolution residual (nearest upsample): rows / columns >> 1, both columns of a pair read one pixel
+      const unsigned lane_y = (unsigned)((((er >> 2) * P.W + 2 * (er & 3)) * P.Nout + ec) * 4);
+      const unsigned lane_x = rsh ? (unsigned)(((er & 3) * P.Nout + ec) * 4) : lane_y;
+      const unsigned lane_st = lane_e < 8 ? (unsigned)(lane_e * 8) : YOOB;
+      const unsigned y_it = (unsigned)(2 * P.W * P.Nout * 4), y_j = (unsigned)(P.Nout * 4), y_a2 = (unsigned)(8 * P.Nout * 4);
+      const unsigned x_it = rsh ? (unsigned)((P.W >> 1) * P.Nout * 4) : y_it, x_j = rsh ? 0u : y_j, x_a2 = rsh ? (unsigned)(4 * P.Nout * 4) : y_a2;
+      const unsigned d_rb4 = (unsigned)((((m_img * P.H + y0a) * P.W + m_x0) * P.Nout + n0w) * 4);
+      const unsigned d_xb4 = rsh ? (unsigned)((((m_img * (P.H >> 1) + (y0a >> 1)) * (P.W >> 1) + (m_x0 >> 1)) * P.Nout + n0w) * 4) : d_rb4;
+      const unsigned d_sb8 = (unsigned)(((m_img * P.stat_tpi + ((m_y0 >> 4) * P.tiles_x + (m_x0 >> 4)) * 2 + wm) * (P.Nout >> 2) + (n0w >> 2)) * 8);
+      const float* const extra_ = P.res_mode ? P.res : P.y;      // residual OR (accumulate) the previous contents of y (both: conv3x3y_launch falls back)
+      const unsigned extra_on = (P.res_mode || P.accumulate) ? YALL : 0u, stat_on = P.stat_part ? YALL : 0u, bias_on = P.bias ? YALL : 0u;
+#define Y_RSB(PTR, BYTES) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((const void*)(PTR)), 0, (int)(BYTES), 0x00020000)
+      float4 rv[2][2][4], bias4[2];
+      float st1 = 0.f, st2 = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) bias4[ct] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.bias, bias_on), ec * 4, (int)((n0w + ct * 32) * 4), 0));
+      auto epi_L = [&](int b) {
+        const int ct = b >> 1, a2 = b & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int it = 0; it < 4; ++it)
+            rv[b & 1][j][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(extra_, extra_on), (int)lane_x,
+                                                                                                 (int)(d_xb4 + it * x_it + j * x_j + a2 * x_a2 + ct * 128), 0));
+      };
+      auto epi_W = [&](int b) {
+        const int ct = b >> 1, a2 = b & 1;
+        // the accumulators are read HERE: without the opaque redefinition the sixteen-float extractions of all four blocks were hoisted to the top
+        // of the epilogue (192 v_accvgpr_read up front, 42 spilled registers)
+        asm volatile("" : "+a"(acc[0][a2][ct]), "+a"(acc[1][a2][ct]), "+a"(acc[2][a2][ct]), "+a"(acc[3][a2][ct]));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float m0 = acc[0][a2][ct][r], m1 = acc[1][a2][ct][r], m2 = acc[2][a2][ct][r], m3 = acc[3][a2][ct][r];
+          const unsigned o = tw_w + (unsigned)((((r & 3) + 8 * (r >> 2)) * EPW) * 4);
+          *(y_lds_f)(size_t)(o) = (m0 + m1) + m2;
+          *(y_lds_f)(size_t)(o + TWB) = (m1 - m2) - m3;
+        }
+      };
+      auto epi_S = [&](int b) {
+        const int ct = b >> 1, a2 = b & 1;
+        if (a2 == 0) { st1 = 0.f; st2 = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const y_f32x4 v4 = *(y_lds_f4)(size_t)(tw_r + (unsigned)j * TWB + (unsigned)(it * 8 * EPW * 4));
+            float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            const float4 u = rv[b & 1][j][it], bb = bias4[ct];
+            v.x = fmaf(v.x, oscale, bb.x + u.x); v.y = fmaf(v.y, oscale, bb.y + u.y); v.z = fmaf(v.z, oscale, bb.z + u.z); v.w = fmaf(v.w, oscale, bb.w + u.w);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(y_u32x4, v), Y_RSB(P.y, YALL), (int)lane_y, (int)(d_rb4 + it * y_it + j * y_j + a2 * y_a2 + ct * 128), 0);
+            st1 += (v.x + v.y) + (v.z + v.w);
+            st2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, st2))));
+          }
+        if (a2 == 1) {      // (sum, sum of squares) of the wave's 8 x 16 pixels per channel quad: the eight lanes holding a quad combine, lanes 0..7 write
+          float s1 = st1, s2 = st2;
+          s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8);
+          s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+          const y_u32x2 sv2 = {__float_as_uint(s1), __float_as_uint(s2)};
+          __builtin_amdgcn_raw_buffer_store_b64(sv2, Y_RSB(P.stat_part, stat_on), (int)lane_st, (int)(d_sb8 + ct * 64), 0);
+        }
+      };
+#define Y_EPI_FENCE __builtin_amdgcn_sched_barrier(0);
+      epi_L(0); epi_L(1); Y_EPI_FENCE
+      epi_W(0); Y_EPI_FENCE epi_S(0); Y_EPI_FENCE epi_L(2); Y_EPI_FENCE
+      epi_W(1); Y_EPI_FENCE epi_S(1); Y_EPI_FENCE epi_L(3); Y_EPI_FENCE
+      epi_W(2); Y_EPI_FENCE epi_S(2); Y_EPI_FENCE
+      epi_W(3); Y_EPI_FENCE epi_S(3); Y_EPI_FENCE
+#undef Y_EPI_FENCE
+#undef Y_RSB
+    }
+#endif
+    // the first step of the next tile becomes the one being multiplied
+    const int t2 = m_tile + G;
+    if (t2 >= ntiles) break;
+    Y_DECODE(t2, m_img, m_y0, m_x0, m_n0)
+    m_tile = t2; m_k = 0;
+    {
+      int t3;
+      advance(m_tile, 0, t3, n_k);
+      n_n0 = m_n0;
+      if (t3 != m_tile && t3 < ntiles) { int i_, y_, x_; Y_DECODE(t3, i_, y_, x_, n_n0) (void)i_; (void)y_; (void)x_; }
+    }
+  }
+  if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
+}
+
+template <int NS, bool GN> static int launch_y(const PatchParams& P, hipStream_t s) {
+  const size_t smem = (size_t)2 * NPL(NS) * YPLANE_B + (size_t)4 * 2 * 32 * EPW * 4;      // two patch buffers + two transposition tiles per wave (f16x3: 161280 of 163840 bytes)
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { pdae_set_error("conv3x3y: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  const long long ntiles = (long long)P.N * P.tiles_y * P.tiles_x * P.tiles_n;
+  dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
+  static int stagger = -1;
+  if (stagger < 0) { const char* e = getenv("PDAE_Y_STAGGER"); stagger = e ? atoi(e) : 0; }
+  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0);
+  return pdae_launch_status("conv3x3y");
+}
+
+// P: as prepared by conv3x3x_launch (tiles of 16 x 16 pixels x 128 channels, Winograd-along-x weights); no fused skip chunks
+int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s) {
+  if (P.res_mode && P.accumulate) { pdae_set_error("conv3x3y: residual and accumulate in one launch"); return 1; }
+#define PDAE_Y3(NS_) (P.coef ? launch_y<NS_, true>(P, s) : launch_y<NS_, false>(P, s))
+  if (math == 1) return PDAE_Y3(1);
+  if (math == 2) return PDAE_Y3(2);
+  return PDAE_Y3(4);
+#undef PDAE_Y3
+}

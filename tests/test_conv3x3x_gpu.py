@@ -248,7 +248,7 @@ def test_grouped_weight_preparation_uses_the_same_form(H, monkeypatch):
     """pdae_conv_wprep_job / pdae_conv_wprep_group (one launch for every prepared copy of a plan) must write the same Winograd-form planes as
     pdae_conv_wprep: forward, data-gradient (transposed, fp16 gradient format) and fused-skip jobs."""
     monkeypatch.setenv("PDAE_W1", "2")
-    N, Hh, W, C, Cout, Cs = 16, 64, 32, 64, 128, 96
+    N, Hh, W, C, Cout, Cs = 32, 64, 64, 64, 128, 96
     w = nhwc(rn(1, Cout, C, 3, 3, scale=0.05)).cuda()
     wsk = nhwc(rn(2, Cout, Cs, 1, 1, scale=0.1)).cuda()
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)

@@ -4,7 +4,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pdae_amd.build import CSRC, LIBDIR, SOURCES, HIPCC, FLAGS
-P3, W3, R3, AT, WN, X3 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip", "attention.hip", "winograd.hip", "conv3x3x.hip"
+P3, W3, R3, AT, WN, X3, Y3 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip", "attention.hip", "winograd.hip", "conv3x3x.hip", "conv3x3y.hip"
 VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"]), "nostage": (P3, ["-DPDAE_PROBE_NOSTAGE"]),
             "mfma": (P3, ["-DPDAE_PROBE_NOB", "-DPDAE_PROBE_NOA", "-DPDAE_PROBE_NOSTAGE"]), "clustered": (P3, ["-DPDAE_P3_CLUSTERED"]),
             "w3_nomma": (W3, ["-DPDAE_W3_PROBE_NOMMA"]), "w3_nostage": (W3, ["-DPDAE_W3_PROBE_NOSTAGE"]), "w3_noload": (W3, ["-DPDAE_W3_PROBE_NOLOAD"]),
@@ -19,6 +19,10 @@ VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"])
             "wn_nostore": (WN, ["-DPDAE_WN_PROBE_NOSTORE"]), "wn_loads": (WN, ["-DPDAE_WN_PROBE_NORAW", "-DPDAE_WN_PROBE_NOB"]),
             "x_noa": (X3, ["-DPDAE_X_PROBE_NOA"]), "x_nob": (X3, ["-DPDAE_X_PROBE_NOB"]), "x_nostage": (X3, ["-DPDAE_X_PROBE_NOSTAGE"]),
             "x_mfma": (X3, ["-DPDAE_X_PROBE_NOA", "-DPDAE_X_PROBE_NOB", "-DPDAE_X_PROBE_NOSTAGE"]),
+            "y_noa": (Y3, ["-DPDAE_Y_PROBE_NOA"]), "y_nob": (Y3, ["-DPDAE_Y_PROBE_NOB"]), "y_nostage": (Y3, ["-DPDAE_Y_PROBE_NOSTAGE"]),
+            "y_nogload": (Y3, ["-DPDAE_Y_PROBE_NOGLOAD"]), "y_noconv": (Y3, ["-DPDAE_Y_PROBE_NOCONV"]),
+            "y_noepi": (Y3, ["-DPDAE_Y_PROBE_NOEPI"]),
+            "y_mfma": (Y3, ["-DPDAE_Y_PROBE_NOA", "-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOSTAGE", "-DPDAE_Y_PROBE_NOEPI"]),
             "r_24u": (R3, ["-DPDAE_R_PROBE_24U"]),
             "r_mfma": (R3, ["-DPDAE_R_PROBE_NOA", "-DPDAE_R_PROBE_NOB", "-DPDAE_R_PROBE_NOGLOAD", "-DPDAE_R_PROBE_NOCONV", "-DPDAE_R_PROBE_NODRAIN"])}
 only = sys.argv[1:]
