@@ -502,6 +502,7 @@ static PatchPlan patch_plan(int C, int H, int W, int N, int Nout) {
 // need split-K (its slabs are sized for the main convolution alone)
 bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, int Cs0, int Cs1) {
   if (math < 1 || up || (C & 31) || (Cs0 & 31) || (Cs1 & 31) || (H % 8) || (W % PTW) || (Nout & 3) || Nout < 32) return false;
+  if (conv3x3p_form(math, C, H, W, N, Nout)) return false;      // Winograd-along-x form of the main convolution: no skip chunks there -- the separate 1x1 launch costs less than the form gains
   const PatchPlan q = patch_plan(C + Cs0 + Cs1, H, W, N, Nout);
   return q.blocks / q.splits >= 256;              // enough tiles without split-K (the fused launch never splits)
 }
@@ -530,7 +531,8 @@ static size_t prep_bytes(int math, int Nout, int C) {
 
 // 1: this convolution (launch-side dimensions) is prepared and launched in the Winograd-along-x form (conv3x3x.hip); 0: direct patch kernels.
 // A pure function of the shape and of PDAE_W1 -- weight preparation and launch call it with the same arguments (fused skip chunks follow
-// their main convolution; a launch the direct plan would split over K keeps the direct form).
+// A launch the direct plan would split over K keeps the direct form.  Fused 1x1 skip chunks exist in the direct form only: conv3x3p_skip_ok
+// says no where this function says 1, and the caller computes the skip convolution separately (it then enters as the residual).
 int conv3x3p_form(int math, int C, int H, int W, int N, int Nout) {
   if (!conv3x3x_ok(math, C, H, W, N, Nout)) return 0;
   return patch_plan(C, H, W, N, Nout).splits == 1 ? 1 : 0;
@@ -582,6 +584,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (P.stat_part && ((Nout & 3) || (q.splits != 1 && Nout > 1024))) { pdae_set_error("conv3x3p: output statistics requested for Nout = %d", Nout); return PDAE_EINVAL; }
   // Winograd F(2, 3) along x (conv3x3x.hip): two thirds of the MFMAs; the prepared weights are in that form iff conv3x3p_form says so
   if (!q.w8 && conv3x3p_form(math, C, H, W, N, Nout)) {
+    if (sk) { pdae_set_error("conv3x3p: fused skip chunks are not built for the Winograd form (pdae_conv2d_fwd_skip_ok == 0 for this shape)"); return PDAE_EINVAL; }
     if (coef && !act) { pdae_set_error("conv3x3p: fused GroupNorm input without SiLU is not built for the Winograd form"); return PDAE_EINVAL; }
     P.stat_tpi = (H / 16) * (W / 16) * 2;
     return conv3x3x_launch(math, P, s);
@@ -638,8 +641,8 @@ void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transpose
   else fill_job3(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, j);
 }
 void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, WprepJob* j, int H, int W, int N) {
-  if (conv3x3p_form(math, Cmain, H, W, N, Nout)) fill_job3(math, w, Nout, Cs, PDAE_WPREP_FORM_X, conv3x3p_wscale(Cmain) * PASCALE, 2, wp, j);
-  else fill_job3(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain) * PASCALE, 1, wp, j);
+  (void)H; (void)W; (void)N;                               // launches with fused skip chunks exist in the direct form only
+  fill_job3(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain) * PASCALE, 1, wp, j);
 }
 
 // weights of a 1x1 skip convolution [Nout][Cs] for the skip chunks of a 3x3 launch whose main input has Cmain channels: same plane
@@ -649,6 +652,6 @@ size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs) {      // (4 k-halv
   return (((size_t)NS * (Cs >> 5) * 4 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short)) + 255) & ~(size_t)255;
 }
 int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s, int H, int W, int N) {
-  if (conv3x3p_form(math, Cmain, H, W, N, Nout)) return wprep_launch(math, w, Nout, Cs, PDAE_WPREP_FORM_X, conv3x3p_wscale(Cmain) * PASCALE, 2, wp, s);
+  (void)H; (void)W; (void)N;
   return wprep_launch(math, w, Nout, Cs, 0, conv3x3p_wscale(Cmain) * PASCALE, 1, wp, s);      // x PASCALE: the skip chunks' activations are unscaled
 }

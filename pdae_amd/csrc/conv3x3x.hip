@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(XTHREADS, 2) conv3x3x_kernel(const PatchParams
 }
 
 // ---- host side
-static int x_mode() { const char* e = getenv("PDAE_W1"); return e ? atoi(e) : 0; }      // 0: off; 1: large layers (fill heuristic of conv3x3r); 2: every eligible shape (tests)
+static int x_mode() { const char* e = getenv("PDAE_W1"); return e ? atoi(e) : 1; }      // 0: off; 1 (default): layers with at least a chip-full of tiles; 2: every eligible shape (tests)
 
 // Form of the prepared weights AND of the launch of a 3x3 convolution with these launch-side dimensions (C input channels, H x W output grid,
 // Nout output channels): decided from the shape alone so that weight preparation and launch agree (the fused skip chunks follow the main
@@ -375,7 +375,7 @@ bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout) {
   if (m == 2) return true;
   const long long tiles = (long long)N * (H / XTH) * (W / PTW) * (Nout / PBN);
   const long long rounds = (tiles + 255) / 256;
-  return tiles >= 512 && tiles * 100 >= rounds * 256 * 85;
+  return tiles >= 256 && tiles * 100 >= rounds * 256 * 85;      // persistent workgroups: the last round must not leave the chip idle
 }
 
 template <int NS, bool GN> static int launch_x(const PatchParams& P, hipStream_t s) {

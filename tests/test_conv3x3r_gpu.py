@@ -24,6 +24,12 @@ def H():
     return hip
 
 
+@pytest.fixture(autouse=True)
+def _direct_form(monkeypatch):
+    """These tests are about the two DIRECT kernels: the Winograd-along-x form (conv3x3y.hip, the default on chip-filling layers) is switched off."""
+    monkeypatch.setenv("PDAE_W1", "0")
+
+
 def rn(seed, *shape, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale

@@ -141,53 +141,71 @@ def test_fused_groupnorm_input_vs_fp64(H, monkeypatch, case):
     assert e_x < 1e-5
 
 
-@pytest.mark.parametrize("case", [(16, 64, 32, 64, 64, 32, 128, True), (16, 64, 32, 32, 96, 0, 128, False), (8, 64, 64, 96, 32, 32, 256, False)])
-def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case):
-    """conv3x3(x) + conv1x1([s0 | s1]) in one K loop -- the skip chunks are the centre tap: transform positions 1 and 2 with weights +-w / 2 --
-    and the GroupNorm partial statistics of the output written by the epilogue, after the reader's fp64 combine."""
-    N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
-    Cs, G = Cs0 + Cs1, 32
-    x = rn(1, N, C, Hh, W) * 1.2 + 0.3
-    sx = rn(2, N, Cs, Hh, W) * 2.0
-    w = rn(3, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(4, Cout, scale=0.1)
-    wsk = rn(5, Cout, Cs, 1, 1, scale=1.0 / math.sqrt(Cs)); bsk = rn(6, Cout, scale=0.1)
-    gamma, beta = 1 + 0.2 * rn(7, C), 0.2 * rn(8, C) + 0.4
+@pytest.mark.parametrize("case", [(16, 64, 32, 32, 96, 0, 128), (8, 64, 64, 96, 32, 32, 256)])
+def test_fused_skip_chunks_exist_in_the_direct_form_only(H, monkeypatch, case):
+    """A convolution launched in the Winograd-along-x form takes no fused 1x1 skip chunks: pdae_conv2d_fwd_skip_ok says no (the caller computes the
+    skip convolution separately and hands it in as the residual -- engine.resblock), pdae_conv_skip_wprep_bytes is 0 and the launch itself refuses.
+    The same pair IS eligible when the form is off."""
+    N, Hh, W, C, Cs0, Cs1, Cout = case
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
     cs = H.Conv(N, Hh, W, Cs0, Cs1, Cout, k=1, math=4)
-    if not H.conv_fwd_skip_ok(c, cs):
-        pytest.skip("pair not eligible for the fused launch at this size")
+    monkeypatch.setenv("PDAE_W1", "0")
+    assert H.conv_fwd_skip_ok(c, cs) and H.conv_skip_wprep_bytes(c, cs) > 0
+    nb_skip = H.conv_skip_wprep_bytes(c, cs)
+    monkeypatch.setenv("PDAE_W1", "2")
+    assert not H.conv_fwd_skip_ok(c, cs) and H.conv_skip_wprep_bytes(c, cs) == 0
+    x = torch.randn(N, Hh, W, C, device="cuda"); s0 = torch.randn(N, Hh, W, Cs0, device="cuda")
+    s1 = torch.randn(N, Hh, W, Cs1, device="cuda") if Cs1 else None
+    w = torch.randn(Cout, 3, 3, C, device="cuda") * 0.05; b = torch.zeros(Cout, device="cuda")
+    wp = torch.empty(c.wprep_bytes(0, force=True) // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, w, 0, wp))
+    wps = torch.zeros(nb_skip // 4, device="cuda")
+    y = torch.empty(N, Hh, W, Cout, device="cuda")
+    with pytest.raises(H.PdaeError):
+        H.run(H.op_conv_fwd_skip(c, x, None, None, 0, wp, b, cs, s0, s1, wps, b, y))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", [(16, 64, 32, 64, 128, True, 0), (16, 64, 32, 32, 128, False, 1), (8, 64, 64, 96, 256, True, 1)])
+def test_output_statistics_from_the_epilogue(H, monkeypatch, case):
+    """The GroupNorm partial statistics of the output ((sum, sum of squares) per wave tile and channel quad, written by the epilogue: plain and
+    fused-GroupNorm launches, with and without a residual), after the reader's fp64 combine (pdae_gn_coef_from_conv_stats)."""
+    N, Hh, W, C, Cout, use_gn, res_mode = case
+    G = 32
+    x = rn(1, N, C, Hh, W) * 1.2 + 0.3
+    w = rn(3, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(4, Cout, scale=0.1)
+    gamma, beta = 1 + 0.2 * rn(7, C), 0.2 * rn(8, C) + 0.4
+    res = rn(5, N, Cout, Hh, W) if res_mode else None
+    c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
     a_ref = _gn_ref(x.double(), gamma.double(), beta.double(), None) if use_gn else x.double()
-    y_ref = F.conv2d(a_ref, w.double(), b.double(), padding=1) + F.conv2d(sx.double(), wsk.double(), bsk.double())
-    xd, sh = nhwc(x).cuda(), nhwc(sx).cuda()
-    s0 = sh[..., :Cs0].contiguous(); s1 = sh[..., Cs0:].contiguous() if Cs1 else None
-    wd, wsd = nhwc(w).cuda(), nhwc(wsk).cuda()
+    y_ref = F.conv2d(a_ref, w.double(), b.double(), padding=1) + (res.double() if res_mode else 0.0)
+    xd, wd = nhwc(x).cuda(), nhwc(w).cuda()
+    resd = nhwc(res).cuda() if res_mode else None
     coef = None
     if use_gn:
         mean, rstd, coef = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, C, device="cuda")
         ws = torch.empty(H.gn_ws_bytes(N, C) // 4 + 64, device="cuda")
         H.run(H.op_gn_stats_coef(xd, C, None, 0, N, Hh * W, G, 1e-5, gamma.cuda(), beta.cuda(), None, None, mean, rstd, coef, ws))
-    nbytes, tpi = H.conv_stats_bytes(c, cs)
-    assert nbytes > 0
     g2, b2 = (1 + 0.1 * rn(9, Cout)).cuda(), (0.1 * rn(10, Cout)).cuda()
 
     def run():
+        nbytes, tpi = H.conv_stats_bytes(c, None)
+        assert nbytes > 0
         wp = torch.empty(c.wprep_bytes(0, force=True, gn=use_gn) // 4, device="cuda")
         H.run(H.op_conv_wprep(c, wd, 4 if use_gn else 0, wp))
-        wps = torch.empty(H.conv_skip_wprep_bytes(c, cs) // 4, device="cuda")
-        H.run(H.op_conv_skip_wprep(c, cs, wsd, wps))
         y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
         part = torch.full((nbytes // 4,), float("nan"), device="cuda")
-        H.run(H.op_conv_fwd_skip(c, xd, None, coef, 1, wp, b.cuda(), cs, s0, s1, wps, bsk.cuda(), y, stats=part))
+        if use_gn:
+            H.run(H.op_conv_fwd_gn(c, xd, None, coef, 1, wp, b.cuda(), y, res=resd, res_mode=res_mode, stats=part))
+        else:
+            H.run(H.op_conv_fwd(c, xd, None, wd, b.cuda(), y, res=resd, res_mode=res_mode, wp=wp, stats=part))
         m, r, k = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, Cout, device="cuda")
         H.run(H.op_gn_coef_from_conv_stats(N, Hh * W, Cout, 0, G, 1e-5, part, tpi, None, 0, g2, b2, None, None, m, r, k))
         return y, part, m, r
     (y_p, part_p, m_p, r_p), (y_x, part_x, m_x, r_x) = _both(monkeypatch, run)
     e_x = rel_err(nchw(y_x), y_ref)
-    print(f"[conv3x3x fused skip] {case}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(y_p), y_ref):.2e})")
+    print(f"[conv3x3x statistics] {case}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(y_p), y_ref):.2e})")
     assert e_x < 1e-5
-    # (a main convolution the direct plan would split over K keeps the direct form, skip chunks included: case 0; the other two differ in rounding)
-    if case[3] != 64:
-        assert not torch.equal(y_p, y_x)
     assert torch.isfinite(part_x).all()
     yd = y_x.double()
     mean_ref = yd.view(N, Hh * W, G, Cout // G).mean((1, 3)).flatten()
@@ -246,14 +264,12 @@ def test_accumulating_data_gradient(H, monkeypatch):
 
 def test_grouped_weight_preparation_uses_the_same_form(H, monkeypatch):
     """pdae_conv_wprep_job / pdae_conv_wprep_group (one launch for every prepared copy of a plan) must write the same Winograd-form planes as
-    pdae_conv_wprep: forward, data-gradient (transposed, fp16 gradient format) and fused-skip jobs."""
+    pdae_conv_wprep: forward, fused-GroupNorm forward and data-gradient (transposed, fp16 gradient format) jobs."""
     monkeypatch.setenv("PDAE_W1", "2")
-    N, Hh, W, C, Cout, Cs = 32, 64, 64, 64, 128, 96
+    N, Hh, W, C, Cout = 32, 64, 64, 64, 128
     w = nhwc(rn(1, Cout, C, 3, 3, scale=0.05)).cuda()
-    wsk = nhwc(rn(2, Cout, Cs, 1, 1, scale=0.1)).cuda()
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
     cd = H.Conv(N, Hh, W, Cout, 0, C, k=3, math=4)       # its data gradient has GEMM N = Cout of this descriptor... use a 128-input-channel conv
-    cs = H.Conv(N, Hh, W, Cs, 0, Cout, k=1, math=4)
     wd2 = nhwc(rn(3, C, Cout, 3, 3, scale=0.05)).cuda()  # weights of cd: (Cout = C, Cin = Cout)
     singles, jobs = [], []
     for (cc, ww, flags) in ((c, w, 0), (c, w, 4), (cd, wd2, 1 | 16)):
@@ -261,9 +277,6 @@ def test_grouped_weight_preparation_uses_the_same_form(H, monkeypatch):
         b = torch.zeros_like(a)
         H.run(H.op_conv_wprep(cc, ww, flags, a))
         singles.append(a); jobs.append((H.wprep_job(cc, ww, flags, b), b))
-    a = torch.zeros(H.conv_skip_wprep_bytes(c, cs) // 4, device="cuda"); b = torch.zeros_like(a)
-    H.run(H.op_conv_skip_wprep(c, cs, wsk, a))
-    singles.append(a); jobs.append((H.skip_wprep_job(c, cs, wsk, b), b))
     jt, ft, tot = H.wprep_group_tables([j for j, _ in jobs], torch.device("cuda"))
     H.run(H.op_conv_wprep_group(jt, ft, len(jobs), tot))
     torch.cuda.synchronize()

@@ -597,8 +597,10 @@ def test_conv_with_fused_groupnorm_input(H, case, math_mode):
 
 @pytest.mark.parametrize("math_mode", [1, 3, 4])
 @pytest.mark.parametrize("case", [(16, 64, 32, 64, 64, 32, 64, True), (16, 64, 32, 64, 96, 0, 128, False), (32, 32, 32, 32, 32, 32, 32, True)])
-def test_conv_with_fused_skip_connection(H, case, math_mode):
-    """pdae_conv2d_fwd_skip: conv3x3(in) + conv1x1([s0 | s1]) + both biases in one launch, with plain and fused-GroupNorm main input."""
+def test_conv_with_fused_skip_connection(H, monkeypatch, case, math_mode):
+    """pdae_conv2d_fwd_skip: conv3x3(in) + conv1x1([s0 | s1]) + both biases in one launch, with plain and fused-GroupNorm main input.
+    (Fused skip chunks exist in the direct form only: the Winograd-along-x form of chip-filling layers is switched off here.)"""
+    monkeypatch.setenv("PDAE_W1", "0")
     N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
     Cs, G = Cs0 + Cs1, 32
     tol = MATH_TOL[math_mode]
@@ -638,11 +640,13 @@ def test_conv_with_fused_skip_connection(H, case, math_mode):
                                   # split-K launches (small layers): the statistics come from the slab reduction
                                   (32, 8, 8, 512, 0, 512, "plain"), (32, 16, 16, 384, 0, 384, "plain"), (4, 16, 16, 128, 0, 128, "gn"),
                                   (8, 32, 32, 256, 0, 256, "plain"), (3, 16, 16, 96, 32, 128, "gn")])
-def test_groupnorm_statistics_from_the_producing_convolution(H, case):
+def test_groupnorm_statistics_from_the_producing_convolution(H, monkeypatch, case):
     """pdae_conv_stats_arm + pdae_gn_coef_from_conv_stats: the 3x3 forward kernels (plain, fused-GroupNorm input, fused skip, image-pair tiles,
     odd batch) leave per-wave (sum, sum of squares) of their OUTPUT behind, and the next GroupNorm's mean / rstd / coefficients computed from
     them match the statistics pass over the stored tensor -- alone and as the second source of a two-tensor concat."""
     N, Hh, W, C0, C1, Cout, form = case
+    if form == "skip":
+        monkeypatch.setenv("PDAE_W1", "0")          # fused skip chunks exist in the direct form only
     C, G = C0 + C1, 32
     x = rn(1, N, C, Hh, W) * 1.3 + 0.4
     w = rn(2, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(3, Cout, scale=0.5) + 0.8       # a mean well away from zero
@@ -817,10 +821,11 @@ def test_grouped_linear_with_a_sampling_batch_over_32_rows(H):
         assert ctx.Nb == Nb and rel_err(y, x.double() @ P[f"l{i}.weight"].double().T + P[f"l{i}.bias"].double()) < 1e-6
 
 
-def test_grouped_weight_preparation_equals_the_single_launches(H):
+def test_grouped_weight_preparation_equals_the_single_launches(H, monkeypatch):
     """pdae_conv_wprep_group: every prepared-weight form the engine uses (3x3 forward, fused-GroupNorm two-source, data-gradient in the exact
     and the fp16-gradient format, 1x1 forward / data gradient, fused skip chunks; bf16 and split formats) written by ONE launch from a job
     table equals, bit for bit, what pdae_conv_wprep / pdae_conv_skip_wprep write one launch at a time."""
+    monkeypatch.setenv("PDAE_W1", "0")              # the fused-skip job below exists in the direct form only (Winograd-form jobs: tests/test_conv3x3x_gpu.py)
     jobs, singles, keep = [], [], []                # a job holds raw pointers: the weights must outlive the grouped launch
 
     def add(c, w, flags, nbytes):
