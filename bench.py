@@ -11,8 +11,9 @@ resident in HBM, randomly initialised weights of the FFHQ-128 architecture ([ASS
 hyper-parameters).  Nothing is skipped inside the timed region.
 
 Rank 0 prints ONE JSON line; `value` is whole-job images/s.  Extra objects:
-  roofline     -- the dominant kernel: the 3x3 forward / data-gradient patch kernels (conv3x3r: persistent, deferred epilogue, on the large
-                  layers; conv3x3p on the small ones), split-fp16 MFMA: algorithmic FLOPs of their launches in one step / their summed
+  roofline     -- the dominant kernel: the 3x3 forward / data-gradient patch kernels (conv3x3y: Winograd F(2,3) along x, persistent, on
+                  chip-filling layers -- priced at the 2 MFMAs per product it issues; conv3x3r: direct persistent form for launches with fused
+                  skip chunks; conv3x3p on the small ones), split-fp16 MFMA: algorithmic FLOPs of their launches in one step / their summed
                   durations, measured here with HIP events on the launch stream (per-op event pairs, one extra un-timed step); `wgrad` and
                   `family` carry the same figures for the 3x3 weight-gradient kernel and for every conv / GEMM launch together;
   step_mfma_roofline_frac / step_hbm_roofline_frac -- the whole step against the MFMA floor (step FLOPs x 3 products / 2.5 PFLOP/s) and
@@ -445,6 +446,12 @@ def main():
             if math == "f16x3":                       # two fp16 planes in the forward 3x3 patch kernel only; everything else bf16x6
                 fwd3 = op.kind in (H.OP_CONV_FWD_GN, H.OP_CONV_FWD_SKIP) or (op.kind == H.OP_CONV_FWD and bool(op.p[6]) and op.i[8] == 3)
                 grad3 = (op.kind == H.OP_CONV_DGRAD and bool(op.p[4])) or (op.kind == H.OP_CONV_WGRAD and bool(op.p[6]))     # dy_amax given
+                if (fwd3 and op.kind != H.OP_CONV_FWD_SKIP) or op.kind == H.OP_CONV_DGRAD and grad3:
+                    # Winograd F(2, 3)-along-x form (conv3x3y.hip): 4 transform positions per 2 outputs x 3 taps = two thirds of the MFMAs
+                    i = op.i
+                    c = H.Conv(i[0], i[1], i[2], i[3], i[4], i[7], k=i[8], stride=i[10], pad=i[11], up=bool(i[12]), math=i[13])
+                    if c.winograd_form(int(op.kind == H.OP_CONV_DGRAD), gn=op.kind == H.OP_CONV_FWD_GN, f16_grad=op.kind == H.OP_CONV_DGRAD):
+                        return 2
                 return 3 if (fwd3 or grad3) else 6
             return npm
         # peak for the arithmetic actually executed: f32 MFMA 157.3 TF, or the dense bf16 MFMA peak divided by the number of
@@ -474,7 +481,8 @@ def main():
 
         dense = getattr(st.plan, "dense_grid", set())    # stride-2 convs run as stride-1 launches on a 75 %-zero grid: not part of the kernel's roofline set
         pk = [k for k in range(st.n_bwd) if is_patch(st.plan.arr[k]) and k not in dense]
-        kname = "conv3x3r_kernel + conv3x3p_kernel (3x3 conv forward + data gradient, LDS-patch kernels: persistent / deferred-epilogue form on the large layers)"
+        kname = ("conv3x3y_kernel + conv3x3r_kernel + conv3x3p_kernel (3x3 conv forward + data gradient, LDS-patch kernels: Winograd F(2,3)-along-x persistent form on "
+                 "chip-filling layers, direct persistent / deferred-epilogue form for launches with fused skip chunks, two-waves-per-SIMD form on the small layers)")
         if not pk:                                    # f32 mode: every convolution runs on the generic f32-MFMA implicit GEMM
             pk = [k for k in range(st.n_bwd) if fl[k] > 0 and st.plan.arr[k].kind != H.OP_GEMM]
             kname = "igemm_kernel (generic implicit-GEMM convolution, f32 MFMA)"
@@ -489,7 +497,8 @@ def main():
             prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
             pmc_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof, f)))
             pmc = json.load(open(os.path.join(prof, pmc_file)))
-            kk = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3r_kernel<") or (k_.startswith("void conv3x3p_kernel<") and ", 8, false" in k_)]   # every non-pair instantiation
+            kk = [v for k_, v in pmc["kernels"].items()
+                  if k_.startswith("void conv3x3y_kernel<") or k_.startswith("void conv3x3r_kernel<") or (k_.startswith("void conv3x3p_kernel<") and ", 8, false" in k_)]   # every non-pair instantiation
             wk_pmc = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3w_kernel<") and "false" in k_]
             if kk and pmc.get("math", "bf16x6") == math:
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kk) / sum(v["dispatches"] for v in kk))
@@ -521,13 +530,13 @@ def main():
                            "math": math, "achieved": round(p_fl / p_ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                            "frac": round(p_fl / p_ms / 1e9 / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                            "traffic_source": traffic_src, "traffic_measured_in_this_run": False, "algorithmic_bytes_per_launch": round(p_by / max(len(pk), 1)),
-                           "peak_note": "algorithmic TFLOP/s; peak = dense 16-bit MFMA peak (2500) / average MFMAs issued per algorithmic product of these launches",
+                           "peak_note": "algorithmic TFLOP/s; peak = dense 16-bit MFMA peak (2500) / average MFMAs issued per algorithmic product of these launches (direct f16x3: 3; Winograd-along-x f16x3: 2)",
                            "launches_per_step": len(pk), "avg_launch_ms": round(p_ms / max(len(pk), 1), 4),
                            "algorithmic_gflop_per_launch": round(p_fl / 1e9 / max(len(pk), 1), 2), "kernel_ms_per_step": round(p_ms, 3),
                            "frac_of_f32_mfma_peak": round(p_fl / p_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                            "heaviest_launch": {"gflop": round(fl[kbig] / 1e9, 2), "ms": round(durs[kbig], 4),
                                                "tflops": round(fl[kbig] / durs[kbig] / 1e9, 2)},
-                           "family": {"kernels": "conv3x3r + conv3x3p + conv3x3w + conv1x1 + igemm(_bf) (every conv fwd/dgrad/wgrad and dense GEMM)",
+                           "family": {"kernels": "conv3x3y + conv3x3r + conv3x3p + conv3x3w + conv1x1 + igemm(_bf) (every conv fwd/dgrad/wgrad and dense GEMM)",
                                       "achieved": round(ig_fl / ig_ms / 1e9, 2), "frac": round(ig_fl / ig_ms / 1e9 / fam_peak, 4), "peak": round(fam_peak, 1),
                                       "launches_per_step": n_ig, "algorithmic_gflop_per_step": round(ig_fl / 1e9, 1),
                                       "ms_per_step": round(ig_ms, 3), "all_ops_ms_per_step": round(sum(durs), 3)}}

@@ -65,6 +65,10 @@ int pdae_set_saturation_counter(unsigned int* counter);
 #define PDAE_WPREP_F16_GRAD 16     /* with TRANSPOSED and math 4: data-gradient weights in the fp16 format (the launch then needs dy_amax) */
 #define PDAE_WPREP_FORCE 2        /* _bytes: shape eligibility only, ignore the "enough tiles to fill 256 CUs" heuristic */
 size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags);
+/* 1 when the prepared copy pdae_conv_wprep(d, w, flags) and the launch that takes it are in the Winograd F(2, 3)-along-x form (conv3x3y.hip: two
+ * thirds of the matrix instructions of the direct form, chip-filling layers only); 0 for the direct kernels or when there is no prepared copy.
+ * Informational (bench.py prices a launch's roofline by the instructions it issues); flags as for pdae_conv_wprep_bytes. */
+int pdae_conv3x3_form(const pdae_conv_desc* d, int flags);
 int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream);
 /* y[N,Ho,Wo,Cout] = conv(x) + bias (+ res).  res_mode: 0 none, 1 res[N,Ho,Wo,Cout], 2 res stored at half resolution
  * (the x_upd(x) skip of an up-ResBlock, module.py:279-284,297).  tile: 0 = auto, 64 or 128.  wp: NULL or pdae_conv_wprep(d, w, 0). */

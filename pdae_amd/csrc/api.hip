@@ -21,7 +21,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 6; }
+extern "C" int pdae_abi_version(void) { return 7; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -86,6 +86,14 @@ extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
     return transposed ? conv1x1_wprep_bytes(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), Cin, d->Cout, M) : conv1x1_wprep_bytes(d->math, d->Cout, Cin, M);
   }
   return 0;
+}
+
+extern "C" int pdae_conv3x3_form(const pdae_conv_desc* d, int flags) {
+  if (pdae_conv_wprep_bytes(d, flags) == 0 || d->KH != 3) return 0;
+  const int transposed = flags & PDAE_WPREP_TRANSPOSED;
+  const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
+  if (transposed) return conv3x3p_form(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), d->Cout, Hl, Wl, d->N, Cin);
+  return conv3x3p_form(d->math, Cin, d->Ho, d->Wo, d->N, d->Cout);
 }
 
 extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream) {

@@ -110,7 +110,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_wino_wprep_bytes", "pdae_wino_wprep", "pdae_wino_fwd", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv3x3_form", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_wino_wprep_bytes", "pdae_wino_wprep", "pdae_wino_fwd", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_subsample2", "pdae_zero_insert2", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_bwd_group", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
@@ -234,6 +234,11 @@ class Conv:
         for n, v in zip([f[0] for f in ConvDesc._fields_], self.fields()):
             setattr(d, n, v)
         return d
+
+    def winograd_form(self, transposed=0, gn=False, f16_grad=False):
+        """True when this convolution's prepared copy / launch are in the Winograd F(2, 3)-along-x form (pdae_conv3x3_form)."""
+        d = self.cdesc()
+        return bool(lib().pdae_conv3x3_form(ctypes.byref(d), int(transposed) | (4 if gn else 0) | (16 if f16_grad else 0)))
 
     def wprep_bytes(self, transposed=0, force=False, gn=False, f16_grad=False):
         """Size of the prepared-weight copy for the patch kernel; 0 = not eligible (generic kernel runs).

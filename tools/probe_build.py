@@ -21,6 +21,7 @@ VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"])
             "x_mfma": (X3, ["-DPDAE_X_PROBE_NOA", "-DPDAE_X_PROBE_NOB", "-DPDAE_X_PROBE_NOSTAGE"]),
             "y_noa": (Y3, ["-DPDAE_Y_PROBE_NOA"]), "y_nob": (Y3, ["-DPDAE_Y_PROBE_NOB"]), "y_nostage": (Y3, ["-DPDAE_Y_PROBE_NOSTAGE"]),
             "y_nogload": (Y3, ["-DPDAE_Y_PROBE_NOGLOAD"]), "y_noconv": (Y3, ["-DPDAE_Y_PROBE_NOCONV"]),
+            "y_nobgl": (Y3, ["-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOGLOAD"]), "y_noabgl": (Y3, ["-DPDAE_Y_PROBE_NOA", "-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOGLOAD"]),
             "y_noepi": (Y3, ["-DPDAE_Y_PROBE_NOEPI"]),
             "y_mfma": (Y3, ["-DPDAE_Y_PROBE_NOA", "-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOSTAGE", "-DPDAE_Y_PROBE_NOEPI"]),
             "r_24u": (R3, ["-DPDAE_R_PROBE_24U"]),
