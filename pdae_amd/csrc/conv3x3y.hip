@@ -3,9 +3,11 @@
 // fragments one 6-MFMA step ahead, 0.75-0.9x of the default routing; profiles/r04_winograd_probe.txt).  The probe build of conv3x3r with 24 of
 // its 36 units per chunk -- exactly this form's matrix work -- runs 0.598 vs 0.857 ms on 128x128 256->128, B = 32.
 //
-//   * 4 waves, one per SIMD, 512 registers: wave (wm, wn) = 8 rows x 8 pixel pairs x 64 output channels, accumulators acc[c][a2][ct] = 16 tiles of
-//     32 x 32 in the 256 AGPRs (transform position c, pair half a2, channel tile ct).  No second accumulator set: the epilogue is NOT deferred, it
-//     runs between tiles (output transform lane-local, then conv3x3r's transposition + float4 stores, through the patch buffer the last chunk freed).
+//   * 4 waves, one per SIMD, 512 registers: wave w = the whole 16 x 16-pixel tile x 32 output channels (32 w ..), accumulators acc[c][a] = 16 tiles
+//     of 32 x 32 in the 256 AGPRs (transform position c; m-tile a = (row half a >> 1, pair half a & 1)).  Each weight fragment is fetched by ONE
+//     wave (the earlier (8 rows x 64 channels) split fetched every fragment twice per CU: 50 B/clk through the vector cache at full matrix rate,
+//     against 25 now) and used for four products; the patch fragments -- LDS, 256 B/clk -- are read by all four waves.  No second accumulator
+//     set: the epilogue is NOT deferred, it runs between tiles (output transform lane-local, conv3x3r's transposition + float4 stores).
 //   * chunk = 16 input channels = one k-step per (ky, c): 12 units of 12 MFMAs (2 halves x 2 channel tiles x 3 products, a dependent pair 4 issues
 //     apart); U fragments: ring of four units (requested three units = 36 MFMAs ahead), patch fragments: ring of two.
 //   * LDS patch in the transform domain, double buffered: 18 rows x 36 positions (c * 8 + pair) x 48-byte rows (16 channels + pad: 36 * 48 = 192
@@ -42,19 +44,22 @@ typedef __attribute__((address_space(3))) const y_f32x4* y_lds_f4;
   _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
     __builtin_amdgcn_sched_group_barrier(0x006, NV, 0);                                                    \
-    if (i_ < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    if (i_ < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                     \
     if (i_ >= 4) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                                        \
     __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);                                                     \
   }
 
+// tile index -> (image, tile row, tile column, channel tile) without integer divisions: q = (n * m) >> 32 with m = floor(2^32 / d) + 1 is n / d for
+// n * d < 2^32 (launch check); d == 1 has no 32-bit m
+struct YDiv { unsigned mn, mx, my; };
+
 template <int NS, bool GN>
-__global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams P, const int stagger) {
+__global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams P, const int stagger, const YDiv D) {
   constexpr int NP = NPL(NS);
   constexpr unsigned BUF_B = NP * YPLANE_B;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, h = lane >> 5;
-  const int wm = wv >> 1, wn = wv & 1;
   const int C = P.C, C1 = C - P.C0, nk = C >> 4;
   const int ntiles = P.N * P.tiles_y * P.tiles_x * P.tiles_n, G = gridDim.x;
   const unsigned lds0 = (unsigned)(size_t)smem;
@@ -63,9 +68,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   const int up_sh = P.up ? 1 : 0;
   const float* const x1_ = P.x1 ? P.x1 : P.x;
 
+#define Y_UDIV(N_, D_, M_) ((D_) == 1 ? (unsigned)(N_) : __umulhi((unsigned)(N_), (M_)))
 #define Y_DECODE(TILE, IMG, Y0, X0, N0)                                                                       \
-  { int tl_ = (TILE); const int tn_ = tl_ % P.tiles_n; tl_ /= P.tiles_n; const int tx_ = tl_ % P.tiles_x; tl_ /= P.tiles_x;   \
-    const int ty_ = tl_ % P.tiles_y; tl_ /= P.tiles_y; IMG = tl_; Y0 = ty_ * 16; X0 = tx_ * 16; N0 = tn_ * 128; }
+  { const unsigned tl_ = (unsigned)(TILE), q1_ = Y_UDIV(tl_, P.tiles_n, D.mn), q2_ = Y_UDIV(q1_, P.tiles_x, D.mx), q3_ = Y_UDIV(q2_, P.tiles_y, D.my);   \
+    IMG = (int)q3_; Y0 = (int)(q2_ - q3_ * (unsigned)P.tiles_y) * 16; X0 = (int)(q1_ - q2_ * (unsigned)P.tiles_x) * 16; N0 = (int)(tl_ - q1_ * (unsigned)P.tiles_n) * 128; }
+#define Y_DECODE_N0(TILE, N0) { const unsigned tl_ = (unsigned)(TILE), q1_ = Y_UDIV(tl_, P.tiles_n, D.mn); N0 = (int)(tl_ - q1_ * (unsigned)P.tiles_n) * 128; }
 
   // ---- staging roles.  Items l = 0, 1: (patch row (t >> 5) + 8 l, pair (t >> 2) & 7, channel quad t & 3): own pixels b = 1, 2 and, for the first / last
   // pair of the row, the edge pixel.  Quarter item (patch rows 16, 17): (row 16 + (t >> 7), pair (t >> 4) & 7, quad (t >> 2) & 3, position t & 3): the
@@ -83,21 +90,27 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   const int ob2 = P.up ? 0 : 1, obe = seg_lo ? -1 : (P.up ? 1 : 2);
 #define Y_LD_TILE(IMG, Y0, X0, LIVE)                                                                          \
   {                                                                                                           \
+    /* the lane's roles are re-derived from the thread index here: kept live across the step they were spilled in the fused-GroupNorm instantiation */ \
+    int t_ = t;                                                                                               \
+    asm volatile("" : "+v"(t_));                                                                              \
+    const int wt_ = (t_ >> 2) & 7, r8_ = t_ >> 5, qc_ = t_ & 3, qwt_ = (t_ >> 4) & 7, qrow_ = 16 + (t_ >> 7); \
+    const int qba_ = qc_ == 0 ? 0 : 1, qbb_ = qc_ == 3 ? 3 : 2;                                               \
+    const bool sl_ = (wt_ & 3) == 0, sh_ = (wt_ & 3) == 3;                                                    \
     ld_vm = 0u;                                                                                               \
     _Pragma("unroll") for (int l = 0; l < 2; ++l) {                                                           \
-      const int ly = (Y0) - 1 + r8 + 8 * l, lx1 = (X0) + 2 * wt;                                              \
+      const int ly = (Y0) - 1 + r8_ + 8 * l, lx1 = (X0) + 2 * wt_;                                            \
       const bool rok = (LIVE) && (unsigned)ly < (unsigned)P.H;                                                \
       ld_pb[l] = ((IMG) * P.Hs + (ly >> up_sh)) * P.Ws + (lx1 >> up_sh);                                      \
-      if (rok) ld_vm |= 1u << l;                                                                              \
-      if (rok && (seg_lo || seg_hi) && (unsigned)(lx1 - 1 + eb) < (unsigned)P.W) ld_vm |= 4u << l;            \
+      ld_vm |= (rok ? 1u : 0u) << l;                                                                          \
+      ld_vm |= ((rok && (sl_ || sh_) && (unsigned)(lx1 - 1 + (sl_ ? 0 : 3)) < (unsigned)P.W) ? 4u : 0u) << l; \
     }                                                                                                         \
     {                                                                                                         \
-      const int ly = (Y0) - 1 + q_row, lxa = (X0) - 1 + 2 * q_wt + q_ba, lxb = (X0) - 1 + 2 * q_wt + q_bb;    \
+      const int ly = (Y0) - 1 + qrow_, lxa = (X0) - 1 + 2 * qwt_ + qba_, lxb = (X0) - 1 + 2 * qwt_ + qbb_;    \
       const bool rok = (LIVE) && (unsigned)ly < (unsigned)P.H;                                                \
       ld_qa = ((IMG) * P.Hs + (ly >> up_sh)) * P.Ws + (lxa >> up_sh);                                         \
       ld_qb = ((IMG) * P.Hs + (ly >> up_sh)) * P.Ws + (lxb >> up_sh);                                         \
-      if (rok && (unsigned)lxa < (unsigned)P.W) ld_vm |= 16u;                                                 \
-      if (rok && (unsigned)lxb < (unsigned)P.W) ld_vm |= 32u;                                                 \
+      ld_vm |= (rok && (unsigned)lxa < (unsigned)P.W) ? 16u : 0u;                                             \
+      ld_vm |= (rok && (unsigned)lxb < (unsigned)P.W) ? 32u : 0u;                                             \
     }                                                                                                         \
   }
   // validity of the data being CONVERTED (one step behind the loads): a copy taken when the load position moves on
@@ -123,14 +136,21 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   };
   // GroupNorm coefficients of the chunk being converted (this thread's quad for the items, and for the quarter item)
   float4 gmu, gsc, gsh, hmu, hsc, hsh;
-  auto coef_load = [&](int img, int k) {
+  auto coef_load = [&](int img, int k) {          // the items' quad: with the raw data, one step ahead
     if constexpr (GN) {
       const size_t NC = (size_t)P.N * C;
       const float* cf = P.coef + (size_t)img * C + (k << 4);
       gmu = *reinterpret_cast<const float4*>(cf + qd * 4); gsc = *reinterpret_cast<const float4*>(cf + NC + qd * 4); gsh = *reinterpret_cast<const float4*>(cf + 2 * NC + qd * 4);
+    }
+  };
+  auto coef_load_q = [&](int img, int k) {        // the quarter item's quad: two units before its conversion (twelve registers less across the step)
+    if constexpr (GN) {
+      const size_t NC = (size_t)P.N * C;
+      const float* cf = P.coef + (size_t)img * C + (k << 4);
       hmu = *reinterpret_cast<const float4*>(cf + q_qd * 4); hsc = *reinterpret_cast<const float4*>(cf + NC + q_qd * 4); hsh = *reinterpret_cast<const float4*>(cf + 2 * NC + q_qd * 4);
     }
   };
+  int c_img = 0, c_k = 0;                          // image / chunk of the raw data being converted
   auto gn_map = [&](float4 v, bool on, const float4& mu, const float4& sc_, const float4& sh_) {
     float4 m;
     m.x = sc_.x * (v.x - mu.x) + sh_.x; m.y = sc_.y * (v.y - mu.y) + sh_.y; m.z = sc_.z * (v.z - mu.z) + sh_.z; m.w = sc_.w * (v.w - mu.w) + sh_.w;
@@ -195,48 +215,50 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   };
 
   // ---- fragments
-  const unsigned a_lane = lds0 + (unsigned)(((wm * 8 + (li >> 2)) * YPW + (li & 3)) * YROWB + h * 16);
+  const unsigned a_lane = lds0 + (unsigned)(((li >> 2) * YPW + (li & 3)) * YROWB + h * 16);
   unsigned abase = a_lane;
-  uint4 fa[2][2][NP];                              // [ring][a2][plane]
+  uint4 fa[2][4][NP];                              // [ring][m-tile a][plane]
   unsigned abase_n = a_lane;                       // the other buffer: unit 0 of the NEXT step is fetched during unit 11, behind the step's barrier
-  auto lda = [&](uint4 (&af)[2][NP], unsigned base, int u) {      // unit u: ky = u >> 2, c = u & 3
+  auto lda = [&](uint4 (&af)[4][NP], unsigned base, int u) {      // unit u: ky = u >> 2, c = u & 3
     const unsigned off = (unsigned)(((u >> 2) * YPW + (u & 3) * 8) * YROWB);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) af[a][p] = __builtin_bit_cast(uint4, *(y_lds_u4)(size_t)(base + off + (unsigned)(a * 4) * YROWB + (unsigned)p * YPLANE_B));
+      for (int p = 0; p < NP; ++p)
+        af[a][p] = __builtin_bit_cast(uint4, *(y_lds_u4)(size_t)(base + off + (unsigned)(((a >> 1) * 8 * YPW + (a & 1) * 4) * YROWB) + (unsigned)p * YPLANE_B));
   };
   // U fragments of unit u of 16-channel chunk k: prepared layout [p][k >> 1][tp = u][kc = k & 1][nt][lane][8]
   const size_t plane_main = (size_t)(C >> 5) * 24 * P.NT * 512;
   const unsigned ps2 = (unsigned)(plane_main * 2);
   const int lane16 = lane * 16;
   const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.wp), 0, 0x7fffffff, 0x00020000);
-  uint4 qb[4][2][NP];                              // [unit mod 4][ct][plane]
-  auto ldb = [&](uint4 (&bq)[2][NP], int k, int u, int nt0) {
+  // weight fragments: ring of YRB units, requested YRB - 1 units (1920 cycles of MFMAs) ahead -- the vector-memory path returns in order, and with
+  // a distance of three a fragment queued behind the raw-data loads of the same unit (HBM latency) arrived late three times per step
+  constexpr int YRB = 6;
+  uint4 qb[YRB][NP];                               // [unit mod YRB][plane]
+  auto ldb = [&](uint4 (&bq)[NP], int k, int u, int nt0) {
     const unsigned soff = (unsigned)((((((k >> 1) * 12 + u) << 1) + (k & 1)) * P.NT + nt0) * 1024);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int p = 0; p < NP; ++p) bq[ct][p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, lane16, (int)(soff + ct * 1024 + p * ps2), 0));
+    for (int p = 0; p < NP; ++p) bq[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, lane16, (int)(soff + p * ps2), 0));
   };
-  f32x16 acc[4][2][2];                             // [c][a2][ct]
-  auto mma = [&](const uint4 (&af)[2][NP], const uint4 (&bq)[2][NP], int c, bool zc) {
+  f32x16 acc[4][4];                                // [c][a]
+  auto mma = [&](const uint4 (&af)[4][NP], const uint4 (&bq)[NP], int c, bool zc) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define PDAE_YA(P_) __builtin_bit_cast(bf16x8, af[a][P_])
-#define PDAE_YB(P_) __builtin_bit_cast(bf16x8, bq[ct][P_])
+#define PDAE_YB(P_) __builtin_bit_cast(bf16x8, bq[P_])
 #define PDAE_YAH(P_) __builtin_bit_cast(f16x8, af[a][P_])
-#define PDAE_YBH(P_) __builtin_bit_cast(f16x8, bq[ct][P_])
-#define PDAE_Y_EACH(STMT) _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) { STMT; }
+#define PDAE_YBH(P_) __builtin_bit_cast(f16x8, bq[P_])
+#define PDAE_Y_EACH(STMT) _Pragma("unroll") for (int a = 0; a < 4; ++a) { STMT; }
     if constexpr (NS == 4) {
-      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(0), PDAE_YBH(1), zc ? zero : acc[c][a][ct], 0, 0, 0))
-      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(1), PDAE_YBH(0), acc[c][a][ct], 0, 0, 0))
-      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(0), PDAE_YBH(0), acc[c][a][ct], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(0), PDAE_YBH(1), zc ? zero : acc[c][a], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(1), PDAE_YBH(0), acc[c][a], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(0), PDAE_YBH(0), acc[c][a], 0, 0, 0))
     } else if constexpr (NS == 2) {
-      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(1), zc ? zero : acc[c][a][ct], 0, 0, 0))
-      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(1), PDAE_YB(0), acc[c][a][ct], 0, 0, 0))
-      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(0), acc[c][a][ct], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(1), zc ? zero : acc[c][a], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(1), PDAE_YB(0), acc[c][a], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(0), acc[c][a], 0, 0, 0))
     } else {
-      PDAE_Y_EACH(acc[c][a][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(0), zc ? zero : acc[c][a][ct], 0, 0, 0))
+      PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_YA(0), PDAE_YB(0), zc ? zero : acc[c][a], 0, 0, 0))
     }
 #undef PDAE_Y_EACH
 #undef PDAE_YA
@@ -247,7 +269,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
 
   // ---- the pipeline.  Steps of this workgroup in order: step = (tile, k), k = 16-channel chunk.  At the top of an iteration the LDS buffer `cur`
   // holds the CONVERTED step m (being multiplied), the registers hold the RAW data of step m + 1 (validity bits cv_vm, GroupNorm coefficients
-  // loaded), qb[0..2] hold the U fragments of units 0..2 of step m.  During the iteration: step m + 1 is converted into the other buffer, step
+  // loaded), qb[0 .. YRB - 2] hold the U fragments of the first YRB - 1 units of step m.  During the iteration: step m + 1 is converted into the other buffer, step
   // m + 2 (the load position l_*) is loaded into the freed registers, its coefficients at unit 11.
   int m_tile = blockIdx.x;
   if (m_tile >= ntiles) return;
@@ -262,14 +284,15 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   Y_DECODE(m_tile, m_img, m_y0, m_x0, m_n0)
   auto advance = [&](int tile, int k, int& tile2, int& k2) { const bool last = k + 1 >= nk; tile2 = last ? tile + G : tile; k2 = last ? 0 : k + 1; };
   int l_tile = m_tile, l_k = 0, l_img = m_img, l_y0 = m_y0, l_x0 = m_x0, l_n0 = m_n0;
-  // the load position moves one step ahead: new source, and at a tile boundary the pixel bookkeeping of the new tile (beyond the last step: nothing valid)
+  // the load position moves one step ahead: new source, and at a tile boundary the pixel bookkeeping of the new tile (beyond the last step: nothing
+  // valid).  (Branch-free under the MFMAs of unit 11 instead of at the top of the step it measured 3 % SLOWER: the unit's issue slots overflow.)
 #define PDAE_Y_LD_NEXT()                                                                                      \
   {                                                                                                           \
     int t2_, k2_;                                                                                             \
     advance(l_tile, l_k, t2_, k2_);                                                                           \
     if (t2_ != l_tile) {                                                                                      \
       const bool live_ = t2_ < ntiles;                                                                        \
-      if (live_) Y_DECODE(t2_, l_img, l_y0, l_x0, l_n0)                                                       \
+      Y_DECODE(live_ ? t2_ : 0, l_img, l_y0, l_x0, l_n0)                                                      \
       Y_LD_TILE(l_img, l_y0, l_x0, live_)                                                                     \
     }                                                                                                         \
     l_tile = t2_; l_k = k2_;                                                                                  \
@@ -279,7 +302,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   Y_LD_TILE(l_img, l_y0, l_x0, true)
   Y_LD_SRC(0)
   gload_item(0); gload_item(1); gload_quarter();
-  coef_load(l_img, 0);
+  coef_load(l_img, 0); coef_load_q(l_img, 0);
   cv_vm = ld_vm;
   cur = 1;                                         // the conversions write buffer cur ^ 1 = 0
   conv_A(0); conv_B(0); conv_C(0, 0); conv_C(0, 2);
@@ -290,15 +313,15 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   gload_item(0); gload_item(1); gload_quarter();
   coef_load(l_img, l_k);
   {
-    const int nt0 = (m_n0 >> 5) + wn * 2;
-    ldb(qb[0], 0, 0, nt0); ldb(qb[1], 0, 1, nt0); ldb(qb[2], 0, 2, nt0);
+    const int nt0 = (m_n0 >> 5) + wv;
+#pragma unroll
+    for (int u = 0; u < YRB - 1; ++u) ldb(qb[u], 0, u, nt0);
   }
   int n_k, n_n0;                                   // chunk / first output channel of step m + 1 (its U fragments are requested from unit 9 on)
   {
     int t2;
     advance(m_tile, 0, t2, n_k);
-    n_n0 = m_n0;
-    if (t2 != m_tile && t2 < ntiles) { int i_, y_, x_; Y_DECODE(t2, i_, y_, x_, n_n0) (void)i_; (void)y_; (void)x_; }
+    Y_DECODE_N0(t2 < ntiles ? t2 : m_tile, n_n0)
   }
   __syncthreads();
   lda(fa[0], a_lane, 0);
@@ -324,27 +347,22 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
 #else
 #define PDAE_Y_GL(...) __VA_ARGS__
 #endif
-#ifdef PDAE_Y_PROBE_NOSTAGE
-#define PDAE_Y_DO_STAGE(...)
-#else
-#define PDAE_Y_DO_STAGE(...) __VA_ARGS__
-#endif
   // One unit: patch fragments of the next unit, U fragments of the unit three ahead (into the ring slot the previous unit has freed), one piece
   // of staging work, the unit's 12 MFMAs.
 #define PDAE_Y_UNIT(U, FIRST, WORK)                                                                           \
   {                                                                                                           \
     PDAE_Y_DO_A(if ((U) < 11) lda(fa[((U) + 1) & 1], abase, (U) + 1); else lda(fa[0], abase_n, 0);)           \
-    PDAE_Y_DO_B(if ((U) + 3 < 12) ldb(qb[((U) + 3) & 3], m_k, (U) + 3, m_nt0);                                \
-                else ldb(qb[((U) + 3) & 3], n_k, (U) + 3 - 12, n_nt0);)                                       \
-    PDAE_Y_DO_STAGE(WORK)                                                                                     \
-    mma(fa[(U) & 1], qb[(U) & 3], (U) & 3, (FIRST) && (U) < 4);                                               \
+    PDAE_Y_DO_B(if ((U) + YRB - 1 < 12) ldb(qb[((U) + YRB - 1) % YRB], m_k, (U) + YRB - 1, m_nt0);            \
+                else ldb(qb[((U) + YRB - 1) % YRB], n_k, (U) + YRB - 1 - 12, n_nt0);)                         \
+    WORK                                                                                                      \
+    mma(fa[(U) & 1], qb[(U) % YRB], (U) & 3, (FIRST) && (U) < 4);                                             \
     PDAE_Y_PATTERN(5)                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
   }
 #define PDAE_Y_STEP(FIRST)                                                                                    \
   {                                                                                                           \
-    const int m_nt0 = (m_n0 >> 5) + wn * 2, n_nt0 = (n_n0 >> 5) + wn * 2;                                     \
-    cv_vm = ld_vm;                                  /* validity of the raw data in the registers (step m + 1) */ \
+    const int m_nt0 = (m_n0 >> 5) + wv, n_nt0 = (n_n0 >> 5) + wv;                                             \
+    cv_vm = ld_vm; c_img = l_img; c_k = l_k;        /* validity / coefficients' position of the raw data in the registers (step m + 1) */ \
     PDAE_Y_LD_NEXT()                                /* the loads of this iteration: step m + 2 */              \
     abase = a_lane + cur * BUF_B; abase_n = a_lane + (cur ^ 1u) * BUF_B;                                      \
     asm volatile("" : "+v"(abase), "+v"(abase_n));                                                            \
@@ -352,10 +370,10 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     PDAE_Y_UNIT(1, FIRST, PDAE_Y_CV(conv_B(0);))                                                              \
     PDAE_Y_UNIT(2, FIRST, PDAE_Y_CV(conv_C(0, 0);))                                                           \
     PDAE_Y_UNIT(3, FIRST, PDAE_Y_CV(conv_C(0, 2);))                                                           \
-    PDAE_Y_UNIT(4, FIRST, PDAE_Y_CV(conv_A(1);))                                                              \
+    PDAE_Y_UNIT(4, FIRST, PDAE_Y_CV(conv_A(1);) PDAE_Y_GL(gload_item(0);))      /* eight units ahead of its conversion */ \
     PDAE_Y_UNIT(5, FIRST, PDAE_Y_CV(conv_B(1);))                                                              \
-    PDAE_Y_UNIT(6, FIRST, PDAE_Y_CV(conv_C(1, 0);))                                                           \
-    PDAE_Y_UNIT(7, FIRST, PDAE_Y_CV(conv_C(1, 2);) PDAE_Y_GL(gload_item(0);))                                 \
+    PDAE_Y_UNIT(6, FIRST, PDAE_Y_CV(conv_C(1, 0);) coef_load_q(c_img, c_k);)                                  \
+    PDAE_Y_UNIT(7, FIRST, PDAE_Y_CV(conv_C(1, 2);))                                                           \
     PDAE_Y_UNIT(8, FIRST, PDAE_Y_CV(conv_quarter();) PDAE_Y_GL(gload_item(1);))                               \
     PDAE_Y_UNIT(9, FIRST, PDAE_Y_GL(gload_quarter();))                                                        \
     PDAE_Y_UNIT(10, FIRST, )                                                                                  \
@@ -370,8 +388,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     m_k += 1;                                                                                                 \
     int t3_;                                                                                                  \
     advance(m_tile, m_k, t3_, n_k);                                                                           \
-    n_n0 = m_n0;                                                                                              \
-    if (t3_ != m_tile && t3_ < ntiles) { int i_, y_, x_; Y_DECODE(t3_, i_, y_, x_, n_n0) (void)i_; (void)y_; (void)x_; } \
+    Y_DECODE_N0(t3_ < ntiles ? t3_ : m_tile, n_n0)                                                            \
   }
   // The first chunk of a tile (accumulators start from zero) is its own straight-line copy IN FRONT of the loop over the others: a join of two
   // 144-MFMA bodies inside one loop makes the register allocator route the accumulators through VGPRs (conv3x3r.hip)
@@ -383,9 +400,9 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     }
 #ifdef PDAE_Y_PROBE_NOEPI
     {
-      f32x16 sm = acc[0][0][0];
+      f32x16 sm = acc[0][0];
 #pragma unroll
-      for (int i = 1; i < 16; ++i) sm += acc[i >> 2][(i >> 1) & 1][i & 1];
+      for (int i = 1; i < 16; ++i) sm += acc[i >> 2][i & 3];
       float z = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) z += sm[r];
@@ -393,7 +410,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     }
 #else
     {
-      // ---- epilogue of the finished tile, straight-line (conv3x3r's drain, not deferred): block b = (channel tile ct, pair half a2) in three stages
+      // ---- epilogue of the finished tile, straight-line (conv3x3r's drain, not deferred): block b = m-tile a (row half b >> 1, pair half b & 1) in three stages
       //   L(b): residual / previous contents of both output columns (8 float4; a possibly EMPTY resource: zeros), two blocks ahead, because the
       //         vector-memory path returns in order and a load queued behind the previous block's stores waits for their acknowledgements;
       //   W(b): the four transform-domain accumulators are read once, both output columns (j = 0: M0 + M1 + M2, j = 1: M1 - M2 - M3) go into the
@@ -406,67 +423,66 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
       const unsigned tw = lds0 + 2u * BUF_B + (unsigned)wv * 2u * TWB;
       const int er = lane_e >> 3, ec = (lane_e & 7) * 4;
       const unsigned tw_w = tw + (unsigned)((4 * (lane_e >> 5) * EPW + (lane_e & 31)) * 4), tw_r = tw + (unsigned)((er * EPW + ec) * 4);
-      const int y0a = m_y0 + wm * 8, n0w = m_n0 + wn * 64;
+      const int n0w = m_n0 + wv * 32;
       const int rsh = P.res_mode == 2 ? 1 : 0;             // half-resolution residual (nearest upsample): rows / columns >> 1, both columns of a pair read one pixel
       const unsigned lane_y = (unsigned)((((er >> 2) * P.W + 2 * (er & 3)) * P.Nout + ec) * 4);
       const unsigned lane_x = rsh ? (unsigned)(((er & 3) * P.Nout + ec) * 4) : lane_y;
       const unsigned lane_st = lane_e < 8 ? (unsigned)(lane_e * 8) : YOOB;
-      const unsigned y_it = (unsigned)(2 * P.W * P.Nout * 4), y_j = (unsigned)(P.Nout * 4), y_a2 = (unsigned)(8 * P.Nout * 4);
+      // byte steps of the output: `it` = 2 rows, j = one pixel, a & 1 = 8 pixels, a >> 1 = 8 rows; of the residual likewise (half resolution: halved)
+      const unsigned y_it = (unsigned)(2 * P.W * P.Nout * 4), y_j = (unsigned)(P.Nout * 4), y_a2 = (unsigned)(8 * P.Nout * 4), y_ar = (unsigned)(8 * P.W * P.Nout * 4);
       const unsigned x_it = rsh ? (unsigned)((P.W >> 1) * P.Nout * 4) : y_it, x_j = rsh ? 0u : y_j, x_a2 = rsh ? (unsigned)(4 * P.Nout * 4) : y_a2;
-      const unsigned d_rb4 = (unsigned)((((m_img * P.H + y0a) * P.W + m_x0) * P.Nout + n0w) * 4);
-      const unsigned d_xb4 = rsh ? (unsigned)((((m_img * (P.H >> 1) + (y0a >> 1)) * (P.W >> 1) + (m_x0 >> 1)) * P.Nout + n0w) * 4) : d_rb4;
-      const unsigned d_sb8 = (unsigned)(((m_img * P.stat_tpi + ((m_y0 >> 4) * P.tiles_x + (m_x0 >> 4)) * 2 + wm) * (P.Nout >> 2) + (n0w >> 2)) * 8);
+      const unsigned x_ar = rsh ? (unsigned)(4 * (P.W >> 1) * P.Nout * 4) : y_ar;
+      const unsigned d_rb4 = (unsigned)((((m_img * P.H + m_y0) * P.W + m_x0) * P.Nout + n0w) * 4);
+      const unsigned d_xb4 = rsh ? (unsigned)((((m_img * (P.H >> 1) + (m_y0 >> 1)) * (P.W >> 1) + (m_x0 >> 1)) * P.Nout + n0w) * 4) : d_rb4;
+      const unsigned d_sb8 = (unsigned)(((m_img * P.stat_tpi + ((m_y0 >> 4) * P.tiles_x + (m_x0 >> 4)) * 2) * (P.Nout >> 2) + (n0w >> 2)) * 8);      // + (a >> 1): the row half's entry
+      const unsigned s_ar = (unsigned)((P.Nout >> 2) * 8);
       const float* const extra_ = P.res_mode ? P.res : P.y;      // residual OR (accumulate) the previous contents of y (both: conv3x3y_launch falls back)
       const unsigned extra_on = (P.res_mode || P.accumulate) ? YALL : 0u, stat_on = P.stat_part ? YALL : 0u, bias_on = P.bias ? YALL : 0u;
 #define Y_RSB(PTR, BYTES) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((const void*)(PTR)), 0, (int)(BYTES), 0x00020000)
-      float4 rv[2][2][4], bias4[2];
+      float4 rv[2][2][4];
       float st1 = 0.f, st2 = 0.f;
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) bias4[ct] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.bias, bias_on), ec * 4, (int)((n0w + ct * 32) * 4), 0));
-      auto epi_L = [&](int b) {
-        const int ct = b >> 1, a2 = b & 1;
+      const float4 bias4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.bias, bias_on), ec * 4, (int)(n0w * 4), 0));
+      auto epi_L = [&](int b) {                       // block b = m-tile a
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int it = 0; it < 4; ++it)
             rv[b & 1][j][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(extra_, extra_on), (int)lane_x,
-                                                                                                 (int)(d_xb4 + it * x_it + j * x_j + a2 * x_a2 + ct * 128), 0));
+                                                                                                 (int)(d_xb4 + it * x_it + j * x_j + (b & 1) * x_a2 + (b >> 1) * x_ar), 0));
       };
       auto epi_W = [&](int b) {
-        const int ct = b >> 1, a2 = b & 1;
         // the accumulators are read HERE: without the opaque redefinition the sixteen-float extractions of all four blocks were hoisted to the top
         // of the epilogue (192 v_accvgpr_read up front, 42 spilled registers)
-        asm volatile("" : "+a"(acc[0][a2][ct]), "+a"(acc[1][a2][ct]), "+a"(acc[2][a2][ct]), "+a"(acc[3][a2][ct]));
+        asm volatile("" : "+a"(acc[0][b]), "+a"(acc[1][b]), "+a"(acc[2][b]), "+a"(acc[3][b]));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float m0 = acc[0][a2][ct][r], m1 = acc[1][a2][ct][r], m2 = acc[2][a2][ct][r], m3 = acc[3][a2][ct][r];
+          const float m0 = acc[0][b][r], m1 = acc[1][b][r], m2 = acc[2][b][r], m3 = acc[3][b][r];
           const unsigned o = tw_w + (unsigned)((((r & 3) + 8 * (r >> 2)) * EPW) * 4);
           *(y_lds_f)(size_t)(o) = (m0 + m1) + m2;
           *(y_lds_f)(size_t)(o + TWB) = (m1 - m2) - m3;
         }
       };
       auto epi_S = [&](int b) {
-        const int ct = b >> 1, a2 = b & 1;
-        if (a2 == 0) { st1 = 0.f; st2 = 0.f; }
+        if ((b & 1) == 0) { st1 = 0.f; st2 = 0.f; }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const y_f32x4 v4 = *(y_lds_f4)(size_t)(tw_r + (unsigned)j * TWB + (unsigned)(it * 8 * EPW * 4));
             float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
-            const float4 u = rv[b & 1][j][it], bb = bias4[ct];
+            const float4 u = rv[b & 1][j][it], bb = bias4;
             v.x = fmaf(v.x, oscale, bb.x + u.x); v.y = fmaf(v.y, oscale, bb.y + u.y); v.z = fmaf(v.z, oscale, bb.z + u.z); v.w = fmaf(v.w, oscale, bb.w + u.w);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(y_u32x4, v), Y_RSB(P.y, YALL), (int)lane_y, (int)(d_rb4 + it * y_it + j * y_j + a2 * y_a2 + ct * 128), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(y_u32x4, v), Y_RSB(P.y, YALL), (int)lane_y, (int)(d_rb4 + it * y_it + j * y_j + (b & 1) * y_a2 + (b >> 1) * y_ar), 0);
             st1 += (v.x + v.y) + (v.z + v.w);
             st2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, st2))));
           }
-        if (a2 == 1) {      // (sum, sum of squares) of the wave's 8 x 16 pixels per channel quad: the eight lanes holding a quad combine, lanes 0..7 write
+        if ((b & 1) == 1) {      // (sum, sum of squares) of a row half's 8 x 16 pixels per channel quad: the eight lanes holding a quad combine, lanes 0..7 write
           float s1 = st1, s2 = st2;
           s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8);
           s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
           const y_u32x2 sv2 = {__float_as_uint(s1), __float_as_uint(s2)};
-          __builtin_amdgcn_raw_buffer_store_b64(sv2, Y_RSB(P.stat_part, stat_on), (int)lane_st, (int)(d_sb8 + ct * 64), 0);
+          __builtin_amdgcn_raw_buffer_store_b64(sv2, Y_RSB(P.stat_part, stat_on), (int)lane_st, (int)(d_sb8 + (b >> 1) * s_ar), 0);
         }
       };
 #define Y_EPI_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -487,8 +503,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     {
       int t3;
       advance(m_tile, 0, t3, n_k);
-      n_n0 = m_n0;
-      if (t3 != m_tile && t3 < ntiles) { int i_, y_, x_; Y_DECODE(t3, i_, y_, x_, n_n0) (void)i_; (void)y_; (void)x_; }
+      Y_DECODE_N0(t3 < ntiles ? t3 : m_tile, n_n0)
     }
   }
   if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
@@ -506,7 +521,10 @@ template <int NS, bool GN> static int launch_y(const PatchParams& P, hipStream_t
   dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
   static int stagger = -1;
   if (stagger < 0) { const char* e = getenv("PDAE_Y_STAGGER"); stagger = e ? atoi(e) : 0; }
-  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0);
+  auto magic = [](int d) { return (unsigned)((0x100000000ull / (unsigned long long)d) + 1ull); };      // unused for d == 1
+  const YDiv D{magic(P.tiles_n), magic(P.tiles_x), magic(P.tiles_y)};
+  if (ntiles >= (1ll << 20) || P.tiles_n >= 4096 || P.tiles_x >= 4096 || P.tiles_y >= 4096) { pdae_set_error("conv3x3y: %lld tiles", ntiles); return 1; }
+  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
   return pdae_launch_status("conv3x3y");
 }
 

@@ -19,11 +19,11 @@ VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"])
             "wn_nostore": (WN, ["-DPDAE_WN_PROBE_NOSTORE"]), "wn_loads": (WN, ["-DPDAE_WN_PROBE_NORAW", "-DPDAE_WN_PROBE_NOB"]),
             "x_noa": (X3, ["-DPDAE_X_PROBE_NOA"]), "x_nob": (X3, ["-DPDAE_X_PROBE_NOB"]), "x_nostage": (X3, ["-DPDAE_X_PROBE_NOSTAGE"]),
             "x_mfma": (X3, ["-DPDAE_X_PROBE_NOA", "-DPDAE_X_PROBE_NOB", "-DPDAE_X_PROBE_NOSTAGE"]),
-            "y_noa": (Y3, ["-DPDAE_Y_PROBE_NOA"]), "y_nob": (Y3, ["-DPDAE_Y_PROBE_NOB"]), "y_nostage": (Y3, ["-DPDAE_Y_PROBE_NOSTAGE"]),
+            "y_noa": (Y3, ["-DPDAE_Y_PROBE_NOA"]), "y_nob": (Y3, ["-DPDAE_Y_PROBE_NOB"]), "y_nostage": (Y3, ["-DPDAE_Y_PROBE_NOCONV", "-DPDAE_Y_PROBE_NOGLOAD"]),
             "y_nogload": (Y3, ["-DPDAE_Y_PROBE_NOGLOAD"]), "y_noconv": (Y3, ["-DPDAE_Y_PROBE_NOCONV"]),
             "y_nobgl": (Y3, ["-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOGLOAD"]), "y_noabgl": (Y3, ["-DPDAE_Y_PROBE_NOA", "-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOGLOAD"]),
             "y_noepi": (Y3, ["-DPDAE_Y_PROBE_NOEPI"]),
-            "y_mfma": (Y3, ["-DPDAE_Y_PROBE_NOA", "-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOSTAGE", "-DPDAE_Y_PROBE_NOEPI"]),
+            "y_mfma": (Y3, ["-DPDAE_Y_PROBE_NOA", "-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOCONV", "-DPDAE_Y_PROBE_NOGLOAD", "-DPDAE_Y_PROBE_NOEPI"]),
             "r_24u": (R3, ["-DPDAE_R_PROBE_24U"]),
             "r_mfma": (R3, ["-DPDAE_R_PROBE_NOA", "-DPDAE_R_PROBE_NOB", "-DPDAE_R_PROBE_NOGLOAD", "-DPDAE_R_PROBE_NOCONV", "-DPDAE_R_PROBE_NODRAIN"])}
 only = sys.argv[1:]
