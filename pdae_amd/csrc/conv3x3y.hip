@@ -217,7 +217,9 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   // ---- fragments
   const unsigned a_lane = lds0 + (unsigned)(((li >> 2) * YPW + (li & 3)) * YROWB + h * 16);
   unsigned abase = a_lane;
-  uint4 fa[2][4][NP];                              // [ring][m-tile a][plane]
+  // patch fragments: ring of YRA units (requested YRA - 1 units ahead); the fused-GroupNorm instantiation has no registers for a third slot
+  constexpr int YRA = GN ? 2 : 3;
+  uint4 fa[YRA][4][NP];                            // [unit mod YRA][m-tile a][plane]
   unsigned abase_n = a_lane;                       // the other buffer: unit 0 of the NEXT step is fetched during unit 11, behind the step's barrier
   auto lda = [&](uint4 (&af)[4][NP], unsigned base, int u) {      // unit u: ky = u >> 2, c = u & 3
     const unsigned off = (unsigned)(((u >> 2) * YPW + (u & 3) * 8) * YROWB);
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   const __amdgpu_buffer_rsrc_t srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(P.wp), 0, 0x7fffffff, 0x00020000);
   // weight fragments: ring of YRB units, requested YRB - 1 units (1920 cycles of MFMAs) ahead -- the vector-memory path returns in order, and with
   // a distance of three a fragment queued behind the raw-data loads of the same unit (HBM latency) arrived late three times per step
-  constexpr int YRB = 6;
+  constexpr int YRB = GN ? 6 : 4;
   uint4 qb[YRB][NP];                               // [unit mod YRB][plane]
   auto ldb = [&](uint4 (&bq)[NP], int k, int u, int nt0) {
     const unsigned soff = (unsigned)((((((k >> 1) * 12 + u) << 1) + (k & 1)) * P.NT + nt0) * 1024);
@@ -324,7 +326,8 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     Y_DECODE_N0(t2 < ntiles ? t2 : m_tile, n_n0)
   }
   __syncthreads();
-  lda(fa[0], a_lane, 0);
+#pragma unroll
+  for (int u = 0; u < YRA - 1; ++u) lda(fa[u], a_lane, u);
 
   // timing probes (tools/probe_build.py; WRONG RESULTS by design)
 #ifdef PDAE_Y_PROBE_NOA
@@ -351,11 +354,12 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   // of staging work, the unit's 12 MFMAs.
 #define PDAE_Y_UNIT(U, FIRST, WORK)                                                                           \
   {                                                                                                           \
-    PDAE_Y_DO_A(if ((U) < 11) lda(fa[((U) + 1) & 1], abase, (U) + 1); else lda(fa[0], abase_n, 0);)           \
+    PDAE_Y_DO_A(if ((U) + YRA - 1 < 12) lda(fa[((U) + YRA - 1) % YRA], abase, (U) + YRA - 1);                 \
+                else lda(fa[((U) + YRA - 1) % YRA], abase_n, (U) + YRA - 1 - 12);)                            \
     PDAE_Y_DO_B(if ((U) + YRB - 1 < 12) ldb(qb[((U) + YRB - 1) % YRB], m_k, (U) + YRB - 1, m_nt0);            \
                 else ldb(qb[((U) + YRB - 1) % YRB], n_k, (U) + YRB - 1 - 12, n_nt0);)                         \
     WORK                                                                                                      \
-    mma(fa[(U) & 1], qb[(U) % YRB], (U) & 3, (FIRST) && (U) < 4);                                             \
+    mma(fa[(U) % YRA], qb[(U) % YRB], (U) & 3, (FIRST) && (U) < 4);                                           \
     PDAE_Y_PATTERN(5)                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
   }
@@ -376,8 +380,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     PDAE_Y_UNIT(7, FIRST, PDAE_Y_CV(conv_C(1, 2);))                                                           \
     PDAE_Y_UNIT(8, FIRST, PDAE_Y_CV(conv_quarter();) PDAE_Y_GL(gload_item(1);))                               \
     PDAE_Y_UNIT(9, FIRST, PDAE_Y_GL(gload_quarter();))                                                        \
+    /* the step's barrier: every conversion into the other buffer is done (unit 8), every read of this one is issued (unit 12 - YRA); */ \
+    /* behind it the first fragments of the NEXT step are fetched from the other buffer */                     \
+    if (YRA == 3) __syncthreads();                                                                            \
     PDAE_Y_UNIT(10, FIRST, )                                                                                  \
-    __syncthreads();       /* every conversion into the other buffer is done (unit 8), every read of this one is issued (unit 10) */ \
+    if (YRA == 2) __syncthreads();                                                                            \
     PDAE_Y_UNIT(11, FIRST, coef_load(l_img, l_k);)                                                            \
     cur ^= 1u;                                                                                                \
   }
