@@ -47,6 +47,10 @@ typedef struct pdae_conv_desc {
                            *     +-60000 are clamped and COUNTED (pdae_set_saturation_counter).  The generic implicit-GEMM kernels and gradient
                            *     launches without dy_amax run mode 3.  fp32 accumulate in all modes. */
 } pdae_conv_desc;
+/* OR-ed into pdae_conv_desc.math by the caller: the FORWARD form of this 3x3 convolution (prepared weights and launch) stays on the direct kernels
+ * whatever the shape heuristics say (pdae_conv3x3_form -> 0), which keeps it eligible for fused 1x1 skip chunks (pdae_conv2d_fwd_skip).  The data- and
+ * weight-gradient entry points ignore the bit.  Use the SAME descriptor for pdae_conv_wprep and the launch. */
+#define PDAE_MATH_DIRECT 0x100
 
 /* fp16-window guard of math 4: counter = device word (zero it yourself) that every math-4 convolution launch increments when it had to clamp
  * a scaled operand (|x| > 60000, NaN, Inf) into the fp16 window; NULL disarms the guard.  A non-zero counter means "results of this pass are

@@ -21,7 +21,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 7; }
+extern "C" int pdae_abi_version(void) { return 8; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -41,6 +41,13 @@ static int check_desc(const pdae_conv_desc* d) {
   PDAE_CHECK_ARG((long long)d->N * Hl * Wl < (1ll << 31) && (long long)d->N * d->Ho * d->Wo < (1ll << 31), "conv: too many pixels");
   return PDAE_OK;
 }
+
+// pdae_conv_desc.math may carry PDAE_MATH_DIRECT: every entry point works on a copy without it (d is re-pointed) and keeps the bit in d_dflag;
+// only the FORWARD weight preparation / launch of a 3x3 convolution look at it (conv3x3p_form).
+static int skip_ok_impl(const pdae_conv_desc* d, const pdae_conv_desc* ds, int dflag);
+#define PDAE_DESC_NORM(d)                                                                                                  \
+  pdae_conv_desc d##_norm; int d##_dflag = 0;                                                                              \
+  if (d) { d##_norm = *d; d##_dflag = d##_norm.math & PDAE_MATH_DIRECT; d##_norm.math &= ~PDAE_MATH_DIRECT; d = &d##_norm; }
 
 static void fwd_geom(ConvGeom& g, const pdae_conv_desc* d, const float* x0, const float* x1) {
   g.src0 = x0; g.src1 = x1; g.C0 = d->C0; g.C1 = d->C1; g.Cin = d->C0 + d->C1;
@@ -73,6 +80,7 @@ static bool gn_patch_ok(const pdae_conv_desc* d, bool fill) {
 }
 
 extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
+  PDAE_DESC_NORM(d)
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
   if (!d || check_desc(d)) return 0;
   if (flags & PDAE_WPREP_GN)
@@ -89,27 +97,29 @@ extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
 }
 
 extern "C" int pdae_conv3x3_form(const pdae_conv_desc* d, int flags) {
+  PDAE_DESC_NORM(d)
   if (pdae_conv_wprep_bytes(d, flags) == 0 || d->KH != 3) return 0;
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
   if (transposed) return conv3x3p_form(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), d->Cout, Hl, Wl, d->N, Cin);
-  return conv3x3p_form(d->math, Cin, d->Ho, d->Wo, d->N, d->Cout);
+  return conv3x3p_form(d->math | d_dflag, Cin, d->Ho, d->Wo, d->N, d->Cout);
 }
 
 extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_stream_t stream) {
+  PDAE_DESC_NORM(d)
   if (int e = check_desc(d)) return e;
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
   PDAE_CHECK_ARG(w && wp, "conv_wprep: null pointer");
   if (flags & PDAE_WPREP_GN) {
     PDAE_CHECK_ARG(!transposed && gn_patch_ok(d, false), "conv_wprep: convolution not eligible for the fused-GroupNorm patch kernel");
-    return conv3x3p_wprep(d->math, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, S(stream), d->Ho, d->Wo, d->N);
+    return conv3x3p_wprep(d->math | d_dflag, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, S(stream), d->Ho, d->Wo, d->N);
   }
   const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi;       // the data gradient's output grid
   PDAE_CHECK_ARG(kind != 0, "conv_wprep: convolution shape not eligible for a prepared-weight kernel");
   if (kind == 3) {
     if (transposed) return conv3x3p_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream), Hl, Wl, d->N);
-    return conv3x3p_wprep(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream), d->Ho, d->Wo, d->N);
+    return conv3x3p_wprep(d->math | d_dflag, w, d->Cout, d->C0, 0, (unsigned short*)wp, S(stream), d->Ho, d->Wo, d->N);
   }
   if (transposed) return conv1x1_wprep(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, S(stream));
   return conv1x1_wprep(d->math, w, d->Cout, Cin, 0, (unsigned short*)wp, S(stream));
@@ -118,14 +128,16 @@ extern "C" int pdae_conv_wprep(const pdae_conv_desc* d, const float* w, int flag
 // ---- grouped weight preparation (wprep.hip): the host fills one job per prepared copy with the SAME decisions pdae_conv_wprep /
 // pdae_conv_skip_wprep take, uploads the table once, and every run of the plan prepares all of them in one launch
 static_assert(sizeof(pdae_wprep_job) == sizeof(WprepJob), "pdae_wprep_job must mirror WprepJob");
+static_assert(PDAE_MATH_DIRECT == PDAE_MATH_DIRECT_BIT, "the direct-form bit of pdae_conv_desc.math");
 extern "C" int pdae_conv_wprep_job(const pdae_conv_desc* d, const float* w, int flags, void* wp, pdae_wprep_job* job) {
+  PDAE_DESC_NORM(d)
   if (int e = check_desc(d)) return e;
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
   PDAE_CHECK_ARG(w && wp && job, "conv_wprep_job: null pointer");
   WprepJob* j = reinterpret_cast<WprepJob*>(job);
   if (flags & PDAE_WPREP_GN) {
     PDAE_CHECK_ARG(!transposed && gn_patch_ok(d, false), "conv_wprep_job: convolution not eligible for the fused-GroupNorm patch kernel");
-    conv3x3p_wprep_job(d->math, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, j, d->Ho, d->Wo, d->N);
+    conv3x3p_wprep_job(d->math | d_dflag, w, d->Cout, d->C0 + d->C1, 0, (unsigned short*)wp, j, d->Ho, d->Wo, d->N);
     return PDAE_OK;
   }
   const int kind = fast_kind(d, transposed, false), Cin = d->C0 + d->C1;
@@ -133,13 +145,15 @@ extern "C" int pdae_conv_wprep_job(const pdae_conv_desc* d, const float* w, int 
   PDAE_CHECK_ARG(kind != 0, "conv_wprep_job: convolution shape not eligible for a prepared-weight kernel");
   if (kind == 3) {
     if (transposed) conv3x3p_wprep_job(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, j, Hl, Wl, d->N);
-    else conv3x3p_wprep_job(d->math, w, d->Cout, d->C0, 0, (unsigned short*)wp, j, d->Ho, d->Wo, d->N);
+    else conv3x3p_wprep_job(d->math | d_dflag, w, d->Cout, d->C0, 0, (unsigned short*)wp, j, d->Ho, d->Wo, d->N);
   } else if (transposed) conv1x1_wprep_job(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), w, Cin, d->Cout, 1, (unsigned short*)wp, j);
   else conv1x1_wprep_job(d->math, w, d->Cout, Cin, 0, (unsigned short*)wp, j);
   return PDAE_OK;
 }
 extern "C" int pdae_conv_skip_wprep_job(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_wprep_job* job) {
-  PDAE_CHECK_ARG(w_skip && wps && job && pdae_conv2d_fwd_skip_ok(d, ds), "conv_skip_wprep_job: not an eligible (conv3x3, skip 1x1) pair");
+  PDAE_DESC_NORM(d)
+  PDAE_DESC_NORM(ds)
+  PDAE_CHECK_ARG(w_skip && wps && job && skip_ok_impl(d, ds, d_dflag), "conv_skip_wprep_job: not an eligible (conv3x3, skip 1x1) pair");
   conv3x3p_skip_wprep_job(d->math, w_skip, ds->Cout, ds->C0 + ds->C1, d->C0 + d->C1, (unsigned short*)wps, reinterpret_cast<WprepJob*>(job), d->Ho, d->Wo, d->N);
   return PDAE_OK;
 }
@@ -153,6 +167,7 @@ static bool edge_on() { const char* e = getenv("PDAE_EDGE"); return !e || atoi(e
 
 extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
                                const float* res, int res_mode, float* y, int tile, pdae_stream_t stream) {
+  PDAE_DESC_NORM(d)
   float* const stat = conv3x3p_take_stats();            // consumed here whatever happens below: a failed call never leaves the request armed
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && w && y && (d->C1 == 0 || x1), "conv2d_fwd: null pointer");
@@ -167,7 +182,7 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
   const int kind = wp ? fast_kind(d, 0, false) : 0;
   PDAE_CHECK_ARG(!wp || (tile == 0 && kind != 0), "conv2d_fwd: wp given but the convolution is not eligible for a prepared-weight kernel");
   if (kind == 3)
-    return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
+    return conv3x3p_launch(d->math | d_dflag, x0, d->N, d->Hi, d->Wi, d->C0, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
                            res_mode ? res : nullptr, res_mode, 0, S(stream), nullptr, 0, nullptr, 0, nullptr, nullptr, stat);
   if (stat) {
     pdae_set_error("conv2d_fwd: output statistics were requested (pdae_conv_stats_arm) but this convolution does not run on the 3x3 patch kernel");
@@ -189,13 +204,14 @@ extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const f
 
 extern "C" int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp,
                                   const float* bias, const float* res, int res_mode, float* y, pdae_stream_t stream) {
+  PDAE_DESC_NORM(d)
   float* const stat = conv3x3p_take_stats();
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && coef && wp && y && (d->C1 == 0 || x1), "conv2d_fwd_gn: null pointer");
   PDAE_CHECK_ARG(res_mode == 0 || res, "conv2d_fwd_gn: res_mode without res");
   PDAE_CHECK_ARG(res_mode != 2 || ((d->Ho % 2) == 0 && (d->Wo % 2) == 0), "conv2d_fwd_gn: res_mode 2 needs even output");
   PDAE_CHECK_ARG(gn_patch_ok(d, false), "conv2d_fwd_gn: convolution not eligible (pdae_conv_wprep_bytes(d, PDAE_WPREP_GN) == 0)");
-  return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
+  return conv3x3p_launch(d->math | d_dflag, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias,
                          res_mode ? res : nullptr, res_mode, 0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act, nullptr, nullptr, stat);
 }
 
@@ -204,43 +220,57 @@ static bool skip_desc_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds) {
          ds->Ho == d->Ho && ds->Wo == d->Wo && ds->Cout == d->Cout && ds->math == d->math;
 }
 
-extern "C" int pdae_conv2d_fwd_skip_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds) {
+static int skip_ok_impl(const pdae_conv_desc* d, const pdae_conv_desc* ds, int dflag) {      // normalised descriptors + the main convolution's PDAE_MATH_DIRECT bit
   if (!d || !ds || check_desc(d) || check_desc(ds) || !skip_desc_ok(d, ds)) return 0;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || (d->C0 & 31) || (d->C1 & 31)) return 0;
-  return conv3x3p_skip_ok(d->math, d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, d->up, ds->C0, ds->C1) ? 1 : 0;
+  return conv3x3p_skip_ok(d->math | dflag, d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, d->up, ds->C0, ds->C1) ? 1 : 0;
+}
+extern "C" int pdae_conv2d_fwd_skip_ok(const pdae_conv_desc* d, const pdae_conv_desc* ds) {
+  PDAE_DESC_NORM(d)
+  PDAE_DESC_NORM(ds)
+  (void)ds_dflag;
+  return skip_ok_impl(d, ds, d_dflag);
 }
 
 extern "C" size_t pdae_conv_skip_wprep_bytes(const pdae_conv_desc* d, const pdae_conv_desc* ds) {
-  if (!pdae_conv2d_fwd_skip_ok(d, ds)) return 0;
+  PDAE_DESC_NORM(d)
+  PDAE_DESC_NORM(ds)
+  if (!skip_ok_impl(d, ds, d_dflag)) return 0;
   return conv3x3p_skip_wprep_bytes(d->math, ds->Cout, ds->C0 + ds->C1);
 }
 
 extern "C" int pdae_conv_skip_wprep(const pdae_conv_desc* d, const pdae_conv_desc* ds, const float* w_skip, void* wps, pdae_stream_t stream) {
-  PDAE_CHECK_ARG(w_skip && wps && pdae_conv2d_fwd_skip_ok(d, ds), "conv_skip_wprep: not an eligible (conv3x3, skip 1x1) pair");
+  PDAE_DESC_NORM(d)
+  PDAE_DESC_NORM(ds)
+  PDAE_CHECK_ARG(w_skip && wps && skip_ok_impl(d, ds, d_dflag), "conv_skip_wprep: not an eligible (conv3x3, skip 1x1) pair");
   return conv3x3p_skip_wprep(d->math, w_skip, ds->Cout, ds->C0 + ds->C1, d->C0 + d->C1, (unsigned short*)wps, S(stream), d->Ho, d->Wo, d->N);
 }
 
 extern "C" int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp,
                                     const float* bias, const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps,
                                     const float* bias_s, float* y, pdae_stream_t stream) {
+  PDAE_DESC_NORM(d)
+  PDAE_DESC_NORM(ds)
   float* const stat = conv3x3p_take_stats();
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(ds && !check_desc(ds) && skip_desc_ok(d, ds), "conv2d_fwd_skip: the 1x1 descriptor must map the conv's output grid (same N, H, W, Cout, math)");
   PDAE_CHECK_ARG(x0 && wp && y && s0 && wps && (ds->C1 == 0 || s1), "conv2d_fwd_skip: null pointer");
   PDAE_CHECK_ARG(coef || d->C1 == 0, "conv2d_fwd_skip: a two-source main input needs the fused GroupNorm form (coef)");
   PDAE_CHECK_ARG(d->C1 == 0 || x1, "conv2d_fwd_skip: null second source");
-  PDAE_CHECK_ARG(pdae_conv2d_fwd_skip_ok(d, ds), "conv2d_fwd_skip: shape not eligible (pdae_conv2d_fwd_skip_ok == 0)");
+  PDAE_CHECK_ARG(skip_ok_impl(d, ds, d_dflag), "conv2d_fwd_skip: shape not eligible (pdae_conv2d_fwd_skip_ok == 0)");
   PatchSkip sk{s0, ds->C1 ? s1 : nullptr, ds->C0, ds->C1, (const unsigned short*)wps, bias_s};
-  return conv3x3p_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias, nullptr, 0,
+  return conv3x3p_launch(d->math | d_dflag, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, (const unsigned short*)wp, d->Cout, y, bias, nullptr, 0,
                          0, S(stream), d->C1 ? x1 : nullptr, d->C0, coef, act, &sk, nullptr, stat);
 }
 
 // ---- GroupNorm statistics of a convolution's output, produced by the convolution itself
 extern "C" size_t pdae_conv_stats_bytes(const pdae_conv_desc* d, const pdae_conv_desc* ds, int32_t* tiles_per_image) {
+  PDAE_DESC_NORM(d)
+  PDAE_DESC_NORM(ds)
   if (tiles_per_image) *tiles_per_image = 0;
   if (!d || check_desc(d)) return 0;
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || ((d->C0 + d->C1) & 31) || (d->Cout & 3)) return 0;
-  if (ds ? !pdae_conv2d_fwd_skip_ok(d, ds) : (fast_kind(d, 0, false) != 3 && !gn_patch_ok(d, false))) return 0;
+  if (ds ? !skip_ok_impl(d, ds, d_dflag) : (fast_kind(d, 0, false) != 3 && !gn_patch_ok(d, false))) return 0;
   int tpi = 0;
   const size_t b = conv3x3p_stats_bytes(d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, ds ? (ds->C0 + ds->C1) >> 5 : 0, &tpi);
   if (tiles_per_image) *tiles_per_image = b ? tpi : 0;
@@ -251,16 +281,19 @@ static bool wino_desc_ok(const pdae_conv_desc* d) {
   return wino_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->up, d->C0, d->C1, d->Ho, d->Wo, d->N, d->Cout);
 }
 extern "C" size_t pdae_wino_wprep_bytes(const pdae_conv_desc* d) {
+  PDAE_DESC_NORM(d)
   if (!d || check_desc(d) || !wino_desc_ok(d)) return 0;
   return wino_wprep_bytes(d->Cout, d->C0);
 }
 extern "C" int pdae_wino_wprep(const pdae_conv_desc* d, const float* w, void* wp, pdae_stream_t stream) {
+  PDAE_DESC_NORM(d)
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(w && wp, "wino_wprep: null pointer");
   PDAE_CHECK_ARG(wino_desc_ok(d), "wino_wprep: convolution not eligible (3x3 / stride 1 / pad 1, math f16x3, one source, C %% 16 == 0, H, W %% 16 == 0, Cout %% 64 == 0)");
   return wino_wprep(w, d->Cout, d->C0, (unsigned short*)wp, S(stream));
 }
 extern "C" int pdae_wino_fwd(const pdae_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, pdae_stream_t stream) {
+  PDAE_DESC_NORM(d)
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x && wp && y, "wino_fwd: null pointer");
   PDAE_CHECK_ARG(wino_desc_ok(d), "wino_fwd: convolution not eligible (pdae_wino_wprep_bytes returned 0)");
@@ -282,6 +315,7 @@ extern "C" int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G
 
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
                                  int accumulate, int tile, const float* dy_amax, pdae_stream_t stream) {
+  PDAE_DESC_NORM(d)
   conv3x3p_take_stats();                  // output statistics belong to forward convolutions only
   if (int e = check_desc(d)) return e;
   const int Cin = d->C0 + d->C1;
@@ -347,11 +381,13 @@ static size_t wgrad_path_bytes(const pdae_conv_desc* d) {
 }
 
 extern "C" size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d) {
+  PDAE_DESC_NORM(d)
   return wgrad_path_bytes(d) + k_colsum_workspace_floats((long long)d->N * d->Ho * d->Wo, d->Cout) * sizeof(float);
 }
 
 extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, float* db, int accumulate,
                                  void* ws, size_t ws_bytes, const float* dy_amax, pdae_stream_t stream) {
+  PDAE_DESC_NORM(d)
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "conv2d_wgrad: null pointer");
   const size_t pb = wgrad_path_bytes(d);

@@ -180,6 +180,7 @@ template <int NS> __device__ __forceinline__ void wprepx_slot(const float* __res
   }
   wprep_store_slot<NS>(e, wscale, wp, plane_stride, i);
 }
+#define PDAE_MATH_DIRECT_BIT 0x100   // = PDAE_MATH_DIRECT of the C ABI, carried in the `math` argument of conv3x3p_form / _launch / _wprep(_job) / _skip_ok
 #define PDAE_WPREP_FORM_X 8        // WprepJob.transposed bit: Winograd-along-x layout (wprepx_slot)
 
 // one job of the grouped launch (= include/pdae_hip.h: pdae_wprep_job) and how the existing entry points describe theirs

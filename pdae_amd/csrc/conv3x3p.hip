@@ -501,8 +501,9 @@ static PatchPlan patch_plan(int C, int H, int W, int N, int Nout) {
 // fused 1x1 skip convolution: the main conv must be eligible without the image-pair geometry / upsample and the combined K loop must not
 // need split-K (its slabs are sized for the main convolution alone)
 bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, int Cs0, int Cs1) {
+  if (conv3x3p_form(math, C, H, W, N, Nout)) return false;      // Winograd-along-x form of the main convolution: no skip chunks there (math may carry the direct bit)
+  math &= ~PDAE_MATH_DIRECT_BIT;
   if (math < 1 || up || (C & 31) || (Cs0 & 31) || (Cs1 & 31) || (H % 8) || (W % PTW) || (Nout & 3) || Nout < 32) return false;
-  if (conv3x3p_form(math, C, H, W, N, Nout)) return false;      // Winograd-along-x form of the main convolution: no skip chunks there -- the separate 1x1 launch costs less than the form gains
   const PatchPlan q = patch_plan(C + Cs0 + Cs1, H, W, N, Nout);
   return q.blocks / q.splits >= 256;              // enough tiles without split-K (the fused launch never splits)
 }
@@ -534,6 +535,7 @@ static size_t prep_bytes(int math, int Nout, int C) {
 // A launch the direct plan would split over K keeps the direct form.  Fused 1x1 skip chunks exist in the direct form only: conv3x3p_skip_ok
 // says no where this function says 1, and the caller computes the skip convolution separately (it then enters as the residual).
 int conv3x3p_form(int math, int C, int H, int W, int N, int Nout) {
+  if (math & PDAE_MATH_DIRECT_BIT) return 0;              // the caller pinned the direct form (pdae_conv_desc.math | PDAE_MATH_DIRECT)
   if (!conv3x3x_ok(math, C, H, W, N, Nout)) return 0;
   return patch_plan(C, H, W, N, Nout).splits == 1 ? 1 : 0;
 }
@@ -566,6 +568,8 @@ size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1, int C0,
                     const float* coef, int act, const PatchSkip* sk, const float* amax, float* stat_part) {
+  const int math_form = math;                             // may carry the direct bit (forward launches): only conv3x3p_form looks at it
+  math &= ~PDAE_MATH_DIRECT_BIT;
   PatchParams P;
   P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
   P.woscale = 1.0f / conv3x3p_wscale(C); P.amax = amax; P.sat = pdae_sat_counter();
@@ -583,7 +587,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   P.stat_tpi = q.splits != 1 ? (H * W + reduce_stats_tp(N, H * W) - 1) / reduce_stats_tp(N, H * W) : q.tiles_x * q.tiles_y * (q.th / 8);
   if (P.stat_part && ((Nout & 3) || (q.splits != 1 && Nout > 1024))) { pdae_set_error("conv3x3p: output statistics requested for Nout = %d", Nout); return PDAE_EINVAL; }
   // Winograd F(2, 3) along x (conv3x3x.hip): two thirds of the MFMAs; the prepared weights are in that form iff conv3x3p_form says so
-  if (!q.w8 && conv3x3p_form(math, C, H, W, N, Nout)) {
+  if (!q.w8 && conv3x3p_form(math_form, C, H, W, N, Nout)) {
     if (sk) { pdae_set_error("conv3x3p: fused skip chunks are not built for the Winograd form (pdae_conv2d_fwd_skip_ok == 0 for this shape)"); return PDAE_EINVAL; }
     if (coef && !act) { pdae_set_error("conv3x3p: fused GroupNorm input without SiLU is not built for the Winograd form"); return PDAE_EINVAL; }
     P.stat_tpi = (H / 16) * (W / 16) * 2;
@@ -628,7 +632,9 @@ static int wprep_launch(int math, const float* w, int Nout, int C, int transpose
 }
 
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s, int H, int W, int N) {
-  if (conv3x3p_form(math, C, H, W, N, Nout)) return wprep_launch(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, s);
+  const int form = conv3x3p_form(math, C, H, W, N, Nout);
+  math &= ~PDAE_MATH_DIRECT_BIT;
+  if (form) return wprep_launch(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, s);
   return wprep_launch(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, s);
 }
 static void fill_job3(int math, const float* w, int Nout, int C, int transposed, float wscale, int T, unsigned short* wp, WprepJob* j) {
@@ -637,7 +643,9 @@ static void fill_job3(int math, const float* w, int Nout, int C, int transposed,
   j->nblocks = (int)(((size_t)(C >> 5) * 2 * T * j->NT * 64 + 255) / 256);
 }
 void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j, int H, int W, int N) {
-  if (conv3x3p_form(math, C, H, W, N, Nout)) fill_job3(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, j);
+  const int form = conv3x3p_form(math, C, H, W, N, Nout);
+  math &= ~PDAE_MATH_DIRECT_BIT;
+  if (form) fill_job3(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, j);
   else fill_job3(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, j);
 }
 void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, WprepJob* j, int H, int W, int N) {

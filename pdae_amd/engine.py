@@ -178,6 +178,7 @@ class Builder:
         self._amax_dy, self._amax_buf, self._amax_until = None, None, -1
         self.fuse_db = os.environ.get("PDAE_FUSE_DB", "1") != "0"      # bias gradients ride in the weight-gradient launch
         self.fuse_skip = os.environ.get("PDAE_FUSE_SKIP", "1") != "0"  # ResBlock skip_connection rides in conv2's K loop (conv_skip)
+        self.skip_direct_ratio = float(os.environ.get("PDAE_SKIP_DIRECT_RATIO", "0"))   # > 0: skip / main channel ratio from which a Winograd-eligible conv2 keeps the direct form + fused skip (default: never)
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
         # forward 3x3 convolutions leave the GroupNorm partial statistics of their output behind (pdae_conv_stats_arm); the GroupNorm that
         # reads such a tensor takes them instead of a statistics pass over it
@@ -491,13 +492,19 @@ class Builder:
         self.p.emit(H.op_silu(x, y, x.numel()))
         return y
 
-    def _skip_parts(self, c, skip):
+    def _skip_parts(self, c, skip, gn=False):
         """(cs, s0, s1, wps, bias_s, ctx) of a fusable 1x1 skip convolution riding on the 3x3 conv c, or None."""
         if skip is None or not self.fuse_skip:
             return None
         s0, s1, sname = skip
         ws, bs = self.P[sname + ".weight"], self.P[sname + ".bias"]
         cs = H.Conv(c.N, c.Ho, c.Wo, s0.shape[3], 0 if s1 is None else s1.shape[3], c.Cout, k=1, math=self.math)
+        # A convolution in the Winograd-along-x form takes no skip chunks: the skip convolution then runs as its own 1x1 launch and enters as the
+        # residual.  PDAE_SKIP_DIRECT_RATIO = r pins the direct form + fused skip (PDAE_MATH_DIRECT in the descriptor, BEFORE the main weights are
+        # prepared) where the skip input has >= r x the main input's channels; measured on the FFHQ-128 step (one box): never 51.42 ms, r = 2
+        # 51.93, r = 1.4 52.07, always 52.07 -- so the default is never.
+        if self.skip_direct_ratio > 0 and c.winograd_form(0, gn=gn) and cs.Cin >= self.skip_direct_ratio * c.Cin:
+            c.direct = True
         nbytes = H.conv_skip_wprep_bytes(c, cs)
         if nbytes == 0:
             return None
@@ -554,7 +561,7 @@ class Builder:
         c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=3, up=up, math=self.math)
         if c.wprep_bytes(0, gn=True) == 0:
             return None
-        sp = self._skip_parts(c, skip)
+        sp = self._skip_parts(c, skip, gn=True)
         if skip is not None and sp is None:
             return None
         pl = self.p

@@ -31,6 +31,7 @@ class ConvDesc(ctypes.Structure):
 
 MATH_F32, MATH_BF16, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2, 3      # pdae_conv_desc.math
 MATH_NAMES = {"f32": 0, "bf16": 1, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
+MATH_DIRECT = 0x100                                               # PDAE_MATH_DIRECT (pdae_hip.h)
 # default arithmetic of the conv GEMMs on fp32 tensors.  Every fp32 operand is split into low-precision planes whose leading cross
 # products are accumulated in fp32 on the MFMA pipe:
 #   "f16x3"  (default): the 3x3 kernels (forward, data gradient, weight gradient) use two fp16 planes (11+11 mantissa bits, 3 products);
@@ -211,13 +212,16 @@ def ops_array(ops):
 class Conv:
     """Geometry of one convolution over NHWC activations (pdae_conv_desc)."""
 
-    def __init__(self, N, Hi, Wi, C0, C1, Cout, k=3, stride=1, pad=None, up=False, math=0):
+    def __init__(self, N, Hi, Wi, C0, C1, Cout, k=3, stride=1, pad=None, up=False, math=0, direct=False):
         pad = k // 2 if pad is None else pad
         Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
         self.N, self.Hi, self.Wi, self.C0, self.C1, self.Cout = N, Hi, Wi, C0, C1, Cout
         self.KH = self.KW = k
         self.stride, self.pad, self.up = stride, pad, int(up)
-        self.math = int(math)       # MATH_F32 / MATH_BF16 / MATH_BF16X3 / MATH_BF16X6
+        self.math = int(math) & 0xff       # MATH_F32 / MATH_BF16 / MATH_BF16X3 / MATH_BF16X6 / f16x3
+        # PDAE_MATH_DIRECT: the FORWARD form of this 3x3 convolution stays on the direct kernels (eligible for fused skip chunks); set before the
+        # weights are prepared, travels in the descriptor's math field
+        self.direct = bool(direct) or bool(int(math) & MATH_DIRECT)
         self.Ho = (Hl + 2 * pad - k) // stride + 1
         self.Wo = (Wl + 2 * pad - k) // stride + 1
         self.Hl, self.Wl = Hl, Wl
@@ -227,7 +231,8 @@ class Conv:
         return self.C0 + self.C1
 
     def fields(self):
-        return [self.N, self.Hi, self.Wi, self.C0, self.C1, self.Ho, self.Wo, self.Cout, self.KH, self.KW, self.stride, self.pad, self.up, self.math]
+        return [self.N, self.Hi, self.Wi, self.C0, self.C1, self.Ho, self.Wo, self.Cout, self.KH, self.KW, self.stride, self.pad, self.up,
+                self.math | (MATH_DIRECT if self.direct else 0)]
 
     def cdesc(self):
         d = ConvDesc()

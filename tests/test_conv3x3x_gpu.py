@@ -166,6 +166,49 @@ def test_fused_skip_chunks_exist_in_the_direct_form_only(H, monkeypatch, case):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("case", [(16, 64, 32, 32, 96, 0, 128, False), (8, 64, 64, 96, 32, 32, 256, True)])
+def test_direct_bit_in_the_descriptor_keeps_the_fused_skip(H, monkeypatch, case):
+    """pdae_conv_desc.math | PDAE_MATH_DIRECT (hip.Conv(direct=True)): the FORWARD form of that convolution stays direct under PDAE_W1 -- prepared weights
+    and launch agree because both read the same descriptor --, so the fused skip launch is offered and correct; the data gradient through the same
+    descriptor ignores the bit and stays in the Winograd form.  (engine.Builder._skip_parts pins wide-skip ResBlocks this way.)"""
+    monkeypatch.setenv("PDAE_W1", "2")
+    N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
+    Cs, G = Cs0 + Cs1, 32
+    x = rn(1, N, C, Hh, W) * 1.2 + 0.3
+    sx = rn(2, N, Cs, Hh, W) * 2.0
+    w = rn(3, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(4, Cout, scale=0.1)
+    wsk = rn(5, Cout, Cs, 1, 1, scale=1.0 / math.sqrt(Cs)); bsk = rn(6, Cout, scale=0.1)
+    gamma, beta = 1 + 0.2 * rn(7, C), 0.2 * rn(8, C) + 0.4
+    c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4, direct=True)
+    cw = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
+    cs = H.Conv(N, Hh, W, Cs0, Cs1, Cout, k=1, math=4)
+    assert cw.winograd_form(0) and not c.winograd_form(0)
+    assert H.conv_fwd_skip_ok(c, cs) and not H.conv_fwd_skip_ok(cw, cs)
+    if Cout % 128 == 0 and C % 128 == 0:
+        assert c.winograd_form(1, f16_grad=True) == cw.winograd_form(1, f16_grad=True)      # the data gradient does not see the bit
+    a_ref = _gn_ref(x.double(), gamma.double(), beta.double(), None) if use_gn else x.double()
+    y_ref = F.conv2d(a_ref, w.double(), b.double(), padding=1) + F.conv2d(sx.double(), wsk.double(), bsk.double())
+    xd, sh = nhwc(x).cuda(), nhwc(sx).cuda()
+    s0 = sh[..., :Cs0].contiguous(); s1 = sh[..., Cs0:].contiguous() if Cs1 else None
+    wd, wsd = nhwc(w).cuda(), nhwc(wsk).cuda()
+    coef = None
+    if use_gn:
+        mean, rstd, coef = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, C, device="cuda")
+        ws = torch.empty(H.gn_ws_bytes(N, C) // 4 + 64, device="cuda")
+        H.run(H.op_gn_stats_coef(xd, C, None, 0, N, Hh * W, G, 1e-5, gamma.cuda(), beta.cuda(), None, None, mean, rstd, coef, ws))
+    wp = torch.empty(c.wprep_bytes(0, force=True, gn=use_gn) // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 4 if use_gn else 0, wp))
+    wps = torch.empty(H.conv_skip_wprep_bytes(c, cs) // 4, device="cuda")
+    H.run(H.op_conv_skip_wprep(c, cs, wsd, wps))
+    y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
+    H.run(H.op_conv_fwd_skip(c, xd, None, coef, 1, wp, b.cuda(), cs, s0, s1, wps, bsk.cuda(), y))
+    assert rel_err(nchw(y), y_ref) < 1e-5
+    # the same weights prepared through the plain descriptor are in the other layout
+    wp2 = torch.empty_like(wp)
+    H.run(H.op_conv_wprep(cw, wd, 4 if use_gn else 0, wp2))
+    assert not torch.equal(wp, wp2)
+
+
 @pytest.mark.parametrize("case", [(16, 64, 32, 64, 128, True, 0), (16, 64, 32, 32, 128, False, 1), (8, 64, 64, 96, 256, True, 1)])
 def test_output_statistics_from_the_epilogue(H, monkeypatch, case):
     """The GroupNorm partial statistics of the output ((sum, sum of squares) per wave tile and channel quad, written by the epilogue: plain and
