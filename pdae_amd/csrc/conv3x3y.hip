@@ -54,7 +54,9 @@ typedef __attribute__((address_space(3))) const y_f32x4* y_lds_f4;
 // n * d < 2^32 (launch check); d == 1 has no 32-bit m
 struct YDiv { unsigned mn, mx, my; };
 
-template <int NS, bool GN>
+// EX: the launch has a residual or accumulates (an epilogue operand to load); without it the 32 loads per tile and their 64 registers do not exist
+// (against an empty resource they still cost the vector-memory path ~35 cycles each: tools/micro/unit_pipe.hip)
+template <int NS, bool GN, bool EX>
 __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams P, const int stagger, const YDiv D) {
   constexpr int NP = NPL(NS);
   constexpr unsigned BUF_B = NP * YPLANE_B;
@@ -136,21 +138,30 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   };
   // GroupNorm coefficients of the chunk being converted (this thread's quad for the items, and for the quarter item)
   float4 gmu, gsc, gsh, hmu, hsc, hsh;
-  auto coef_load = [&](int img, int k) {          // the items' quad: with the raw data, one step ahead
-    if constexpr (GN) {
-      const size_t NC = (size_t)P.N * C;
-      const float* cf = P.coef + (size_t)img * C + (k << 4);
-      gmu = *reinterpret_cast<const float4*>(cf + qd * 4); gsc = *reinterpret_cast<const float4*>(cf + NC + qd * 4); gsh = *reinterpret_cast<const float4*>(cf + 2 * NC + qd * 4);
-    }
+  // GroupNorm coefficients of a step = 12 float4 ([mu | scale | shift] x 4 channel quads): ONE buffer load per wave fetches them (lane i < 12 takes
+  // float4 i), they are parked in a private LDS slot and read back per quad.  The direct form (six global loads per thread and step) was 6 of the
+  // 38 vector-memory instructions of a fused-GroupNorm step, each ~35 cycles of the CU's vector-memory path (tools/micro/unit_pipe.hip).
+  float4 cf_raw = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned cf_lds = lds0 + 2u * BUF_B + 4u * 2u * 32u * EPW * 4u + (unsigned)wv * 256u;
+  const unsigned cf_voff = lane < 12 ? (unsigned)(((lane >> 2) * P.N * C + (lane & 3) * 4) * 4) : YOOB;
+  const unsigned cf_slot = cf_lds + (unsigned)(lane < 12 ? lane : 12) * 16u;
+  auto coef_fetch = [&](int img, int k) {
+    if constexpr (GN)
+      cf_raw = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RS(P.coef), (int)cf_voff, (int)((img * C + (k << 4)) * 4), 0));
   };
-  auto coef_load_q = [&](int img, int k) {        // the quarter item's quad: two units before its conversion (twelve registers less across the step)
-    if constexpr (GN) {
-      const size_t NC = (size_t)P.N * C;
-      const float* cf = P.coef + (size_t)img * C + (k << 4);
-      hmu = *reinterpret_cast<const float4*>(cf + q_qd * 4); hsc = *reinterpret_cast<const float4*>(cf + NC + q_qd * 4); hsh = *reinterpret_cast<const float4*>(cf + 2 * NC + q_qd * 4);
-    }
+  auto coef_stash = [&]() {
+    if constexpr (GN) *(__attribute__((address_space(3))) y_f32x4*)(size_t)cf_slot = y_f32x4{cf_raw.x, cf_raw.y, cf_raw.z, cf_raw.w};
   };
-  int c_img = 0, c_k = 0;                          // image / chunk of the raw data being converted
+  auto cf_read = [&](int kind, int quad) {
+    const y_f32x4 v = *(y_lds_f4)(size_t)(cf_lds + (unsigned)((kind * 4 + quad) * 16));
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
+  auto coef_load = [&]() {                         // the items' quad, for the conversions of the next step
+    if constexpr (GN) { gmu = cf_read(0, qd); gsc = cf_read(1, qd); gsh = cf_read(2, qd); }
+  };
+  auto coef_load_q = [&]() {                       // the quarter item's quad: two units before its conversion (twelve registers less across the step)
+    if constexpr (GN) { hmu = cf_read(0, q_qd); hsc = cf_read(1, q_qd); hsh = cf_read(2, q_qd); }
+  };
   auto gn_map = [&](float4 v, bool on, const float4& mu, const float4& sc_, const float4& sh_) {
     float4 m;
     m.x = sc_.x * (v.x - mu.x) + sh_.x; m.y = sc_.y * (v.y - mu.y) + sh_.y; m.z = sc_.z * (v.z - mu.z) + sh_.z; m.w = sc_.w * (v.w - mu.w) + sh_.w;
@@ -304,7 +315,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   Y_LD_TILE(l_img, l_y0, l_x0, true)
   Y_LD_SRC(0)
   gload_item(0); gload_item(1); gload_quarter();
-  coef_load(l_img, 0); coef_load_q(l_img, 0);
+  coef_fetch(l_img, 0); coef_stash(); coef_load(); coef_load_q();
   cv_vm = ld_vm;
   cur = 1;                                         // the conversions write buffer cur ^ 1 = 0
   conv_A(0); conv_B(0); conv_C(0, 0); conv_C(0, 2);
@@ -313,7 +324,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   cur = 0;
   PDAE_Y_LD_NEXT()
   gload_item(0); gload_item(1); gload_quarter();
-  coef_load(l_img, l_k);
+  coef_fetch(l_img, l_k); coef_stash(); coef_load();      // (the quarter item's quad is read at unit 6 of the first step)
   {
     const int nt0 = (m_n0 >> 5) + wv;
 #pragma unroll
@@ -366,7 +377,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
 #define PDAE_Y_STEP(FIRST)                                                                                    \
   {                                                                                                           \
     const int m_nt0 = (m_n0 >> 5) + wv, n_nt0 = (n_n0 >> 5) + wv;                                             \
-    cv_vm = ld_vm; c_img = l_img; c_k = l_k;        /* validity / coefficients' position of the raw data in the registers (step m + 1) */ \
+    cv_vm = ld_vm;                                  /* validity of the raw data in the registers (step m + 1) */ \
     PDAE_Y_LD_NEXT()                                /* the loads of this iteration: step m + 2 */              \
     abase = a_lane + cur * BUF_B; abase_n = a_lane + (cur ^ 1u) * BUF_B;                                      \
     asm volatile("" : "+v"(abase), "+v"(abase_n));                                                            \
@@ -374,18 +385,18 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     PDAE_Y_UNIT(1, FIRST, PDAE_Y_CV(conv_B(0);))                                                              \
     PDAE_Y_UNIT(2, FIRST, PDAE_Y_CV(conv_C(0, 0);))                                                           \
     PDAE_Y_UNIT(3, FIRST, PDAE_Y_CV(conv_C(0, 2);))                                                           \
-    PDAE_Y_UNIT(4, FIRST, PDAE_Y_CV(conv_A(1);) PDAE_Y_GL(gload_item(0);))      /* eight units ahead of its conversion */ \
+    PDAE_Y_UNIT(4, FIRST, PDAE_Y_CV(conv_A(1);) PDAE_Y_GL(gload_item(0);) coef_fetch(l_img, l_k);)      /* eight units ahead of its conversion */ \
     PDAE_Y_UNIT(5, FIRST, PDAE_Y_CV(conv_B(1);))                                                              \
-    PDAE_Y_UNIT(6, FIRST, PDAE_Y_CV(conv_C(1, 0);) coef_load_q(c_img, c_k);)                                  \
+    PDAE_Y_UNIT(6, FIRST, PDAE_Y_CV(conv_C(1, 0);) coef_load_q();)                                            \
     PDAE_Y_UNIT(7, FIRST, PDAE_Y_CV(conv_C(1, 2);))                                                           \
     PDAE_Y_UNIT(8, FIRST, PDAE_Y_CV(conv_quarter();) PDAE_Y_GL(gload_item(1);))                               \
     PDAE_Y_UNIT(9, FIRST, PDAE_Y_GL(gload_quarter();))                                                        \
     /* the step's barrier: every conversion into the other buffer is done (unit 8), every read of this one is issued (unit 12 - YRA); */ \
     /* behind it the first fragments of the NEXT step are fetched from the other buffer */                     \
     if (YRA == 3) __syncthreads();                                                                            \
-    PDAE_Y_UNIT(10, FIRST, )                                                                                  \
+    PDAE_Y_UNIT(10, FIRST, coef_stash();)                                                                     \
     if (YRA == 2) __syncthreads();                                                                            \
-    PDAE_Y_UNIT(11, FIRST, coef_load(l_img, l_k);)                                                            \
+    PDAE_Y_UNIT(11, FIRST, coef_load();)                                                                      \
     cur ^= 1u;                                                                                                \
   }
 
@@ -446,10 +457,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
       const float* const extra_ = P.res_mode ? P.res : P.y;      // residual OR (accumulate) the previous contents of y (both: conv3x3y_launch falls back)
       const unsigned extra_on = (P.res_mode || P.accumulate) ? YALL : 0u, stat_on = P.stat_part ? YALL : 0u, bias_on = P.bias ? YALL : 0u;
 #define Y_RSB(PTR, BYTES) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((const void*)(PTR)), 0, (int)(BYTES), 0x00020000)
-      float4 rv[2][2][4];
+      float4 rv[EX ? 2 : 1][2][EX ? 4 : 1];
       float st1 = 0.f, st2 = 0.f;
       const float4 bias4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.bias, bias_on), ec * 4, (int)(n0w * 4), 0));
       auto epi_L = [&](int b) {                       // block b = m-tile a
+        if constexpr (EX)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -477,8 +489,9 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
           for (int it = 0; it < 4; ++it) {
             const y_f32x4 v4 = *(y_lds_f4)(size_t)(tw_r + (unsigned)j * TWB + (unsigned)(it * 8 * EPW * 4));
             float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
-            const float4 u = rv[b & 1][j][it], bb = bias4;
-            v.x = fmaf(v.x, oscale, bb.x + u.x); v.y = fmaf(v.y, oscale, bb.y + u.y); v.z = fmaf(v.z, oscale, bb.z + u.z); v.w = fmaf(v.w, oscale, bb.w + u.w);
+            float4 bb = bias4;
+            if constexpr (EX) { const float4 u = rv[b & 1][j][it]; bb.x += u.x; bb.y += u.y; bb.z += u.z; bb.w += u.w; }
+            v.x = fmaf(v.x, oscale, bb.x); v.y = fmaf(v.y, oscale, bb.y); v.z = fmaf(v.z, oscale, bb.z); v.w = fmaf(v.w, oscale, bb.w);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(y_u32x4, v), Y_RSB(P.y, YALL), (int)lane_y, (int)(d_rb4 + it * y_it + j * y_j + (b & 1) * y_a2 + (b >> 1) * y_ar), 0);
             st1 += (v.x + v.y) + (v.z + v.w);
             st2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, st2))));
@@ -516,11 +529,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
 }
 
-template <int NS, bool GN> static int launch_y(const PatchParams& P, hipStream_t s) {
-  const size_t smem = (size_t)2 * NPL(NS) * YPLANE_B + (size_t)4 * 2 * 32 * EPW * 4;      // two patch buffers + two transposition tiles per wave (f16x3: 161280 of 163840 bytes)
+template <int NS, bool GN, bool EX> static int launch_y(const PatchParams& P, hipStream_t s) {
+  const size_t smem = (size_t)2 * NPL(NS) * YPLANE_B + (size_t)4 * 2 * 32 * EPW * 4 + 4 * 256;      // two patch buffers + two transposition tiles per wave + the coefficient slots (f16x3: 162304 of 163840 bytes)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3y: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
@@ -531,14 +544,15 @@ template <int NS, bool GN> static int launch_y(const PatchParams& P, hipStream_t
   auto magic = [](int d) { return (unsigned)((0x100000000ull / (unsigned long long)d) + 1ull); };      // unused for d == 1
   const YDiv D{magic(P.tiles_n), magic(P.tiles_x), magic(P.tiles_y)};
   if (ntiles >= (1ll << 20) || P.tiles_n >= 4096 || P.tiles_x >= 4096 || P.tiles_y >= 4096) { pdae_set_error("conv3x3y: %lld tiles", ntiles); return 1; }
-  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
+  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
   return pdae_launch_status("conv3x3y");
 }
 
 // P: as prepared by conv3x3x_launch (tiles of 16 x 16 pixels x 128 channels, Winograd-along-x weights); no fused skip chunks
 int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s) {
   if (P.res_mode && P.accumulate) { pdae_set_error("conv3x3y: residual and accumulate in one launch"); return 1; }
-#define PDAE_Y3(NS_) (P.coef ? launch_y<NS_, true>(P, s) : launch_y<NS_, false>(P, s))
+#define PDAE_Y3(NS_) (P.coef ? (ex ? launch_y<NS_, true, true>(P, s) : launch_y<NS_, true, false>(P, s)) : (ex ? launch_y<NS_, false, true>(P, s) : launch_y<NS_, false, false>(P, s)))
+  const bool ex = P.res_mode || P.accumulate;
   if (math == 1) return PDAE_Y3(1);
   if (math == 2) return PDAE_Y3(2);
   return PDAE_Y3(4);
