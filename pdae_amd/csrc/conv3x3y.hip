@@ -162,12 +162,25 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   auto coef_load_q = [&]() {                       // the quarter item's quad: two units before its conversion (twelve registers less across the step)
     if constexpr (GN) { hmu = cf_read(0, q_qd); hsc = cf_read(1, q_qd); hsh = cf_read(2, q_qd); }
   };
+  // silu(scale * (x - mu) + shift) on a channel quad, written on float pairs so that the subtract / fma / the three multiply-adds of SiLU are packed
+  // instructions (v_pk_add_f32, v_pk_fma_f32, v_pk_mul_f32: half the VALU issue slots; the fused-GroupNorm instantiation spends 3.9 VALU instructions
+  // per MFMA on this map); padding pixels are multiplied by 0 AFTER the map (their raw value is the 0 of an out-of-range load)
+  typedef float y_f32x2 __attribute__((ext_vector_type(2)));
   auto gn_map = [&](float4 v, bool on, const float4& mu, const float4& sc_, const float4& sh_) {
-    float4 m;
-    m.x = sc_.x * (v.x - mu.x) + sh_.x; m.y = sc_.y * (v.y - mu.y) + sh_.y; m.z = sc_.z * (v.z - mu.z) + sh_.z; m.w = sc_.w * (v.w - mu.w) + sh_.w;
-    m.x = p_silu(m.x); m.y = p_silu(m.y); m.z = p_silu(m.z); m.w = p_silu(m.w);      // act == 1 (launch check)
-    v.x = on ? m.x : v.x; v.y = on ? m.y : v.y; v.z = on ? m.z : v.z; v.w = on ? m.w : v.w;      // padding pixels stay zero AFTER the map
-    return v;
+    const float onf = on ? 1.0f : 0.0f;
+    y_f32x2 r[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const y_f32x2 x2 = hh ? y_f32x2{v.z, v.w} : y_f32x2{v.x, v.y};
+      const y_f32x2 mu2 = hh ? y_f32x2{mu.z, mu.w} : y_f32x2{mu.x, mu.y};
+      const y_f32x2 sc2 = hh ? y_f32x2{sc_.z, sc_.w} : y_f32x2{sc_.x, sc_.y};
+      const y_f32x2 sh2 = hh ? y_f32x2{sh_.z, sh_.w} : y_f32x2{sh_.x, sh_.y};
+      const y_f32x2 m = __builtin_elementwise_fma(sc2, x2 - mu2, sh2);
+      const y_f32x2 a = m * -1.4426950408889634f;
+      const y_f32x2 d = y_f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
+      r[hh] = m * y_f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])} * onf;      // act == 1 (launch check)
+    }
+    return make_float4(r[0][0], r[0][1], r[1][0], r[1][1]);
   };
   unsigned cur = 0;
   // LDS store bases (into buffer cur ^ 1): items: row r8 + 8 l, position c * 8 + wt, quad qd; quarter item: row q_row, position q_c * 8 + q_wt
