@@ -1,23 +1,30 @@
-// Winograd F(2, 3)-along-x 3x3 convolution (forward / data gradient) for gfx950 in the PERSISTENT one-wave-per-SIMD structure of conv3x3r.hip --
-// the register budget the form needs (conv3x3x.hip, the two-waves-per-SIMD attempt, had 256 registers per wave: operands single-buffered, U
-// fragments one 6-MFMA step ahead, 0.75-0.9x of the default routing; profiles/r04_winograd_probe.txt).  The probe build of conv3x3r with 24 of
-// its 36 units per chunk -- exactly this form's matrix work -- runs 0.598 vs 0.857 ms on 128x128 256->128, B = 32.
+// Winograd F(2, 3)-along-x 3x3 convolution (forward / data gradient) for gfx950 in the PERSISTENT one-wave-per-SIMD structure of conv3x3r.hip.
+//
+// Per output pixel pair (x, x + 1) and row tap ky the three column taps become four transform positions c:
+//   input   s = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)            of the pair's window d0..d3 = pixels 2p - 1 .. 2p + 2   (here, while staging, in fp32)
+//   weights u = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2)  (wprepx_slot in conv3x3p.h, once per optimizer step)
+//   M_c += s_c u_c on the MFMAs;   Y0 = M0 + M1 + M2,  Y1 = M1 - M2 - M3 in the epilogue
+// i.e. 4 instead of 6 products per pair, row tap and channel: two thirds of the matrix instructions of the direct form.  History of the form:
+// conv3x3x.hip (two waves per SIMD, 256 registers: 0.75-0.9x of the direct kernels), the probe build of conv3x3r with 24 of its 36 units per
+// chunk (0.598 vs 0.857 ms on 128x128 256->128, B = 32: the bound that motivated this file), winograd.hip (the 2-D form, gated out);
+// profiles/r04_winograd_probe.txt has the measurements, DESIGN.md section 7 the probe ladder of this kernel.
 //
 //   * 4 waves, one per SIMD, 512 registers: wave w = the whole 16 x 16-pixel tile x 32 output channels (32 w ..), accumulators acc[c][a] = 16 tiles
 //     of 32 x 32 in the 256 AGPRs (transform position c; m-tile a = (row half a >> 1, pair half a & 1)).  Each weight fragment is fetched by ONE
 //     wave (the earlier (8 rows x 64 channels) split fetched every fragment twice per CU: 50 B/clk through the vector cache at full matrix rate,
 //     against 25 now) and used for four products; the patch fragments -- LDS, 256 B/clk -- are read by all four waves.  No second accumulator
 //     set: the epilogue is NOT deferred, it runs between tiles (output transform lane-local, conv3x3r's transposition + float4 stores).
-//   * chunk = 16 input channels = one k-step per (ky, c): 12 units of 12 MFMAs (2 halves x 2 channel tiles x 3 products, a dependent pair 4 issues
-//     apart); U fragments: ring of four units (requested three units = 36 MFMAs ahead), patch fragments: ring of two.
+//   * step = 16 input channels = 12 units (ky, c) of 12 MFMAs (4 m-tiles x 3 products, a dependent pair 4 issues apart).  Weight fragments: ring
+//     of YRB units straight from L2 (buffer loads, YRB - 1 units ahead); patch fragments: ring of YRA units from LDS.
 //   * LDS patch in the transform domain, double buffered: 18 rows x 36 positions (c * 8 + pair) x 48-byte rows (16 channels + pad: 36 * 48 = 192
-//     (mod 256) keeps every ds_read_b128 fragment conflict-free) x planes = 62 KB per buffer.  The raw input of chunk s + 2 is loaded while chunk s
-//     is multiplied and transformed / split / stored into the other buffer while chunk s + 1 is: per thread two items (patch row, pair, channel
-//     quad: own pixel pair + one edge pixel, the neighbours' pixels across lanes) and one quarter item of patch rows 16, 17 (one position of a
-//     pair: two loads); each item's conversion is spread over three units.
+//     (mod 256) keeps every ds_read_b128 fragment conflict-free) x planes = 62 KB per buffer.  The raw input of step s + 2 is loaded while step s
+//     is multiplied (8 - 11 units ahead of its use) and transformed / split / stored into the other buffer while step s + 1 is: per thread two
+//     items (patch row, pair, channel quad: own pixel pair + one segment-edge pixel, the neighbours' pixels through DPP row shifts) and one
+//     quarter item of patch rows 16, 17 (one position of a pair: two loads); the conversions are spread over units 0 - 8.  ONE barrier per step,
+//     placed so that the first fragments of the next step are fetched behind it.
 //   * everything inside a unit is branch-free (absent operands = empty buffer resources / out-of-range offsets, as in conv3x3r).
-// Prepared weights: the Winograd-along-x layout of conv3x3x.hip (wprepx_slot, 12 taps x 2 k halves per 32-channel chunk).  Fused skip chunks are
-// not built here: such launches stay on conv3x3x.
+// Prepared weights: the Winograd-along-x layout (wprepx_slot, 12 taps x 2 k halves per 32-channel chunk).  Fused 1x1 skip chunks are not built for
+// this form: pdae_conv2d_fwd_skip_ok says no where it applies (conv3x3p_skip_ok).
 #include <stdlib.h>
 
 #include "common.h"
