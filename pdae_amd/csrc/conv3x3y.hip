@@ -63,7 +63,9 @@ struct YDiv { unsigned mn, mx, my; };
 
 // EX: the launch has a residual or accumulates (an epilogue operand to load); without it the 32 loads per tile and their 64 registers do not exist
 // (against an empty resource they still cost the vector-memory path ~35 cycles each: tools/micro/unit_pipe.hip)
-template <int NS, bool GN, bool EX>
+// ST: the launch leaves the GroupNorm partial statistics of its output (pdae_conv_stats_arm); data gradients and convolutions not followed by a
+// GroupNorm do not, and then the 64 VALU instructions per epilogue block that sum them do not exist either
+template <int NS, bool GN, bool EX, bool ST>
 __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams P, const int stagger, const YDiv D) {
   constexpr int NP = NPL(NS);
   constexpr unsigned BUF_B = NP * YPLANE_B;
@@ -493,12 +495,32 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
         // the accumulators are read HERE: without the opaque redefinition the sixteen-float extractions of all four blocks were hoisted to the top
         // of the epilogue (192 v_accvgpr_read up front, 42 spilled registers)
         asm volatile("" : "+a"(acc[0][b]), "+a"(acc[1][b]), "+a"(acc[2][b]), "+a"(acc[3][b]));
+        // LDS STORE SOURCE HAZARD (found here in round 4): `ds_write2_b32 v40, v41, v42` followed one instruction later by
+        // `v_accvgpr_read_b32 v42, a98` stored the NEW v42 in lanes 12-15 of every 16 -- a store's operands leave the register file over several
+        // cycles (longer when two waves of a SIMD pair store at once) and the accumulator read is not interlocked against that.  So: all values of a
+        // half block are computed first (no accumulator read between the stores) and a spacer separates the stores from the next reads;
+        // tools/isa_hazard.py finds the pattern in the assembly, tests/test_kernel_resources_cpu.py asserts it is absent.
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float m0 = acc[0][b][r], m1 = acc[1][b][r], m2 = acc[2][b][r], m3 = acc[3][b][r];
-          const unsigned o = tw_w + (unsigned)((((r & 3) + 8 * (r >> 2)) * EPW) * 4);
-          *(y_lds_f)(size_t)(o) = (m0 + m1) + m2;
-          *(y_lds_f)(size_t)(o + TWB) = (m1 - m2) - m3;
+        for (int hf = 0; hf < 2; ++hf) {
+          float z0[8], z1[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = hf * 8 + q;
+            const float m0 = acc[0][b][r], m1 = acc[1][b][r], m2 = acc[2][b][r], m3 = acc[3][b][r];
+            z0[q] = (m0 + m1) + m2;
+            z1[q] = (m1 - m2) - m3;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = hf * 8 + q;
+            const unsigned o = tw_w + (unsigned)((((r & 3) + 8 * (r >> 2)) * EPW) * 4);
+            *(y_lds_f)(size_t)(o) = z0[q];
+            *(y_lds_f)(size_t)(o + TWB) = z1[q];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
       auto epi_S = [&](int b) {
@@ -513,10 +535,12 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
             if constexpr (EX) { const float4 u = rv[b & 1][j][it]; bb.x += u.x; bb.y += u.y; bb.z += u.z; bb.w += u.w; }
             v.x = fmaf(v.x, oscale, bb.x); v.y = fmaf(v.y, oscale, bb.y); v.z = fmaf(v.z, oscale, bb.z); v.w = fmaf(v.w, oscale, bb.w);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(y_u32x4, v), Y_RSB(P.y, YALL), (int)lane_y, (int)(d_rb4 + it * y_it + j * y_j + (b & 1) * y_a2 + (b >> 1) * y_ar), 0);
-            st1 += (v.x + v.y) + (v.z + v.w);
-            st2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, st2))));
+            if constexpr (ST) {
+              st1 += (v.x + v.y) + (v.z + v.w);
+              st2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, st2))));
+            }
           }
-        if ((b & 1) == 1) {      // (sum, sum of squares) of a row half's 8 x 16 pixels per channel quad: the eight lanes holding a quad combine, lanes 0..7 write
+        if (ST && (b & 1) == 1) {      // (sum, sum of squares) of a row half's 8 x 16 pixels per channel quad: the eight lanes holding a quad combine, lanes 0..7 write
           float s1 = st1, s2 = st2;
           s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8);
           s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
@@ -549,11 +573,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
 }
 
-template <int NS, bool GN, bool EX> static int launch_y(const PatchParams& P, hipStream_t s) {
+template <int NS, bool GN, bool EX, bool ST> static int launch_y(const PatchParams& P, hipStream_t s) {
   const size_t smem = (size_t)2 * NPL(NS) * YPLANE_B + (size_t)4 * 2 * 32 * EPW * 4 + 4 * 256;      // two patch buffers + two transposition tiles per wave + the coefficient slots (f16x3: 162304 of 163840 bytes)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN, EX, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3y: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
@@ -564,17 +588,20 @@ template <int NS, bool GN, bool EX> static int launch_y(const PatchParams& P, hi
   auto magic = [](int d) { return (unsigned)((0x100000000ull / (unsigned long long)d) + 1ull); };      // unused for d == 1
   const YDiv D{magic(P.tiles_n), magic(P.tiles_x), magic(P.tiles_y)};
   if (ntiles >= (1ll << 20) || P.tiles_n >= 4096 || P.tiles_x >= 4096 || P.tiles_y >= 4096) { pdae_set_error("conv3x3y: %lld tiles", ntiles); return 1; }
-  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
+  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX, ST>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
   return pdae_launch_status("conv3x3y");
 }
 
 // P: as prepared by conv3x3x_launch (tiles of 16 x 16 pixels x 128 channels, Winograd-along-x weights); no fused skip chunks
 int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s) {
   if (P.res_mode && P.accumulate) { pdae_set_error("conv3x3y: residual and accumulate in one launch"); return 1; }
-#define PDAE_Y3(NS_) (P.coef ? (ex ? launch_y<NS_, true, true>(P, s) : launch_y<NS_, true, false>(P, s)) : (ex ? launch_y<NS_, false, true>(P, s) : launch_y<NS_, false, false>(P, s)))
-  const bool ex = P.res_mode || P.accumulate;
+#define PDAE_Y2(NS_, GN_) (ex ? (st ? launch_y<NS_, GN_, true, true>(P, s) : launch_y<NS_, GN_, true, false>(P, s))       \
+                              : (st ? launch_y<NS_, GN_, false, true>(P, s) : launch_y<NS_, GN_, false, false>(P, s)))
+#define PDAE_Y3(NS_) (P.coef ? PDAE_Y2(NS_, true) : PDAE_Y2(NS_, false))
+  const bool ex = P.res_mode || P.accumulate, st = P.stat_part != nullptr;
   if (math == 1) return PDAE_Y3(1);
   if (math == 2) return PDAE_Y3(2);
   return PDAE_Y3(4);
 #undef PDAE_Y3
+#undef PDAE_Y2
 }

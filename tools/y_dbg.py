@@ -7,7 +7,7 @@ x = torch.randn(N, S, W, Cin, device="cuda"); w = torch.randn(Cout, 3, 3, Cin, d
 outs = {}
 for mode in ("0", "2"):
     os.environ["PDAE_W1"] = mode
-    c = H.Conv(N, S, W, Cin, 0, Cout, k=3, math=4)
+    c = H.Conv(N, S, W, Cin, 0, Cout, k=3, math=int(os.environ.get("MATH", "4")))
     wp = torch.empty(c.wprep_bytes(0, force=True) // 4, device="cuda"); H.run(H.op_conv_wprep(c, w, 0, wp))
     y = torch.full((N, S, W, Cout), float("nan"), device="cuda")
     H.run(H.op_conv_fwd(c, x, None, w, b, y, wp=wp)); torch.cuda.synchronize()
