@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
 #pragma unroll
     for (int u = 0; u < YRB - 1; ++u) ldb(qb[u], 0, u, nt0);
   }
-  int n_k, n_n0;                                   // chunk / first output channel of step m + 1 (its U fragments are requested from unit 9 on)
+  int n_k, n_n0;                                   // chunk / first output channel of step m + 1 (its U fragments are requested YRB - 1 units ahead, from this step)
   {
     int t2;
     advance(m_tile, 0, t2, n_k);
