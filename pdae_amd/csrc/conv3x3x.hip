@@ -375,7 +375,9 @@ bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout) {
   if (m == 2) return true;
   const long long tiles = (long long)N * (H / XTH) * (W / PTW) * (Nout / PBN);
   const long long rounds = (tiles + 255) / 256;
-  return tiles >= 256 && tiles * 100 >= rounds * 256 * 85;      // persistent workgroups: the last round must not leave the chip idle
+  static int min_eff = -1;                                    // PDAE_W1_EFF: minimum % of the CUs busy in the last round (tuning aid)
+  if (min_eff < 0) { const char* e = getenv("PDAE_W1_EFF"); min_eff = e ? atoi(e) : 85; }
+  return tiles >= 256 && tiles * 100 >= rounds * 256 * min_eff;      // persistent workgroups: the last round must not leave the chip idle
 }
 
 template <int NS, bool GN> static int launch_x(const PatchParams& P, hipStream_t s) {
