@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256, 1) k(float* out, long long* cyc, int step
 #pragma unroll
       for (int i = 0; i < NV; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i & 7]) : "v"(v[(i + 1) & 7]));
 #pragma unroll
-      for (int i = 0; i < NS; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+      for (int i = 0; i < NS; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc) :: "scc");
 #pragma unroll
       for (int i = 0; i < NL; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(lv) : "v"(laddr));
       if (NL && (m % 12) == 11) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
