@@ -75,7 +75,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   const int ntiles = P.N * P.tiles_y * P.tiles_x * P.tiles_n, G = gridDim.x;
   const unsigned lds0 = (unsigned)(size_t)smem;
   const float ascale = NS == 4 ? (P.amax ? p_pow2_scale(*P.amax) : PASCALE) : 1.0f;
-  float sat_hit = 0.f;
+  float sat_hit = 0.f;                             // fp16-window guard: running per-lane max |raw operand| (UNSCALED: two v_max3 per float4; the scale is applied once, at the end)
+  auto sat_track = [&](const float4& v) {
+    sat_hit = __builtin_fmaxf(__builtin_fmaxf(sat_hit, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
+    sat_hit = __builtin_fmaxf(__builtin_fmaxf(sat_hit, __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
+  };
   const int up_sh = P.up ? 1 : 0;
   const float* const x1_ = P.x1 ? P.x1 : P.x;
 
@@ -202,12 +206,12 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
       const bool rok = (cv_vm >> l) & 1u;
       apre[l][0] = gn_map(apre[l][0], rok, gmu, gsc, gsh); apre[l][1] = gn_map(apre[l][1], rok, gmu, gsc, gsh);
     }
-    if constexpr (NS == 4) { pdae_f16_amax4(apre[l][0], 2.0f * ascale, sat_hit); pdae_f16_amax4(apre[l][1], 2.0f * ascale, sat_hit); }
+    if constexpr (NS == 4) { sat_track(apre[l][0]); sat_track(apre[l][1]); }
   };
   auto conv_B = [&](int l) {
     float4 de = apre[l][2];
     if constexpr (GN) de = gn_map(de, (cv_vm >> (2 + l)) & 1u, gmu, gsc, gsh);
-    if constexpr (NS == 4) pdae_f16_amax4(de, 2.0f * ascale, sat_hit);
+    if constexpr (NS == 4) sat_track(de);
     const float4 d1 = apre[l][0], d2 = apre[l][1];
 #define Y_SHR4(V) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x114, 0xf, 0xf, true))      /* row_shr:4: lane - 4 */
 #define Y_SHL4(V) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), 0x104, 0xf, 0xf, true))      /* row_shl:4: lane + 4 */
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   auto conv_quarter = [&]() {
     float4 da = qpre[0], db = qpre[1];
     if constexpr (GN) { da = gn_map(da, (cv_vm >> 4) & 1u, hmu, hsc, hsh); db = gn_map(db, (cv_vm >> 5) & 1u, hmu, hsc, hsh); }
-    if constexpr (NS == 4) { pdae_f16_amax4(da, 2.0f * ascale, sat_hit); pdae_f16_amax4(db, 2.0f * ascale, sat_hit); }
+    if constexpr (NS == 4) { sat_track(da); sat_track(db); }
     // c = 0: d0 - d2; c = 1: d1 + d2; c = 2: d2 - d1; c = 3: d1 - d3   (da = first, db = second pixel of the position)
     const float sg = q_c == 1 ? 1.0f : -1.0f;
     float4 s = q_c == 2 ? Y_F4(-, db, da) : make_float4(fmaf(sg, db.x, da.x), fmaf(sg, db.y, da.y), fmaf(sg, db.z, da.z), fmaf(sg, db.w, da.w));
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
       Y_DECODE_N0(t3 < ntiles ? t3 : m_tile, n_n0)
     }
   }
-  if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
+  if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit * (2.0f * ascale));      // |s| <= 2 max|d| after the transform
 }
 
 template <int NS, bool GN, bool EX, bool ST> static int launch_y(const PatchParams& P, hipStream_t s) {
