@@ -275,8 +275,12 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   // a distance of three a fragment queued behind the raw-data loads of the same unit (HBM latency) arrived late three times per step
   constexpr int YRB = GN ? 6 : 4;
   uint4 qb[YRB][NP];                               // [unit mod YRB][plane]
-  auto ldb = [&](uint4 (&bq)[NP], int k, int u, int nt0) {
-    const unsigned soff = (unsigned)((((((k >> 1) * 12 + u) << 1) + (k & 1)) * P.NT + nt0) * 1024);
+  // byte offset of unit 0 of chunk k, channel tile nt0 (one scalar chain per STEP); a unit adds u * b_ustep -- the per-load form
+  // ((((k >> 1) * 12 + u) << 1) + (k & 1)) * NT + nt0) * 1024 was five scalar instructions per load, 60 per step, in a wave whose issue port is full
+  const unsigned b_ustep = (unsigned)(2 * P.NT * 1024);
+  auto b_base = [&](int k, int nt0) { return (unsigned)((((k >> 1) * 24 + (k & 1)) * P.NT + nt0) * 1024); };
+  auto ldb = [&](uint4 (&bq)[NP], unsigned base, int u) {
+    const unsigned soff = base + (unsigned)u * b_ustep;
 #pragma unroll
     for (int p = 0; p < NP; ++p) bq[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, lane16, (int)(soff + p * ps2), 0));
   };
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   {
     const int nt0 = (m_n0 >> 5) + wv;
 #pragma unroll
-    for (int u = 0; u < YRB - 1; ++u) ldb(qb[u], 0, u, nt0);
+    for (int u = 0; u < YRB - 1; ++u) ldb(qb[u], b_base(0, nt0), u);
   }
   int n_k, n_n0;                                   // chunk / first output channel of step m + 1 (its U fragments are requested YRB - 1 units ahead, from this step)
   {
@@ -393,8 +397,8 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   {                                                                                                           \
     PDAE_Y_DO_A(if ((U) + YRA - 1 < 12) lda(fa[((U) + YRA - 1) % YRA], abase, (U) + YRA - 1);                 \
                 else lda(fa[((U) + YRA - 1) % YRA], abase_n, (U) + YRA - 1 - 12);)                            \
-    PDAE_Y_DO_B(if ((U) + YRB - 1 < 12) ldb(qb[((U) + YRB - 1) % YRB], m_k, (U) + YRB - 1, m_nt0);            \
-                else ldb(qb[((U) + YRB - 1) % YRB], n_k, (U) + YRB - 1 - 12, n_nt0);)                         \
+    PDAE_Y_DO_B(if ((U) + YRB - 1 < 12) ldb(qb[((U) + YRB - 1) % YRB], m_bb, (U) + YRB - 1);                  \
+                else ldb(qb[((U) + YRB - 1) % YRB], n_bb, (U) + YRB - 1 - 12);)                               \
     WORK                                                                                                      \
     mma(fa[(U) % YRA], qb[(U) % YRB], (U) & 3, (FIRST) && (U) < 4);                                           \
     PDAE_Y_PATTERN(5)                                                                                         \
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   }
 #define PDAE_Y_STEP(FIRST)                                                                                    \
   {                                                                                                           \
-    const int m_nt0 = (m_n0 >> 5) + wv, n_nt0 = (n_n0 >> 5) + wv;                                             \
+    const unsigned m_bb = b_base(m_k, (m_n0 >> 5) + wv), n_bb = b_base(n_k, (n_n0 >> 5) + wv);                \
     cv_vm = ld_vm;                                  /* validity of the raw data in the registers (step m + 1) */ \
     PDAE_Y_LD_NEXT()                                /* the loads of this iteration: step m + 2 */              \
     abase = a_lane + cur * BUF_B; abase_n = a_lane + (cur ^ 1u) * BUF_B;                                      \
