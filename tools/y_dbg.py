@@ -1,5 +1,6 @@
+"""conv3x3y vs the direct kernels on one small shape (MATH env: arithmetic mode): where the outputs differ -- by pixel parity, m-tile, channel tile, row;\nthe script that located the LDS store source hazard.  python tools/y_dbg.py"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pdae_amd import hip as H
 N, S, W, Cin, Cout = 2, 32, 16, 32, 128
