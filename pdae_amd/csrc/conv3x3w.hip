@@ -273,8 +273,13 @@ __global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams
     if constexpr (PD == 2) ldb(bq[1], 0, 1);
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) {
+#ifdef PDAE_W3_PROBE_6TAPS       // timing probe (WRONG results): 24 of the 36 tap steps = the matrix work of a Winograd F(3, 2)-along-x weight gradient
+      const int n = 3;
+      const int before = 3 * kc;
+#else
       const int n = (kc >> 2) == TH ? 5 : 4;                                   // taps of this k-chunk
       const int before = 4 * kc + (TH == 0 ? (kc < 4 ? kc : 4) : (kc > 4 ? kc - 4 : 0));   // steps before this k-chunk
+#endif
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         if (j < n) {

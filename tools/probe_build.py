@@ -8,6 +8,7 @@ P3, W3, R3, AT, WN, X3, Y3 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip", "at
 VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"]), "nostage": (P3, ["-DPDAE_PROBE_NOSTAGE"]),
             "mfma": (P3, ["-DPDAE_PROBE_NOB", "-DPDAE_PROBE_NOA", "-DPDAE_PROBE_NOSTAGE"]), "clustered": (P3, ["-DPDAE_P3_CLUSTERED"]),
             "w3_nomma": (W3, ["-DPDAE_W3_PROBE_NOMMA"]), "w3_nostage": (W3, ["-DPDAE_W3_PROBE_NOSTAGE"]), "w3_noload": (W3, ["-DPDAE_W3_PROBE_NOLOAD"]),
+            "w3_6taps": (W3, ["-DPDAE_W3_PROBE_6TAPS"]),
             "w3_mmaonly": (W3, ["-DPDAE_W3_PROBE_NOSTAGE", "-DPDAE_W3_PROBE_NOLOAD"]),
             "r_noa": (R3, ["-DPDAE_R_PROBE_NOA"]), "r_nob": (R3, ["-DPDAE_R_PROBE_NOB"]), "r_nogload": (R3, ["-DPDAE_R_PROBE_NOGLOAD"]),
             "r_noconv": (R3, ["-DPDAE_R_PROBE_NOCONV"]), "r_nodrain": (R3, ["-DPDAE_R_PROBE_NODRAIN"]),
