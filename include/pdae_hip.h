@@ -29,7 +29,25 @@ extern "C" {
 typedef void* pdae_stream_t; /* hipStream_t */
 
 const char* pdae_last_error(void);
-int pdae_abi_version(void);   /* 6: + pdae_wino_*; 5: + pdae_subsample2 / pdae_zero_insert2; 4: + pdae_conv_wprep_job / _group (3: + pdae_conv_stats_* / pdae_gn_coef_from_conv_stats; 2: saturation counter, row-coefficient samplers, fused attention, RCCL) */
+/* ABI history.  9 (round 5): - pdae_wino_* (the gated 2-D Winograd probe left the library: tools/probes/r04_winograd/); + pdae_set_knob / pdae_get_knob
+ *   (the library no longer reads its environment per call); + pdae_conv_gn_input_arm / pdae_conv2d_wgrad_gn_ok (weight gradient that recomputes a fused
+ *   GroupNorm input); + pdae_conv_gnbwd_bytes / pdae_conv_gnbwd_arm / pdae_gn_bwd_parts_arm (GroupNorm-backward sums from the data
+ *   gradient's epilogue); prepared 3x3 weights are TAGGED with their form and a launch that expects the other form fails with PDAE_EINVAL; the
+ *   prepared copy of a direct-form 3x3 convolution shrinks back to 18 k-halves per 32 channels (24 only in the Winograd form) and a fused-skip
+ *   copy to 2 -- cached copies written by ABI 7 / 8 must be re-prepared.
+ * 8 (round 4): + pdae_conv3x3_form, PDAE_MATH_DIRECT; the Winograd F(2,3)-along-x layout of prepared 3x3 weights (12 transform taps = 24 k-halves per 32
+ *   channels; ABI 7 sized EVERY 3x3 copy for it: +33 % over ABI 6) -- the internal job field `transposed` of pdae_wprep_job carries bit 8
+ *   (PDAE_WPREP_FORM_X) for that layout.  7: the same layout behind PDAE_W1 without the query.
+ * 6: + pdae_wino_* (removed in 9); 5: + pdae_subsample2 / pdae_zero_insert2; 4: + pdae_conv_wprep_job / _group; 3: + pdae_conv_stats_* /
+ *   pdae_gn_coef_from_conv_stats; 2: saturation counter, row-coefficient samplers, fused attention, RCCL. */
+int pdae_abi_version(void);
+
+/* Tuning / A-B switches (PDAE_W1, PDAE_W1_EFF, PDAE_P3R, PDAE_P3R_MIN, PDAE_P3R_EFF, PDAE_EDGE, PDAE_P3_TH, PDAE_SPLIT_STATS,
+ * PDAE_W3_STAGGER, PDAE_Y_STAGGER, PDAE_C1_SLAB, PDAE_C1_BF16, PDAE_NO_SKINNY, PDAE_C1_PIPE).  A knob's value is pdae_set_knob() > the environment variable of
+ * the same name, read ONCE at the knob's first use > the default; the library never re-reads its environment.  Unknown name: PDAE_EINVAL.
+ * Changing PDAE_W1 between pdae_conv_wprep and the launch that takes the copy makes that launch fail (form tag), it does not corrupt results. */
+int pdae_set_knob(const char* name, int value);
+int pdae_get_knob(const char* name, int* value);
 
 /* ---- convolution (F.conv2d / conv1d k=1: module.py:242,265,276,412,420; unet.py:62,174; encoder/ffhq.py:12-30) */
 typedef struct pdae_conv_desc {
@@ -101,7 +119,7 @@ int pdae_conv_skip_wprep(const pdae_conv_desc* d, const pdae_conv_desc* ds, cons
  * part of the ABI (48 bytes). */
 typedef struct pdae_wprep_job {
   const float* w; void* wp;          /* fp32 weights, prepared copy */
-  int32_t Nout, C, NT, transposed;   /* GEMM N, GEMM K channels, 32-channel tiles, data-gradient form */
+  int32_t Nout, C, NT, transposed;   /* GEMM N, GEMM K channels, 32-channel tiles, bit 0: data-gradient form, bit 3 (8): Winograd-along-x layout (T = 12 / 2) */
   int32_t T, ns;                     /* taps of the 3x3 layout (9, 1 for fused skip chunks; 0 = the 1x1 layout), operand format (1..4) */
   float wscale; int32_t nblocks;     /* power-of-two weight scale (format 4), 256-thread blocks this job needs */
 } pdae_wprep_job;
@@ -111,14 +129,6 @@ int pdae_conv_wprep_group(const pdae_wprep_job* jobs_dev, const int32_t* first_b
 int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
                          const pdae_conv_desc* ds, const float* s0, const float* s1, const void* wps, const float* bias_s, float* y,
                          pdae_stream_t stream);
-/* Winograd F(2x2, 3x3) forward convolution for WEIGHT-CONSTANT 3x3 / stride-1 / pad-1 layers in the f16x3 arithmetic (math 4): 16 instead of 36
- * products per 2 x 2 outputs (F.conv2d of module.py:242,265, unet.py:62,174 where the weights do not change between launches: the frozen trunk
- * and eps branch of ShiftUNet, every convolution of a sampling pass).  pdae_wino_wprep_bytes: size of the transformed weights
- * U = G g G^T (two fp16 planes in MFMA-fragment order), or 0 when d is not eligible (single source, C0 % 16 == 0, Ho, Wo % 16 == 0,
- * Cout % 64 == 0); pdae_wino_wprep writes them from w [Cout][3][3][Cin]; pdae_wino_fwd: y[N,Ho,Wo,Cout] = conv(x) + bias. */
-size_t pdae_wino_wprep_bytes(const pdae_conv_desc* d);
-int pdae_wino_wprep(const pdae_conv_desc* d, const float* w, void* wp, pdae_stream_t stream);
-int pdae_wino_fwd(const pdae_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, pdae_stream_t stream);
 /* GroupNorm statistics of a convolution's OUTPUT, produced by the convolution while it stores the tensor -- the GroupNorm that follows
  * (module.py:241,257: in_layers / out_layers norm of the next stage) then needs no pass over the tensor at all:
  *   bytes = pdae_conv_stats_bytes(d, ds, &tpi)   size of the partial-sum buffer, 0 when the forward convolution of d (with the fused skip
@@ -142,11 +152,35 @@ int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, 
  * two-fp16-plane format too, with dy scaled by the power of two that puts its abs-max into [1024, 2048) (undone exactly in the epilogue);
  * NULL: the exact three-plane bf16 split (range-free). */
 int pdae_amax(const float* x, size_t n, float* out, pdae_stream_t stream);
+/* GroupNorm-backward sums from the data gradient that PRODUCES dA (ABI 9; conv3x3y.hip, GB instantiation).  The backward of
+ * y = silu(a[n,c] (x - mu[n,c]) + b[n,c]) needs two sums per (n, c) over the pixels: S0 = sum dv, S1 = sum dv (x - mu), dv = dA silu'(.) --
+ * pdae_gn_bwd takes them with a reduction pass over (x, dA), 2 of its 5 tensor passes.  When dA is the output of a 3x3 data gradient in the
+ * Winograd-along-x form, that launch can leave them from its epilogue instead (x enters as its epilogue operand):
+ *   bytes = pdae_conv_gnbwd_bytes(d, flags, &tiles)   size of part[N][tiles][C0 + C1][2] for the data gradient of d (d->C0 / C1 = the channel split of
+ *                                                     the GroupNorm's two-source input; flags: PDAE_WPREP_F16_GRAD when the launch brings dy_amax);
+ *                                                     0 = not available (not the Winograd form, d->up, sources not whole 32-channel runs, > 64 tiles
+ *                                                     of 16 x 16 pixels per image)
+ *   pdae_conv_gnbwd_arm(x0, C0, x1, C1, coef, 1, part) one-shot: the NEXT pdae_conv2d_dgrad on this host thread (whole input, no accumulate) also
+ *                                                     writes part; coef = [mu | a | b] of the GroupNorm's forward; SiLU, no dropout (act must be 1)
+ *   pdae_gn_bwd_parts_arm(part, tiles)                one-shot: the NEXT pdae_gn_bwd (mode 0, act 1, drop_p 0) skips its reduction and finalizes from part
+ * In a pdae_op record: CONV_DGRAD p[5..8] = x0, x1, coef, part, i[18..20] = C0, C1, act;  GN_BWD p[19] = part, i[13] = tiles. */
+size_t pdae_conv_gnbwd_bytes(const pdae_conv_desc* d, int flags, int32_t* tiles_per_image);
+int pdae_conv_gnbwd_arm(const float* x0, int C0, const float* x1, int C1, const float* coef, int act, float* part);
+int pdae_gn_bwd_parts_arm(const float* part, int tiles_per_image);
 /* dw[Cout][KH][KW][Cin] (+)= sum over pixels; split-K over pixels through the workspace, reduced in fixed order.
  * db (optional) [Cout] (+)= column sums of dy = the bias gradient; the 3x3 kernel takes them from its own dY staging (no second read of dy). */
 size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d);
 int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, float* db, int accumulate, void* ws,
                       size_t ws_bytes, const float* dy_amax, pdae_stream_t stream);
+/* Weight gradient of a convolution whose FORWARD applied GroupNorm / AdaGN (+ SiLU) to its raw two-source input inside the staging
+ * (pdae_conv2d_fwd_gn; module.py:241-242: in_layers GroupNorm -> SiLU -> conv): that forward never wrote the activated tensor, so the weight
+ * gradient recomputes act(a[n,c] * (x - mu[n,c]) + b[n,c]) the same way while it stages X (ABI 9).  pdae_conv_gn_input_arm(coef, act) is a one-shot
+ * request like pdae_conv_stats_arm: the NEXT pdae_conv2d_wgrad on this host thread takes it on entry and then reads (x0, x1) as the RAW sources;
+ * coef = [mu | a | b], each [N][C0 + C1], as pdae_gn_coef / pdae_gn_stats_coef / pdae_gn_coef_from_conv_stats leave them; act 1 = SiLU, 0 = none.
+ * Eligible (pdae_conv2d_wgrad_gn_ok == 1): 3x3 / stride 1 / pad 1, C0 and C1 multiples of 32, Wo % 16 == 0, Ho % 8 == 0, Cout % 4 == 0, math >= 1;
+ * anything else fails with PDAE_EINVAL (there is no silent fallback: the materialised form is the caller's to choose). */
+int pdae_conv2d_wgrad_gn_ok(const pdae_conv_desc* d);
+int pdae_conv_gn_input_arm(const float* coef, int act);
 
 /* ---- strided-batched GEMM (F.linear, torch.einsum of module.py:450-457 / 479-488, and their backward)
  * C[b][m][n] (+)= alpha * sum_k opA[b][m][k] * opB[b][k][n] + bias[n];  opA = A[m*lda+k] (transA=0) | A[k*lda+m] (1);

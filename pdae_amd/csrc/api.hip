@@ -9,7 +9,6 @@
 #include "igemm.h"
 #include "kernels.h"
 #include "conv3x3p.h"
-#include "winograd.h"
 
 static thread_local char g_err[512] = "";
 
@@ -21,7 +20,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 8; }
+extern "C" int pdae_abi_version(void) { return 9; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -29,6 +28,45 @@ unsigned int* pdae_sat_counter() { return g_sat; }
 extern "C" int pdae_set_saturation_counter(unsigned int* counter) { g_sat = counter; return PDAE_OK; }
 
 static inline hipStream_t S(pdae_stream_t s) { return (hipStream_t)s; }
+
+// ---- knob registry (common.h): the only getenv of the library
+#include <stdlib.h>
+#include <mutex>
+static const struct { const char* name; int def; } g_knob_def[KNOB_COUNT] = {
+    {"PDAE_W1", 1}, {"PDAE_W1_EFF", 85}, {"PDAE_P3R", 1}, {"PDAE_P3R_MIN", 512}, {"PDAE_P3R_EFF", 85}, {"PDAE_EDGE", 1}, {"PDAE_P3_TH", 0},
+    {"PDAE_SPLIT_STATS", 1}, {"PDAE_W3_STAGGER", 0}, {"PDAE_Y_STAGGER", 0}, {"PDAE_C1_SLAB", 1}, {"PDAE_C1_BF16", 0}, {"PDAE_NO_SKINNY", 0},
+    {"PDAE_C1_PIPE", 1}};
+static int g_knob_val[KNOB_COUNT];
+static bool g_knob_set[KNOB_COUNT];
+static std::mutex g_knob_mu;
+int pdae_knob(int id) {
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  if (!g_knob_set[id]) {
+    const char* e = getenv(g_knob_def[id].name);
+    g_knob_val[id] = (e && *e) ? atoi(e) : g_knob_def[id].def;
+    g_knob_set[id] = true;
+  }
+  return g_knob_val[id];
+}
+static int knob_id(const char* name) {
+  if (name)
+    for (int k = 0; k < KNOB_COUNT; ++k)
+      if (!strcmp(name, g_knob_def[k].name)) return k;
+  return -1;
+}
+extern "C" int pdae_set_knob(const char* name, int value) {
+  const int id = knob_id(name);
+  PDAE_CHECK_ARG(id >= 0, "set_knob: unknown knob '%s'", name ? name : "(null)");
+  std::lock_guard<std::mutex> lk(g_knob_mu);
+  g_knob_val[id] = value; g_knob_set[id] = true;
+  return PDAE_OK;
+}
+extern "C" int pdae_get_knob(const char* name, int* value) {
+  const int id = knob_id(name);
+  PDAE_CHECK_ARG(id >= 0 && value, "get_knob: unknown knob '%s'", name ? name : "(null)");
+  *value = pdae_knob(id);
+  return PDAE_OK;
+}
 
 static int check_desc(const pdae_conv_desc* d) {
   PDAE_CHECK_ARG(d && d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad dims");
@@ -84,11 +122,12 @@ extern "C" size_t pdae_conv_wprep_bytes(const pdae_conv_desc* d, int flags) {
   const int transposed = flags & PDAE_WPREP_TRANSPOSED;
   if (!d || check_desc(d)) return 0;
   if (flags & PDAE_WPREP_GN)
-    return (!transposed && gn_patch_ok(d, !(flags & PDAE_WPREP_FORCE))) ? conv3x3p_wprep_bytes(d->math, d->Cout, d->C0 + d->C1, d->Ho, d->Wo, d->N) : 0;
+    return (!transposed && gn_patch_ok(d, !(flags & PDAE_WPREP_FORCE))) ? conv3x3p_wprep_bytes(d->math | d_dflag, d->Cout, d->C0 + d->C1, d->Ho, d->Wo, d->N) : 0;
   const int kind = fast_kind(d, transposed, !(flags & PDAE_WPREP_FORCE));
   const int Hl = d->up ? 2 * d->Hi : d->Hi, Wl = d->up ? 2 * d->Wi : d->Wi, Cin = d->C0 + d->C1;
   if (kind == 3)
-    return transposed ? conv3x3p_wprep_bytes(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), Cin, d->Cout, Hl, Wl, d->N) : conv3x3p_wprep_bytes(d->math, d->Cout, d->C0, d->Ho, d->Wo, d->N);
+    return transposed ? conv3x3p_wprep_bytes(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), Cin, d->Cout, Hl, Wl, d->N)
+                      : conv3x3p_wprep_bytes(d->math | d_dflag, d->Cout, d->C0, d->Ho, d->Wo, d->N);
   if (kind == 1) {
     const long long M = (long long)d->N * d->Ho * d->Wo;
     return transposed ? conv1x1_wprep_bytes(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), Cin, d->Cout, M) : conv1x1_wprep_bytes(d->math, d->Cout, Cin, M);
@@ -162,8 +201,8 @@ extern "C" int pdae_conv_wprep_group(const pdae_wprep_job* jobs_dev, const int32
   return wprep_group_launch(reinterpret_cast<const WprepJob*>(jobs_dev), first_block_dev, njobs, total_blocks, S(stream));
 }
 
-// PDAE_EDGE=0: the 3-channel edge layers stay on the fp32 FMA head kernels / the generic implicit GEMM (A/B aid; read per call)
-static bool edge_on() { const char* e = getenv("PDAE_EDGE"); return !e || atoi(e) != 0; }
+// PDAE_EDGE=0: the 3-channel edge layers stay on the fp32 FMA head kernels / the generic implicit GEMM (A/B aid)
+static bool edge_on() { return pdae_knob(KNOB_EDGE) != 0; }
 
 extern "C" int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, const float* w, const void* wp, const float* bias,
                                const float* res, int res_mode, float* y, int tile, pdae_stream_t stream) {
@@ -276,30 +315,6 @@ extern "C" size_t pdae_conv_stats_bytes(const pdae_conv_desc* d, const pdae_conv
   if (tiles_per_image) *tiles_per_image = b ? tpi : 0;
   return b;
 }
-// ---- Winograd F(2x2, 3x3) forward convolution of weight-constant layers (winograd.hip)
-static bool wino_desc_ok(const pdae_conv_desc* d) {
-  return wino_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->up, d->C0, d->C1, d->Ho, d->Wo, d->N, d->Cout);
-}
-extern "C" size_t pdae_wino_wprep_bytes(const pdae_conv_desc* d) {
-  PDAE_DESC_NORM(d)
-  if (!d || check_desc(d) || !wino_desc_ok(d)) return 0;
-  return wino_wprep_bytes(d->Cout, d->C0);
-}
-extern "C" int pdae_wino_wprep(const pdae_conv_desc* d, const float* w, void* wp, pdae_stream_t stream) {
-  PDAE_DESC_NORM(d)
-  if (int e = check_desc(d)) return e;
-  PDAE_CHECK_ARG(w && wp, "wino_wprep: null pointer");
-  PDAE_CHECK_ARG(wino_desc_ok(d), "wino_wprep: convolution not eligible (3x3 / stride 1 / pad 1, math f16x3, one source, C %% 16 == 0, H, W %% 16 == 0, Cout %% 64 == 0)");
-  return wino_wprep(w, d->Cout, d->C0, (unsigned short*)wp, S(stream));
-}
-extern "C" int pdae_wino_fwd(const pdae_conv_desc* d, const float* x, const void* wp, const float* bias, float* y, pdae_stream_t stream) {
-  PDAE_DESC_NORM(d)
-  if (int e = check_desc(d)) return e;
-  PDAE_CHECK_ARG(x && wp && y, "wino_fwd: null pointer");
-  PDAE_CHECK_ARG(wino_desc_ok(d), "wino_fwd: convolution not eligible (pdae_wino_wprep_bytes returned 0)");
-  return wino_fwd(x, d->N, d->Ho, d->Wo, d->C0, (const unsigned short*)wp, d->Cout, bias, y, S(stream));
-}
-
 extern "C" int pdae_conv_stats_arm(float* part) {
   conv3x3p_arm_stats(part);
   return PDAE_OK;
@@ -313,10 +328,39 @@ extern "C" int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G
   return k_gn_coef_from_conv_stats(N, HW, C0, C1, G, eps, part0, tpi0, C1 ? part1 : nullptr, tpi1, gamma, beta, ss, zss, mean, rstd, coef, S(stream));
 }
 
+// ---- GroupNorm-backward sums from the data gradient that produces dA (conv3x3y.hip, GB instantiation): the reduction pass of pdae_gn_bwd over
+// (x, dA) -- 2 of its 5 tensor passes -- is replaced by an epilogue of the launch that writes dA.
+extern "C" size_t pdae_conv_gnbwd_bytes(const pdae_conv_desc* d, int flags, int32_t* tiles_per_image) {
+  PDAE_DESC_NORM(d)
+  (void)d_dflag;
+  if (tiles_per_image) *tiles_per_image = 0;
+  if (!d || check_desc(d) || d->up || d->stride != 1 || fast_kind(d, 1, false) != 3) return 0;
+  const int t = conv3x3p_gnb_tiles(bwd_math(d, flags & PDAE_WPREP_F16_GRAD), d->Cout, d->Hi, d->Wi, d->N, d->C0 + d->C1, d->C0, d->C1);
+  if (tiles_per_image) *tiles_per_image = t;
+  return (size_t)d->N * t * (d->C0 + d->C1) * 2 * sizeof(float);
+}
+static thread_local PatchGnb g_gnb_arm = {nullptr, nullptr, 0, 0, nullptr, nullptr};
+extern "C" int pdae_conv_gnbwd_arm(const float* x0, int C0, const float* x1, int C1, const float* coef, int act, float* part) {
+  PDAE_CHECK_ARG(x0 && coef && part && C0 > 0 && C1 >= 0 && (C1 == 0 || x1), "conv_gnbwd_arm: null pointer");
+  PDAE_CHECK_ARG(act == 1, "conv_gnbwd_arm: only the SiLU form (act = 1, no dropout) is built");
+  g_gnb_arm = PatchGnb{x0, C1 ? x1 : nullptr, C0, C1, coef, part};
+  return PDAE_OK;
+}
+static bool take_gnb(PatchGnb* out) { *out = g_gnb_arm; g_gnb_arm.part = nullptr; return out->part != nullptr; }
+static thread_local const float* g_gnparts = nullptr;
+static thread_local int g_gnparts_tiles = 0;
+extern "C" int pdae_gn_bwd_parts_arm(const float* part, int tiles_per_image) {
+  PDAE_CHECK_ARG(part && tiles_per_image > 0 && tiles_per_image <= 64, "gn_bwd_parts_arm: bad arguments (1..64 tiles per image)");
+  g_gnparts = part; g_gnparts_tiles = tiles_per_image;
+  return PDAE_OK;
+}
+
 extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const float* w, const void* wp_t, float* dx, int ci_off, int ci_cnt,
                                  int accumulate, int tile, const float* dy_amax, pdae_stream_t stream) {
   PDAE_DESC_NORM(d)
   conv3x3p_take_stats();                  // output statistics belong to forward convolutions only
+  PatchGnb gnb;
+  const bool want_gnb = take_gnb(&gnb);   // consumed here whatever happens below
   if (int e = check_desc(d)) return e;
   const int Cin = d->C0 + d->C1;
   PDAE_CHECK_ARG(dy && w && dx && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= Cin, "conv2d_dgrad: bad arguments");
@@ -327,9 +371,12 @@ extern "C" int pdae_conv2d_dgrad(const pdae_conv_desc* d, const float* dy, const
   const int kind = wp_t ? fast_kind(d, 1, false) : 0;
   PDAE_CHECK_ARG(!wp_t || (tile == 0 && ((kind == 3 && ci_off == 0 && ci_cnt == Cin) || (kind == 1 && (ci_off & 31) == 0 && (ci_cnt & 3) == 0))),
                  "conv2d_dgrad: wp_t given but the convolution / channel range is not eligible for a prepared-weight kernel");
+  PDAE_CHECK_ARG(!want_gnb || (kind == 3 && !d->up && gnb.C0 == d->C0 && gnb.C1 == d->C1),
+                 "conv2d_dgrad: GroupNorm-backward sums were armed (pdae_conv_gnbwd_arm) but this data gradient cannot leave them (pdae_conv_gnbwd_bytes == 0, "
+                 "or the armed channel split differs from the descriptor's C0 / C1)");
   if (kind == 3)
     return conv3x3p_launch(bwd_math(d, dy_amax != nullptr), dy, d->N, d->Ho, d->Wo, d->Cout, Hl, Wl, 0, (const unsigned short*)wp_t, Cin, dx, nullptr,
-                           nullptr, 0, accumulate, S(stream), nullptr, 0, nullptr, 0, nullptr, dy_amax);
+                           nullptr, 0, accumulate, S(stream), nullptr, 0, nullptr, 0, nullptr, dy_amax, nullptr, want_gnb ? &gnb : nullptr);
   if (kind == 1)
     return conv1x1_launch(bwd_math(d, dy_amax != nullptr), dy, d->Cout, nullptr, 0, (long long)d->N * d->Ho * d->Wo, (const unsigned short*)wp_t, Cin,
                           ci_off, ci_cnt, dx, nullptr, nullptr, 0, d->Ho, d->Wo, accumulate, S(stream), dy_amax);
@@ -360,6 +407,26 @@ static void wgrad_plan(const pdae_conv_desc* d, int& tile, int& splits, int& kch
   splits = cdiv(K, kchunk);
 }
 
+// ---- weight gradient of a convolution whose forward applied GroupNorm (+ SiLU) to its raw input inside the staging (pdae_conv2d_fwd_gn):
+// the activated tensor was never written, so the weight gradient recomputes it the same way (conv3x3w.hip, GN instantiation).
+static bool wgrad_gn_ok(const pdae_conv_desc* d) {
+  return conv3x3w_gn_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C0, d->C1, d->Ho, d->Wo, d->N, d->Cout);
+}
+extern "C" int pdae_conv2d_wgrad_gn_ok(const pdae_conv_desc* d) {
+  PDAE_DESC_NORM(d)
+  (void)d_dflag;
+  return (d && !check_desc(d) && wgrad_gn_ok(d)) ? 1 : 0;
+}
+// One-shot request, as pdae_conv_stats_arm: the next pdae_conv2d_wgrad on this host thread TAKES it on entry (whatever happens afterwards).
+static thread_local const float* g_wgn_coef = nullptr;
+static thread_local int g_wgn_act = 0;
+extern "C" int pdae_conv_gn_input_arm(const float* coef, int act) {
+  PDAE_CHECK_ARG(coef && (act == 0 || act == 1), "conv_gn_input_arm: bad arguments");
+  g_wgn_coef = coef; g_wgn_act = act;
+  return PDAE_OK;
+}
+static const float* take_wgn(int* act) { const float* c = g_wgn_coef; *act = g_wgn_act; g_wgn_coef = nullptr; return c; }
+
 // workspace of the weight gradient proper (slabs / partials), 256-byte aligned; the bias-gradient column-sum scratch follows it
 static size_t wgrad_path_bytes(const pdae_conv_desc* d) {
   size_t b;
@@ -376,6 +443,10 @@ static size_t wgrad_path_bytes(const pdae_conv_desc* d) {
       const size_t b1 = conv1x1w_workspace_bytes((long long)d->N * d->Ho * d->Wo, d->C0 + d->C1, d->Cout);
       if (b1 > b) b = b1;
     }
+    if (d->C1 && wgrad_gn_ok(d)) {                      // two-source 3x3: the launch may arrive with pdae_conv_gn_input_arm
+      const size_t b3 = conv3x3w_workspace_bytes(d->N, d->Ho, d->Wo, d->C0 + d->C1, d->Cout);
+      if (b3 > b) b = b3;
+    }
   }
   return (b + 255) & ~(size_t)255;
 }
@@ -388,10 +459,23 @@ extern "C" size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d) {
 extern "C" int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, float* db, int accumulate,
                                  void* ws, size_t ws_bytes, const float* dy_amax, pdae_stream_t stream) {
   PDAE_DESC_NORM(d)
+  int gn_act = 0;
+  const float* const gn_coef = take_wgn(&gn_act);        // consumed here: a failed call never leaves the request armed
   if (int e = check_desc(d)) return e;
   PDAE_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "conv2d_wgrad: null pointer");
   const size_t pb = wgrad_path_bytes(d);
   const long long Mpix = (long long)d->N * d->Ho * d->Wo;
+  if (gn_coef) {
+    PDAE_CHECK_ARG(wgrad_gn_ok(d), "conv2d_wgrad: a GroupNorm input was armed (pdae_conv_gn_input_arm) but pdae_conv2d_wgrad_gn_ok(d) == 0");
+    PDAE_CHECK_ARG(!db || (ws && ws_bytes >= pb + k_colsum_workspace_floats(Mpix, d->Cout) * sizeof(float)),
+                   "conv2d_wgrad: workspace too small for the bias gradient (%zu < pdae_conv2d_wgrad_workspace_bytes)", ws_bytes);
+    float* part = nullptr; int rows = 0;
+    if (int e = conv3x3w_launch(d->math, x0, d->N, d->Hi, d->Wi, d->C0 + d->C1, d->Ho, d->Wo, d->up, dy, d->Cout, dw, accumulate, (float*)ws,
+                                ws_bytes < pb ? ws_bytes : pb, S(stream), db ? &part : nullptr, db ? &rows : nullptr, dy_amax, db, d->C1 ? x1 : nullptr,
+                                d->C0, gn_coef, gn_act))
+      return e;
+    return (db && part) ? k_colsum(part, rows, d->Cout, db, accumulate, ws ? (float*)((char*)ws + pb) : nullptr, S(stream)) : PDAE_OK;
+  }
   PDAE_CHECK_ARG(!db || (ws && ws_bytes >= pb + k_colsum_workspace_floats(Mpix, d->Cout) * sizeof(float)),
                  "conv2d_wgrad: workspace too small for the bias gradient (%zu < pdae_conv2d_wgrad_workspace_bytes)", ws_bytes);
   float* cws = ws ? (float*)((char*)ws + pb) : nullptr;                 // column-sum scratch
@@ -498,11 +582,14 @@ extern "C" int pdae_gn_bwd(const float* x0, int C0, const float* x1, int C1, int
                            float drop_p, uint64_t seed, uint64_t offset, const float* add, float* dx0, int acc0, float* dx1, int acc1,
                            float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, void* ws, float* dx0_amax, uint32_t* ticket,
                            pdae_stream_t stream) {
+  const float* const parts = g_gnparts; const int parts_tiles = g_gnparts_tiles;      // one-shot (pdae_gn_bwd_parts_arm): consumed here
+  g_gnparts = nullptr; g_gnparts_tiles = 0;
   PDAE_CHECK_ARG(x0 && coef && rstd && gamma && beta && dA && ws && (C1 == 0 || x1), "gn_bwd: null pointer");
+  PDAE_CHECK_ARG(!parts || (mode == 0 && act == 1 && drop_p == 0.f && !ticket), "gn_bwd: externally computed sums need mode 0, SiLU, no dropout");
   PDAE_CHECK_ARG(mode >= 0 && mode <= 2 && (mode != 1 || ((H % 2) == 0 && (W % 2) == 0)), "gn_bwd: bad mode");
   PDAE_CHECK_ARG((!dss || ss) && (!dzss || zss) && (!dgamma || dbeta), "gn_bwd: gradient requested for an absent input");
   return k_gn_bwd(x0, C0, x1, C1, N, H, W, G, coef, rstd, gamma, beta, ss, zss, dA, act, mode, drop_p, seed, offset, add, dx0, acc0, dx1, acc1,
-                  dgamma, dbeta, acc_param, dss, dzss, (float*)ws, S(stream), dx0_amax, ticket);
+                  dgamma, dbeta, acc_param, dss, dzss, (float*)ws, S(stream), dx0_amax, ticket, parts, parts_tiles);
 }
 
 // ---- elementwise
@@ -663,8 +750,11 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
   pdae_conv_desc d;
   switch (o.kind) {
     case PDAE_OP_CONV_FWD: desc_from(i, d); if (p[19]) conv3x3p_arm_stats((float*)p[19]); return pdae_conv2d_fwd(&d, F(0), F(1), F(2), p[6], F(3), F(4), (int)i[14], FM(5), (int)i[15], st);
-    case PDAE_OP_CONV_DGRAD: desc_from(i, d); return pdae_conv2d_dgrad(&d, F(0), F(1), p[3], FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], F(4), st);
-    case PDAE_OP_CONV_WGRAD: desc_from(i, d); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), FM(5), (int)i[14], p[4], (size_t)i[15], F(6), st);
+    case PDAE_OP_CONV_DGRAD:
+      desc_from(i, d);
+      if (p[8]) { if (int e = pdae_conv_gnbwd_arm(F(5), (int)i[18], F(6), (int)i[19], F(7), (int)i[20], FM(8))) return e; }
+      return pdae_conv2d_dgrad(&d, F(0), F(1), p[3], FM(2), (int)i[14], (int)i[15], (int)i[16], (int)i[17], F(4), st);
+    case PDAE_OP_CONV_WGRAD: desc_from(i, d); if (p[7]) pdae_conv_gn_input_arm(F(7), (int)i[16]); return pdae_conv2d_wgrad(&d, F(0), F(1), F(2), FM(3), FM(5), (int)i[14], p[4], (size_t)i[15], F(6), st);
     case PDAE_OP_GEMM:
       return pdae_gemm((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), i[5], i[6], i[7], F(1), i[8], i[9], i[10], FM(2),
                        i[11], i[12], i[13], (int)i[14], (int)i[15], F(3), (int)i[16], st);
@@ -680,6 +770,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
       return pdae_gn_apply(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], F(2), (int)i[5], (int)i[6], FM(3), FM(4), (float)f[0],
                            (uint64_t)i[7], (uint64_t)i[8], st);
     case PDAE_OP_GN_BWD:
+      if (p[19]) { if (int e = pdae_gn_bwd_parts_arm(F(19), (int)i[13])) return e; }
       return pdae_gn_bwd(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], F(2), F(3), F(4), F(5), F(6), F(7), F(8),
                          (int)i[6], (int)i[7], (float)f[0], (uint64_t)i[11], (uint64_t)i[12], F(9), FM(10), (int)i[8], FM(11), (int)i[9], FM(12),
                          FM(13), (int)i[10], FM(14), FM(15), p[16], FM(17), (uint32_t*)p[18], st);
@@ -759,6 +850,7 @@ extern "C" int pdae_run_ops(const pdae_op* ops, int n, pdae_stream_t stream) {
     int e = run_one(ops[k], stream);
     if (e != PDAE_OK) {
       conv3x3p_take_stats();                // a statistics request armed for an op that failed before its entry point must not reach a later launch
+      { int a_; take_wgn(&a_); PatchGnb g_; take_gnb(&g_); g_gnparts = nullptr; }
       char msg[400];
       snprintf(msg, sizeof(msg), "%s", g_err);
       pdae_set_error("op %d (kind %d): %s", k, ops[k].kind, msg);

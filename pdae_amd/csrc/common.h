@@ -27,7 +27,36 @@ static inline int pdae_launch_status(const char* what) {
   return PDAE_OK;
 }
 
+// Timing-probe macros compile pieces of a kernel out (WRONG RESULTS by design).  They are only legal in the side builds of tools/probe_build.py,
+// which defines PDAE_PROBE_BUILD: a product build that picks one up by accident does not compile.
+#if (defined(PDAE_AT_PROBE_NNNOLOAD) || defined(PDAE_AT_PROBE_NNNOMMA) || defined(PDAE_AT_PROBE_NONN) || defined(PDAE_AT_PROBE_NONT) || defined(PDAE_AT_PROBE_NOSCHED) || defined(PDAE_PROBE_NOA) || defined(PDAE_PROBE_NOB) || defined(PDAE_PROBE_NOSTAGE) || defined(PDAE_R_PROBE_24U) || defined(PDAE_R_PROBE_NOA) || defined(PDAE_R_PROBE_NOB) || defined(PDAE_R_PROBE_NOCONV) || defined(PDAE_R_PROBE_NODRAIN) || defined(PDAE_R_PROBE_NOGLOAD) || defined(PDAE_W3_PROBE_6TAPS) || defined(PDAE_W3_PROBE_NOLOAD) || defined(PDAE_W3_PROBE_NOMMA) || defined(PDAE_W3_PROBE_NOSTAGE) || defined(PDAE_Y_PROBE_NOA) || defined(PDAE_Y_PROBE_NOB) || defined(PDAE_Y_PROBE_NOCONV) || defined(PDAE_Y_PROBE_NOEPI) || defined(PDAE_Y_PROBE_NOGLOAD)) && !defined(PDAE_PROBE_BUILD)
+#error "PDAE_*_PROBE_* macros give wrong results by design: build probes with tools/probe_build.py (-DPDAE_PROBE_BUILD), never the product library"
+#endif
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- tuning / A-B switches of the library (api.hip).  ONE registry: a knob's value is pdae_set_knob() > its environment variable, read ONCE at the
+// knob's first use > its default.  Nothing re-reads the environment per call: a process cannot change the routing between preparing a
+// convolution's weights and launching it by editing its environment (tests switch through pdae_set_knob; prepared buffers are additionally
+// tagged with their form, conv3x3p.hip).  The names are the environment variables of DESIGN.md section 10.
+enum PdaeKnob {
+  KNOB_W1 = 0,        // PDAE_W1: Winograd F(2,3)-along-x form of the 3x3 convolutions: 0 off, 1 chip-filling layers (default), 2 every eligible shape
+  KNOB_W1_EFF,        // PDAE_W1_EFF: minimum % of the CUs busy in the last round of tiles for that form (85)
+  KNOB_P3R,           // PDAE_P3R: conv3x3r (direct persistent form): 0 never, 1 by fill heuristic (default), 2 every eligible shape
+  KNOB_P3R_MIN,       // PDAE_P3R_MIN (512)
+  KNOB_P3R_EFF,       // PDAE_P3R_EFF (85)
+  KNOB_EDGE,          // PDAE_EDGE: 3-channel edge layers on the MFMA edge kernels (1)
+  KNOB_P3_TH,         // PDAE_P3_TH: tile height of conv3x3p (0 = default 8)
+  KNOB_SPLIT_STATS,   // PDAE_SPLIT_STATS: split-K 3x3 launches leave GroupNorm partial statistics (1)
+  KNOB_W3_STAGGER,    // PDAE_W3_STAGGER (0)
+  KNOB_Y_STAGGER,     // PDAE_Y_STAGGER (0)
+  KNOB_C1_SLAB,       // PDAE_C1_SLAB: slab-traffic term of the conv1x1 split-K plan (1)
+  KNOB_C1_BF16,       // PDAE_C1_BF16: three-plane bf16 format in the 1x1 kernels also in mode 4 (0)
+  KNOB_NO_SKINNY,     // PDAE_NO_SKINNY: M <= 32 linears on the generic GEMM (0)
+  KNOB_C1_PIPE,       // PDAE_C1_PIPE: double-buffered staging of conv1x1 (1)
+  KNOB_COUNT
+};
+int pdae_knob(int id);
 
 // fp16 operand split of (e0 * sc, e1 * sc), sc a power of two: packed head plane (round-to-nearest fp16) and packed residual plane (fp16 of
 // e * sc - head, which is exact in fp32).  v_fma_mixlo/mixhi_f16 fuse scale, conversion and packing, and take the fp16 head straight back

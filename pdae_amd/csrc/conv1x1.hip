@@ -332,7 +332,7 @@ static PointPlan point_plan(long long M, int C, int Nout) {
   q.tiles_m = (int)((M + 127) / 128); q.tiles_n = (Nout + 127) / 128;
   const long long base = (long long)q.tiles_m * q.tiles_n;
   const int nstage = (C + 63) >> 6;                      // 64-channel stages
-  static const double slab_w = []() { const char* e = getenv("PDAE_C1_SLAB"); return e ? atof(e) : 1.0; }();      // 0: the round-2 plan (A/B aid)
+  const double slab_w = (double)pdae_knob(KNOB_C1_SLAB);      // 0: the round-2 plan (A/B aid)
   long long best = -1; int best_s = 1;
   for (int sN = 1; sN <= nstage && sN <= 16; ++sN) {     // minimise rounds(grid) x stages-per-block (+1 for prologue / epilogue)
     const int per = (nstage + sN - 1) / sN, sp = (nstage + per - 1) / per;
@@ -365,8 +365,7 @@ static size_t point_prep_bytes(int math, int Nrows, int C) {
 
 // PDAE_C1_BF16=1 (tuning aid): the 1x1 kernels run the three-plane bf16 split also in mode 4
 static int c1_math(int math) {
-  static const bool off = getenv("PDAE_C1_BF16") != nullptr;
-  return (math == 4 && off) ? 3 : math;
+  return (math == 4 && pdae_knob(KNOB_C1_BF16)) ? 3 : math;
 }
 
 // prepared weights of all Nrows GEMM-N rows + split-K slabs sized for ANY launch on a 32-aligned sub-range of the rows

@@ -74,6 +74,11 @@ struct PatchParams {
   // for each of its eight channel quads to stat_part[image][stat_tpi wave-tiles][Nout / 4] as float2; pdae_gn_coef_from_conv_stats sums the
   // wave-tiles in fp64.  The next GroupNorm then needs no pass over this tensor (it was 9 % of a sampling step).
   float* stat_part; int stat_tpi;
+  // GroupNorm-BACKWARD sums of a data gradient's output dA (conv3x3y, GB instantiation; PatchGnb in igemm.h): the launch loads the GroupNorm's raw
+  // input x as its epilogue operand, forms dv = dA * silu'(a (x - mu) + b) for every value it stores and leaves (sum dv, sum dv (x - mu)) per channel
+  // and 16 x 16 tile in gb_part[image][gb_tpi][Nout][2] -- the layout gn_bwd_reduce_kernel writes, so gn_bwd_finalize / _apply run unchanged and the
+  // separate reduction pass over (x, dA) (2 of the 5 tensor passes of a GroupNorm backward) does not exist.
+  const float* gb_x0; const float* gb_x1; int gb_C0; const float* gb_coef; float* gb_part; int gb_tpi;
 };
 
 // 2^(10 - floor(log2(amax))): amax * scale in [1024, 2048)  (amax == 0 or non-finite: 1)
@@ -191,7 +196,7 @@ void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cma
 void conv1x1_wprep_job(int math, const float* w, int Nrows, int C, int transposed, unsigned short* wp, WprepJob* j);
 int wprep_group_launch(const WprepJob* jobs_dev, const int* first_block_dev, int njobs, int total_blocks, hipStream_t s);
 
-// conv3x3x.hip: Winograd F(2, 3) along x (two thirds of the matrix work) on the large layers; conv3x3p_form = 1 when a convolution with these
+// conv3x3y.hip: Winograd F(2, 3) along x (two thirds of the matrix work) on the large layers; conv3x3p_form = 1 when a convolution with these
 // launch-side dimensions is prepared AND launched in that form
 bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout);
 int conv3x3x_launch(int math, const PatchParams& P, hipStream_t s);

@@ -466,9 +466,7 @@ template <int NS, int PTH, bool W8, bool GN = false> static int launch_ns(const 
 }
 
 static int patch_th() {                        // PDAE_P3_TH = 8 | 16 overrides the tile height (tuning aid)
-  static int th = -1;
-  if (th < 0) { const char* e = getenv("PDAE_P3_TH"); th = e ? atoi(e) : 0; }
-  return th;
+  return pdae_knob(KNOB_P3_TH);
 }
 
 // launch plan of one convolution: tile geometry and split-K factor, a pure function of the shape (shared by the workspace
@@ -522,12 +520,36 @@ static size_t slab_bytes(int C, int H, int W, int N, int Nout) {
   return q.splits > 1 ? (size_t)q.splits * N * H * W * Nout * sizeof(float) : 0;
 }
 
-// (24 k-halves per chunk: room for the 12 transform taps of the Winograd-along-x layout as well as for the 9 direct ones -- the buffer size does
-// not depend on which form a launch takes)
-static size_t prep_bytes(int math, int Nout, int C) {
+// k-halves per 32-channel chunk: 2 x 12 transform taps in the Winograd-along-x layout, 2 x 9 in the direct one (ABI 7 / 8 reserved 24 for every
+// copy: +33 % on every direct-form layer and data-gradient copy).  `form` = conv3x3p_form of the same arguments: size query, preparation and
+// launch all derive it from the shape, so they agree on where the split-K slabs start (a Winograd-form launch never has slabs).
+static size_t prep_bytes(int math, int Nout, int C, int form) {
   const int NS = math < 1 ? 1 : (math == 4 ? 2 : (math > 3 ? 3 : math));       // planes: math 4 = two fp16 planes
-  const size_t b = (size_t)NS * (C >> 5) * 24 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short);
+  const size_t b = (size_t)NS * (C >> 5) * (form ? 24 : 18) * ((Nout + 31) / 32) * 512 * sizeof(unsigned short);
   return (b + 255) & ~(size_t)255;
+}
+
+// ---- form tags of prepared 3x3 weights.  A prepared copy is written either in the direct layout (9 taps) or in the Winograd-along-x layout (12
+// transform taps); a launch in the other form would read garbage and still return 0.  Every preparation (pdae_conv_wprep, or the description of
+// a job of the grouped launch) therefore records the layout it writes under the copy's address, and every launch that takes a copy checks it: a
+// mismatch -- PDAE_W1 changed through pdae_set_knob, or PDAE_MATH_DIRECT present on one side only -- fails with PDAE_EINVAL instead of computing
+// wrong numbers.  Host-side only (no device traffic, no synchronisation); copies of unknown provenance (never seen by this library instance) pass.
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_form_mu;
+static std::unordered_map<const void*, int> g_form_tag;      // wp -> 1 + form
+static void form_note(const void* wp, int form) {
+  std::lock_guard<std::mutex> lk(g_form_mu);
+  g_form_tag[wp] = 1 + form;
+}
+static int form_check(const void* wp, int form) {
+  std::lock_guard<std::mutex> lk(g_form_mu);
+  auto it = g_form_tag.find(wp);
+  if (it == g_form_tag.end() || it->second == 1 + form) return PDAE_OK;
+  pdae_set_error("conv3x3p: the prepared weights at %p were written in the %s layout but this launch takes the %s form (PDAE_W1 changed between "
+                 "pdae_conv_wprep and the launch, or PDAE_MATH_DIRECT is set on one of the two descriptors only)", wp,
+                 it->second == 2 ? "Winograd-along-x" : "direct", form ? "Winograd-along-x" : "direct");
+  return PDAE_EINVAL;
 }
 
 // 1: this convolution (launch-side dimensions) is prepared and launched in the Winograd-along-x form (conv3x3x.hip); 0: direct patch kernels.
@@ -540,12 +562,24 @@ int conv3x3p_form(int math, int C, int H, int W, int N, int Nout) {
   return patch_plan(C, H, W, N, Nout).splits == 1 ? 1 : 0;
 }
 
+// Tiles per image of the GroupNorm-backward partial sums a data gradient with these LAUNCH-side dimensions (C = dY channels, Nout = the GroupNorm's
+// channels = C0 + C1) can leave in its epilogue: only the Winograd-form launches (conv3x3y) build it; at most 64 tiles per image (the finalize
+// kernel's workspace, k_gn_workspace_floats); both sources whole 32-channel runs.  0: not available.
+int conv3x3p_gnb_tiles(int math, int C, int H, int W, int N, int Nout, int C0, int C1) {
+  if (C0 + C1 != Nout || (C0 & 31) || (C1 & 31) || !conv3x3p_form(math, C, H, W, N, Nout)) return 0;
+  const int t = (H / 16) * (W / 16);
+  return t <= 64 ? t : 0;
+}
+
 // power-of-two scale of the fp16-format prepared weights: trained conv weights are ~ 1/sqrt(fan_in), which would put their low plane
 // into the fp16 subnormals; scaled to O(1) both planes keep full precision, the kernel multiplies the accumulators by the inverse (exact)
 float conv3x3p_wscale(int C) { int k = 0; while ((1 << (2 * k)) < 9 * C) ++k; return (float)(1 << k); }
 
 // prepared weights + split-K slabs of the convolution (one buffer: [planes | slabs])
-size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) { return prep_bytes(math, Nout, C) + slab_bytes(C, H, W, N, Nout); }
+// (math may carry the direct bit, exactly as for the preparation and the launch: same arguments, same layout, same size)
+size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) {
+  return prep_bytes(math & ~PDAE_MATH_DIRECT_BIT, Nout, C, conv3x3p_form(math, C, H, W, N, Nout)) + slab_bytes(C, H, W, N, Nout);
+}
 
 // One-shot request (pdae_conv_stats_arm): the next forward convolution entry point on this host thread TAKES it -- on entry, before any argument
 // check, so that no return path leaves it armed for a later launch on another tensor -- and hands it to conv3x3p_launch explicitly, which
@@ -558,7 +592,7 @@ size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip
   if (Nout & 3) return 0;
   PatchPlan q = patch_plan(C + 32 * fused_skip_chunks, H, W, N, Nout);
   if (fused_skip_chunks) q.splits = 1;
-  static const int split_stats = []() { const char* e = getenv("PDAE_SPLIT_STATS"); return e ? atoi(e) : 1; }();       // 0: split launches leave none (A/B aid)
+  const int split_stats = pdae_knob(KNOB_SPLIT_STATS);       // 0: split launches leave none (A/B aid)
   if (q.splits != 1 && (Nout > 1024 || !split_stats)) return 0;
   const int t = q.splits != 1 ? (H * W + reduce_stats_tp(N, H * W) - 1) / reduce_stats_tp(N, H * W) : q.tiles_x * q.tiles_y * (q.th / 8);
   if (tpi) *tpi = t;
@@ -567,13 +601,14 @@ size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip
 
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1, int C0,
-                    const float* coef, int act, const PatchSkip* sk, const float* amax, float* stat_part) {
+                    const float* coef, int act, const PatchSkip* sk, const float* amax, float* stat_part, const PatchGnb* gb) {
   const int math_form = math;                             // may carry the direct bit (forward launches): only conv3x3p_form looks at it
   math &= ~PDAE_MATH_DIRECT_BIT;
   PatchParams P;
   P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
   P.woscale = 1.0f / conv3x3p_wscale(C); P.amax = amax; P.sat = pdae_sat_counter();
   P.nx = 0; P.s0 = P.s1 = nullptr; P.Cs0 = P.Cs1 = 0; P.wps = nullptr; P.bias_x = nullptr;
+  P.gb_x0 = P.gb_x1 = nullptr; P.gb_C0 = 0; P.gb_coef = nullptr; P.gb_part = nullptr; P.gb_tpi = 0;
   if (sk) { P.nx = (sk->C0 + sk->C1) >> 5; P.s0 = sk->s0; P.s1 = sk->s1; P.Cs0 = sk->C0; P.Cs1 = sk->C1; P.wps = sk->wps; P.bias_x = sk->bias; }
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.wp = wp; P.NT = (Nout + 31) / 32; P.Nout = Nout;
   P.y = y; P.bias = bias; P.res = res; P.res_mode = res_mode; P.accumulate = accumulate;
@@ -582,12 +617,22 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (sk && (q.w8 || up || (sk->C0 & 31) || (sk->C1 & 31))) { pdae_set_error("conv3x3p: fused skip convolution not eligible for this shape"); return PDAE_EINVAL; }
   if (coef && (q.w8 || (x1 && (C0 & 31)))) { pdae_set_error("conv3x3p: fused GroupNorm input needs W %% 16 == 0 and C0 %% 32 == 0"); return PDAE_EINVAL; }
   P.tiles_x = q.tiles_x; P.tiles_y = q.tiles_y; P.tiles_n = q.tiles_n; P.splits = q.splits; P.cps = q.cps;
-  P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C));
+  const int form = (!q.w8 && conv3x3p_form(math_form, C, H, W, N, Nout)) ? 1 : 0;
+  if (int e = form_check(wp, form)) return e;
+  P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C, form));
   P.stat_part = stat_part;
   P.stat_tpi = q.splits != 1 ? (H * W + reduce_stats_tp(N, H * W) - 1) / reduce_stats_tp(N, H * W) : q.tiles_x * q.tiles_y * (q.th / 8);
   if (P.stat_part && ((Nout & 3) || (q.splits != 1 && Nout > 1024))) { pdae_set_error("conv3x3p: output statistics requested for Nout = %d", Nout); return PDAE_EINVAL; }
   // Winograd F(2, 3) along x (conv3x3x.hip): two thirds of the MFMAs; the prepared weights are in that form iff conv3x3p_form says so
-  if (!q.w8 && conv3x3p_form(math_form, C, H, W, N, Nout)) {
+  if (gb) {
+    const int tpi = conv3x3p_gnb_tiles(math_form, C, H, W, N, Nout, gb->C0, gb->C1);
+    if (!tpi || !form || sk || coef || res_mode || accumulate || stat_part || up) {
+      pdae_set_error("conv3x3p: GroupNorm-backward sums were requested (pdae_conv_gnbwd_arm) but this data gradient cannot leave them (pdae_conv_gnbwd_bytes == 0)");
+      return PDAE_EINVAL;
+    }
+    P.gb_x0 = gb->x0; P.gb_x1 = gb->C1 ? gb->x1 : nullptr; P.gb_C0 = gb->C1 ? gb->C0 : Nout; P.gb_coef = gb->coef; P.gb_part = gb->part; P.gb_tpi = tpi;
+  }
+  if (form) {
     if (sk) { pdae_set_error("conv3x3p: fused skip chunks are not built for the Winograd form (pdae_conv2d_fwd_skip_ok == 0 for this shape)"); return PDAE_EINVAL; }
     if (coef && !act) { pdae_set_error("conv3x3p: fused GroupNorm input without SiLU is not built for the Winograd form"); return PDAE_EINVAL; }
     P.stat_tpi = (H / 16) * (W / 16) * 2;
@@ -634,6 +679,7 @@ static int wprep_launch(int math, const float* w, int Nout, int C, int transpose
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s, int H, int W, int N) {
   const int form = conv3x3p_form(math, C, H, W, N, Nout);
   math &= ~PDAE_MATH_DIRECT_BIT;
+  form_note(wp, form);
   if (form) return wprep_launch(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, s);
   return wprep_launch(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, s);
 }
@@ -645,6 +691,7 @@ static void fill_job3(int math, const float* w, int Nout, int C, int transposed,
 void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j, int H, int W, int N) {
   const int form = conv3x3p_form(math, C, H, W, N, Nout);
   math &= ~PDAE_MATH_DIRECT_BIT;
+  form_note(wp, form);
   if (form) fill_job3(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, j);
   else fill_job3(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, j);
 }
@@ -655,9 +702,9 @@ void conv3x3p_skip_wprep_job(int math, const float* w, int Nout, int Cs, int Cma
 
 // weights of a 1x1 skip convolution [Nout][Cs] for the skip chunks of a 3x3 launch whose main input has Cmain channels: same plane
 // format and (fp16 format) the same power-of-two scale as the main weights
-size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs) {      // (4 k-halves per chunk: room for the two transform positions of the Winograd-along-x form)
+size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs) {      // one centre tap = 2 k-halves per chunk (fused skip chunks exist in the direct form only)
   const int NS = math < 1 ? 1 : (math == 4 ? 2 : (math > 3 ? 3 : math));
-  return (((size_t)NS * (Cs >> 5) * 4 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short)) + 255) & ~(size_t)255;
+  return (((size_t)NS * (Cs >> 5) * 2 * ((Nout + 31) / 32) * 512 * sizeof(unsigned short)) + 255) & ~(size_t)255;
 }
 int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s, int H, int W, int N) {
   (void)H; (void)W; (void)N;

@@ -503,8 +503,8 @@ template <int NS, bool GN> static int launch_r(const PatchParams& P, hipStream_t
   return pdae_launch_status("conv3x3r");
 }
 
-// PDAE_P3R = 0 routes everything to the other patch kernels (A-B aid), 2 ignores the fill heuristic (tests: small shapes).  Read per launch.
-static int r_mode() { const char* e = getenv("PDAE_P3R"); return e ? atoi(e) : 1; }
+// PDAE_P3R = 0 routes everything to the other patch kernels (A-B aid), 2 ignores the fill heuristic (tests: small shapes)
+static int r_mode() { return pdae_knob(KNOB_P3R); }
 
 // eligibility of a launch conv3x3p_launch has planned WITHOUT split-K: at most two operand planes, 16 x 16 tiles, whole 128-channel output
 // tiles, buffer-addressable tensors (< 4 GB each), and enough tiles that the last round of the 256 persistent workgroups wastes little
@@ -520,9 +520,7 @@ bool conv3x3r_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws,
   if (r_mode() == 2) return true;
   const long long tiles = (long long)N * (H / RTH) * (W / PTW) * (Nout / RBN);
   const long long rounds = (tiles + 255) / 256;
-  static int min_tiles = -1, min_eff = -1;                    // PDAE_P3R_MIN / PDAE_P3R_EFF: tuning aids
-  if (min_tiles < 0) { const char* e = getenv("PDAE_P3R_MIN"); min_tiles = e ? atoi(e) : 512; }
-  if (min_eff < 0) { const char* e = getenv("PDAE_P3R_EFF"); min_eff = e ? atoi(e) : 85; }
+  const int min_tiles = pdae_knob(KNOB_P3R_MIN), min_eff = pdae_knob(KNOB_P3R_EFF);      // tuning aids
   return tiles >= min_tiles && tiles * 100 >= rounds * 256 * min_eff;   // at least two tiles per CU (something to overlap), last round >= 85 % full
 }
 

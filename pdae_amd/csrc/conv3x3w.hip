@@ -79,6 +79,28 @@ template <int NS> __device__ __forceinline__ void w_split2(float e0, float e1, u
   }
 }
 
+// act(a * (x - mu) + b) on a channel quad, on float pairs (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32: half the VALU issue slots), SiLU through
+// v_exp_f32 / v_rcp_f32 -- the arithmetic of gn_apply_stream_kernel (norm.hip) and of conv3x3y's gn_map; `on` = 0: a padding pixel (zero AFTER the map)
+typedef float w_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 w_gn_map(const float4& v, unsigned on, const float4& mu, const float4& sc, const float4& sh, int act) {
+  const float onf = on ? 1.0f : 0.0f;
+  w_f32x2 r[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const w_f32x2 x2 = hh ? w_f32x2{v.z, v.w} : w_f32x2{v.x, v.y};
+    const w_f32x2 mu2 = hh ? w_f32x2{mu.z, mu.w} : w_f32x2{mu.x, mu.y};
+    const w_f32x2 sc2 = hh ? w_f32x2{sc.z, sc.w} : w_f32x2{sc.x, sc.y};
+    const w_f32x2 sh2 = hh ? w_f32x2{sh.z, sh.w} : w_f32x2{sh.x, sh.y};
+    const w_f32x2 m = __builtin_elementwise_fma(sc2, x2 - mu2, sh2);
+    if (act) {
+      const w_f32x2 a = m * -1.4426950408889634f;
+      const w_f32x2 d = w_f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
+      r[hh] = m * w_f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])} * onf;
+    } else r[hh] = m * onf;
+  }
+  return make_float4(r[0][0], r[0][1], r[1][0], r[1][1]);
+}
+
 // two transposing reads -> 8 consecutive k (pixel rows r0..r0+7 as seen by this lane's half) of this lane's column.  The compiler builtin
 // (not inline asm) so that hipcc tracks the LDS counter itself and can keep the next tap's fragments in flight under this tap's MFMAs
 // (an asm statement needs its own "s_waitcnt lgkmcnt(0)", which exposes the LDS latency once per tap).
@@ -103,6 +125,10 @@ struct WgradParams {
   float* db_part;                        // optional bias-gradient partials [splits][Cout] (column sums of dY, written by the ci_chunk 0 blocks)
   unsigned int* sat;                     // fp16 format: saturation counter (common.h) or NULL
   int stagger;                           // start delay (units of 64 clocks) of every second block arriving on a CU, see w3_phase_offset
+  // GN instantiation: X is act(a[n,c] * (x - mu[n,c]) + b[n,c]) of the RAW virtual concat [x | x1] (C0 channels in x), recomputed while the
+  // patch is staged -- the activated tensor of the forward pass (module.py:241,279-284: in_layers GroupNorm + SiLU) is then never written,
+  // saved or re-read; coef = [mu | a | b] each [N][C] as pdae_gn_coef leaves them; zero padding applies AFTER the map.
+  const float* x1; int C0; const float* coef; int act;
 };
 
 // Two blocks share a CU so that one stages while the other multiplies -- but blocks launched together run in lock step (same phase lengths),
@@ -123,8 +149,9 @@ __device__ __forceinline__ void w3_phase_offset(int stagger, unsigned* lds_word)
   if (late) for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
 }
 
-template <int NS, bool W8 = false>
+template <int NS, bool W8 = false, bool GN = false>
 __global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams P) {
+  static_assert(!(GN && W8), "the fused GroupNorm input is not built for image-pair tiles");
   constexpr int WPW = WPW_(W8), WNPIX = WNPIX_(W8), WX_LD = WX_LD_(W8);
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   constexpr int SX = WNPL(NS) * WNPIX * WSX;
@@ -143,7 +170,12 @@ __global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams
   const int ci_chunk = bid % P.ci_chunks; bid /= P.ci_chunks;
   const int co_tile = bid % P.co_tiles; const int split = bid / P.co_tiles;
   const int ci0 = ci_chunk * 32, co0 = co_tile * WCO;
-  const int C = P.C, Cout = P.Cout;
+  const int Cout = P.Cout;
+  // the block's 32 input channels lie in ONE tensor of the virtual concat (C0 % 32 == 0): source pointer, its channel count, first channel in it
+  const bool src_first = !GN || ci0 < P.C0;
+  const float* const xsrc = src_first ? P.x : P.x1;
+  const int C = GN ? (src_first ? P.C0 : P.C - P.C0) : P.C;          // channels per pixel of the tensor this block READS (P.C: of the weight)
+  const int cis = GN ? (src_first ? ci0 : ci0 - P.C0) : ci0;
 
   f32x16 acc[5];                            // th 0: taps 0..3, th 1: taps 5..8; acc[4]: this wave's half of the centre tap
 #pragma unroll
@@ -193,6 +225,8 @@ __global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams
   const int yrow = P.W * Cout;
   bool y_ok = co_ok;                          // W8: also false for the missing second image of an odd batch (set per tile)
   const float yscale_ok = (W8 || co_ok) ? yscale : 0.f;      // fp16 format, 16-pixel-wide tiles: lanes beyond Cout load a valid address and are scaled to zero
+  float4 gmu, gsc, gsh;                      // GN: coefficients of the tile being staged (loaded with it, used by lstore)
+  unsigned xokm = 0u;                        // GN: validity bit per patch slot (padding is zero AFTER the map)
   auto gload = [&](int tile) {
     int img = tile / (P.tiles_y * P.tiles_x); int rem = tile - img * P.tiles_y * P.tiles_x;
     int ty = rem / P.tiles_x, tx = rem - ty * P.tiles_x;
@@ -200,12 +234,19 @@ __global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams
     const int y0 = ty * WTH, x0 = tx * WTW;
     const bool pair_missing = W8 && img + 1 >= P.N;
     const int tmask = 16 | (y0 == 0 ? 1 : 0) | (y0 + WTH >= P.H ? 2 : 0) | (!W8 && x0 == 0 ? 4 : 0) | (!W8 && x0 + WTW >= P.W ? 8 : 0) | (pair_missing ? 32 : 0);
-    const float* xb = P.x + ((size_t)(img * P.Hs + (y0 >> ush)) * P.Ws + (x0 >> ush)) * C + ci0;
+    const float* xb = xsrc + ((size_t)(img * P.Hs + (y0 >> ush)) * P.Ws + (x0 >> ush)) * C + cis;
+    if constexpr (GN) {                          // this thread's channel quad (t & 7 in every slot) of the tile's image: [mu | a | b]
+      const float* cf = P.coef + (size_t)img * P.C + ci0 + (t & 7) * 4;
+      const size_t NC = (size_t)P.N * P.C;
+      gmu = *reinterpret_cast<const float4*>(cf); gsc = *reinterpret_cast<const float4*>(cf + NC); gsh = *reinterpret_cast<const float4*>(cf + 2 * NC);
+      xokm = 0u;
+    }
 #pragma unroll
     for (int l = 0; l < WX_LD; ++l) {            // unconditional loads from clamped addresses, zeroed afterwards
       const bool ok = (xw[l] & tmask) == 0;
       const float4 v = *reinterpret_cast<const float4*>(xb + (ok ? xw[l] >> 6 : 0));
-      xpre[l] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (GN) { xpre[l] = v; xokm |= (ok ? 1u : 0u) << l; }      // zeroed AFTER the map (lstore)
+      else xpre[l] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float* yb = P.dy + ((size_t)(img * P.H + y0) * P.W + x0) * Cout + co0;
     if constexpr (W8) y_ok = co_ok && !(pair_missing && ycol >= 8);
@@ -222,6 +263,7 @@ __global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams
     for (int l = 0; l < WX_LD; ++l) {
       int idx = t + WTHREADS * l; int pix = idx >> 3, qd = idx & 7;
       if (pix < WNPIX) {
+        if constexpr (GN) xpre[l] = w_gn_map(xpre[l], (xokm >> l) & 1u, gmu, gsc, gsh, P.act);
         if constexpr (NS == 4) pdae_f16_amax4(xpre[l], WXSCALE, sat_hit);
         unsigned u[WNPL(NS)], v[WNPL(NS)];
         w_split2<NS>(xpre[l].x, xpre[l].y, u, WXSCALE); w_split2<NS>(xpre[l].z, xpre[l].w, v, WXSCALE);
@@ -361,7 +403,7 @@ __global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams
     for (int r = 0; r < 16; ++r) acc[4][r] += cen[r * 64 + lane];
   }
   // epilogue: slab `split` of the workspace, layout [Cout][9][C]
-  float* slab = P.ws + (size_t)split * Cout * 9 * C;
+  float* slab = P.ws + (size_t)split * Cout * 9 * P.C;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     if (j == 4 && th == 1) break;
@@ -369,7 +411,7 @@ __global__ void __launch_bounds__(WTHREADS, 2) conv3x3w_kernel(const WgradParams
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (co < Cout) slab[((size_t)co * 9 + tp) * C + ci0 + li] = NS == 4 ? acc[j][r] * oscale : acc[j][r];
+      if (co < Cout) slab[((size_t)co * 9 + tp) * P.C + ci0 + li] = NS == 4 ? acc[j][r] * oscale : acc[j][r];
     }
   }
 }
@@ -400,6 +442,12 @@ bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, i
   return (long long)N * (H / WTH) * (W / WTW) >= 64;
 }
 
+// the GN instantiation (fused GroupNorm + SiLU input, two-source): both sources whole 32-channel chunks, 16-pixel-wide tiles
+bool conv3x3w_gn_ok(int math, int KH, int KW, int stride, int pad, int C0, int C1, int H, int W, int N, int Cout) {
+  if (W == 8 || (C0 & 31) || (C1 & 31)) return false;
+  return conv3x3w_ok(math, KH, KW, stride, pad, 0, C0 + C1, H, W, N, Cout);
+}
+
 // slabs [splits][Cout][9][C] + bias-gradient partials [splits][Cout]
 size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout) {
   int splits, tps;
@@ -407,23 +455,27 @@ size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout) {
   return ((size_t)splits * Cout * 9 * C + (size_t)splits * Cout) * sizeof(float);
 }
 
-template <int NS, bool W8 = false> static int launch_w(const WgradParams& P, hipStream_t s) {
+template <int NS, bool W8 = false, bool GN = false> static int launch_w(const WgradParams& P, hipStream_t s) {
   const size_t smem = (size_t)(WNPL(NS) * WNPIX_(W8) * WSX + WNPL(NS) * WTPIX * WSY) * sizeof(unsigned short) + WTHREADS * sizeof(float4);   // + bias-sum slots
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3w_kernel<NS, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3w_kernel<NS, W8, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3w: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3w_kernel<NS, W8>), dim3(P.splits * P.co_tiles * P.ci_chunks), dim3(WTHREADS), smem, s, P);
+  hipLaunchKernelGGL((conv3x3w_kernel<NS, W8, GN>), dim3(P.splits * P.co_tiles * P.ci_chunks), dim3(WTHREADS), smem, s, P);
   return pdae_launch_status("conv3x3w");
 }
 
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
-                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax, float* db) {
+                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax, float* db,
+                    const float* x1, int C0, const float* coef, int act) {
   WgradParams P;
+  P.x1 = x1; P.C0 = x1 ? C0 : C; P.coef = coef; P.act = act;
+  if (!coef && x1) { pdae_set_error("conv3x3w: a two-source input needs the fused GroupNorm form (coef)"); return PDAE_EINVAL; }
+  if (coef && (W == 8 || (P.C0 & 31) || ((C - P.C0) & 31))) { pdae_set_error("conv3x3w: fused GroupNorm input needs W %% 16 == 0 and both sources whole 32-channel chunks"); return PDAE_EINVAL; }
   P.dy_amax = dy_amax; P.sat = pdae_sat_counter();
-  static const int stagger = [] { const char* e = getenv("PDAE_W3_STAGGER"); return e ? atoi(e) : 0; }();      // off by default: measured +-0 (the kernel is power-bound, not phase-bound)
+  const int stagger = pdae_knob(KNOB_W3_STAGGER);      // off by default: measured +-0 (the kernel is power-bound, not phase-bound)
   P.stagger = stagger;
   if (math == 4 && !dy_amax) math = 3;          // fp16 format needs the dY scale: without it the exact bf16 split runs
   P.x = x; P.N = N; P.Hs = Hs; P.Ws = Ws; P.C = C; P.H = H; P.W = W; P.up = up; P.dy = dy; P.Cout = Cout; P.ws = ws;
@@ -437,6 +489,7 @@ int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (!ws || ws_bytes < need) { pdae_set_error("conv3x3w: workspace too small (%zu < %zu)", ws_bytes, need); return PDAE_EINVAL; }
   int e;
   if (w8) e = math == 1 ? launch_w<1, true>(P, s) : (math == 2 ? launch_w<2, true>(P, s) : (math == 4 ? launch_w<4, true>(P, s) : launch_w<3, true>(P, s)));
+  else if (coef) e = math == 1 ? launch_w<1, false, true>(P, s) : (math == 2 ? launch_w<2, false, true>(P, s) : (math == 4 ? launch_w<4, false, true>(P, s) : launch_w<3, false, true>(P, s)));
   else e = math == 1 ? launch_w<1>(P, s) : (math == 2 ? launch_w<2>(P, s) : (math == 4 ? launch_w<4>(P, s) : launch_w<3>(P, s)));
   if (e) return e;
   // the bias gradient's final sum rides in the reduce launch when the caller gave its destination (db_part is then reported as consumed)

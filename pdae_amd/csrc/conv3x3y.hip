@@ -65,8 +65,11 @@ struct YDiv { unsigned mn, mx, my; };
 // (against an empty resource they still cost the vector-memory path ~35 cycles each: tools/micro/unit_pipe.hip)
 // ST: the launch leaves the GroupNorm partial statistics of its output (pdae_conv_stats_arm); data gradients and convolutions not followed by a
 // GroupNorm do not, and then the 64 VALU instructions per epilogue block that sum them do not exist either
-template <int NS, bool GN, bool EX, bool ST>
+// GB: the launch is a data gradient that leaves the GroupNorm-backward sums of its output (PatchParams::gb_*): EX's operand slots carry the
+// GroupNorm's raw input x instead of a residual (the operand is NOT added), the sums replace ST's
+template <int NS, bool GN, bool EX, bool ST, bool GB = false>
 __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams P, const int stagger, const YDiv D) {
+  static_assert(!GB || (EX && !ST && !GN), "GB: a data gradient with the operand slots, no forward statistics, no fused GroupNorm input");
   constexpr int NP = NPL(NS);
   constexpr unsigned BUF_B = NP * YPLANE_B;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -472,24 +475,44 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
       const int er = lane_e >> 3, ec = (lane_e & 7) * 4;
       const unsigned tw_w = tw + (unsigned)((4 * (lane_e >> 5) * EPW + (lane_e & 31)) * 4), tw_r = tw + (unsigned)((er * EPW + ec) * 4);
       const int n0w = m_n0 + wv * 32;
-      const int rsh = P.res_mode == 2 ? 1 : 0;             // half-resolution residual (nearest upsample): rows / columns >> 1, both columns of a pair read one pixel
+      const int rsh = (!GB && P.res_mode == 2) ? 1 : 0;    // half-resolution residual (nearest upsample): rows / columns >> 1, both columns of a pair read one pixel
+      // GB: the operand is the GroupNorm input [x0 | x1]: this wave's 32 channels lie in one of the two tensors (C0 % 32 == 0), whose pixel stride
+      // is ITS channel count
+      const bool g_first = !GB || n0w < P.gb_C0;
+      const int xc = GB ? (g_first ? P.gb_C0 : P.Nout - P.gb_C0) : P.Nout, xn0 = GB ? (g_first ? n0w : n0w - P.gb_C0) : n0w;
       const unsigned lane_y = (unsigned)((((er >> 2) * P.W + 2 * (er & 3)) * P.Nout + ec) * 4);
-      const unsigned lane_x = rsh ? (unsigned)(((er & 3) * P.Nout + ec) * 4) : lane_y;
+      const unsigned lane_x = rsh ? (unsigned)(((er & 3) * xc + ec) * 4) : (unsigned)((((er >> 2) * P.W + 2 * (er & 3)) * xc + ec) * 4);
       const unsigned lane_st = lane_e < 8 ? (unsigned)(lane_e * 8) : YOOB;
       // byte steps of the output: `it` = 2 rows, j = one pixel, a & 1 = 8 pixels, a >> 1 = 8 rows; of the residual likewise (half resolution: halved)
       const unsigned y_it = (unsigned)(2 * P.W * P.Nout * 4), y_j = (unsigned)(P.Nout * 4), y_a2 = (unsigned)(8 * P.Nout * 4), y_ar = (unsigned)(8 * P.W * P.Nout * 4);
-      const unsigned x_it = rsh ? (unsigned)((P.W >> 1) * P.Nout * 4) : y_it, x_j = rsh ? 0u : y_j, x_a2 = rsh ? (unsigned)(4 * P.Nout * 4) : y_a2;
-      const unsigned x_ar = rsh ? (unsigned)(4 * (P.W >> 1) * P.Nout * 4) : y_ar;
+      const unsigned x_it = rsh ? (unsigned)((P.W >> 1) * xc * 4) : (unsigned)(2 * P.W * xc * 4), x_j = rsh ? 0u : (unsigned)(xc * 4);
+      const unsigned x_a2 = rsh ? (unsigned)(4 * xc * 4) : (unsigned)(8 * xc * 4);
+      const unsigned x_ar = rsh ? (unsigned)(4 * (P.W >> 1) * xc * 4) : (unsigned)(8 * P.W * xc * 4);
       const unsigned d_rb4 = (unsigned)((((m_img * P.H + m_y0) * P.W + m_x0) * P.Nout + n0w) * 4);
-      const unsigned d_xb4 = rsh ? (unsigned)((((m_img * (P.H >> 1) + (m_y0 >> 1)) * (P.W >> 1) + (m_x0 >> 1)) * P.Nout + n0w) * 4) : d_rb4;
+      const unsigned d_xb4 = rsh ? (unsigned)((((m_img * (P.H >> 1) + (m_y0 >> 1)) * (P.W >> 1) + (m_x0 >> 1)) * xc + xn0) * 4)
+                                 : (unsigned)((((m_img * P.H + m_y0) * P.W + m_x0) * xc + xn0) * 4);
       const unsigned d_sb8 = (unsigned)(((m_img * P.stat_tpi + ((m_y0 >> 4) * P.tiles_x + (m_x0 >> 4)) * 2) * (P.Nout >> 2) + (n0w >> 2)) * 8);      // + (a >> 1): the row half's entry
       const unsigned s_ar = (unsigned)((P.Nout >> 2) * 8);
-      const float* const extra_ = P.res_mode ? P.res : P.y;      // residual OR (accumulate) the previous contents of y (both: conv3x3y_launch falls back)
-      const unsigned extra_on = (P.res_mode || P.accumulate) ? YALL : 0u, stat_on = P.stat_part ? YALL : 0u, bias_on = P.bias ? YALL : 0u;
+      const float* const extra_ = GB ? (g_first ? P.gb_x0 : P.gb_x1) : (P.res_mode ? P.res : P.y);      // residual OR (accumulate) the previous contents of y (both: conv3x3y_launch falls back)
+      const unsigned extra_on = (GB || P.res_mode || P.accumulate) ? YALL : 0u, stat_on = P.stat_part ? YALL : 0u, bias_on = P.bias ? YALL : 0u;
 #define Y_RSB(PTR, BYTES) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((const void*)(PTR)), 0, (int)(BYTES), 0x00020000)
       float4 rv[EX ? 2 : 1][2][EX ? 4 : 1];
       float st1 = 0.f, st2 = 0.f;
-      const float4 bias4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.bias, bias_on), ec * 4, (int)(n0w * 4), 0));
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);      // (GB: a data gradient has no bias -- four registers the sums need)
+      if constexpr (!GB) bias4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.bias, bias_on), ec * 4, (int)(n0w * 4), 0));
+      // GB: coefficients of this lane's channel quad in the tile's image as  z = a x + b',  b' = b - a mu  (eight registers instead of twelve: the
+      // kernel is at its register limit), and the tile's sums S0 = sum dv, S1x = sum dv x as float pairs; sum dv (x - mu) = S1x - mu S0 is formed per
+      // lane at the end of the tile (mu is loaded again there -- the operand slots are free by then), i.e. the cancellation acts on 32-pixel partials
+      // and costs the same rounding as a per-element subtraction
+      float4 gba = make_float4(0.f, 0.f, 0.f, 0.f), gbb = gba;
+      y_f32x2 gs0[2] = {y_f32x2{0.f, 0.f}, y_f32x2{0.f, 0.f}}, gs1[2] = {y_f32x2{0.f, 0.f}, y_f32x2{0.f, 0.f}};
+      const unsigned g_nc4 = (unsigned)(P.N * P.Nout * 4), g_co4 = (unsigned)((m_img * P.Nout + n0w) * 4);
+      if constexpr (GB) {
+        const float4 m_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.gb_coef, YALL), ec * 4, (int)g_co4, 0));
+        gba = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.gb_coef, YALL), ec * 4, (int)(g_co4 + g_nc4), 0));
+        gbb = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.gb_coef, YALL), ec * 4, (int)(g_co4 + 2u * g_nc4), 0));
+        gbb.x = fmaf(-gba.x, m_.x, gbb.x); gbb.y = fmaf(-gba.y, m_.y, gbb.y); gbb.z = fmaf(-gba.z, m_.z, gbb.z); gbb.w = fmaf(-gba.w, m_.w, gbb.w);
+      }
       auto epi_L = [&](int b) {                       // block b = m-tile a
         if constexpr (EX)
 #pragma unroll
@@ -540,9 +563,28 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
             const y_f32x4 v4 = *(y_lds_f4)(size_t)(tw_r + (unsigned)j * TWB + (unsigned)(it * 8 * EPW * 4));
             float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
             float4 bb = bias4;
-            if constexpr (EX) { const float4 u = rv[b & 1][j][it]; bb.x += u.x; bb.y += u.y; bb.z += u.z; bb.w += u.w; }
-            v.x = fmaf(v.x, oscale, bb.x); v.y = fmaf(v.y, oscale, bb.y); v.z = fmaf(v.z, oscale, bb.z); v.w = fmaf(v.w, oscale, bb.w);
+            if constexpr (EX && !GB) { const float4 u = rv[b & 1][j][it]; bb.x += u.x; bb.y += u.y; bb.z += u.z; bb.w += u.w; }
+            if constexpr (GB) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
+            else { v.x = fmaf(v.x, oscale, bb.x); v.y = fmaf(v.y, oscale, bb.y); v.z = fmaf(v.z, oscale, bb.z); v.w = fmaf(v.w, oscale, bb.w); }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(y_u32x4, v), Y_RSB(P.y, YALL), (int)lane_y, (int)(d_rb4 + it * y_it + j * y_j + (b & 1) * y_a2 + (b >> 1) * y_ar), 0);
+            if constexpr (GB) {
+              // dv = dA * silu'(z), z = a x + b', silu'(z) = s (1 + z (1 - s)), s = 1 / (1 + 2^(-z log2 e)): the arithmetic of compute_dv (norm.hip)
+              // on float pairs (packed VALU); act == 1, no dropout (launch check)
+              const float4 u = rv[b & 1][j][it];
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) {
+                const y_f32x2 x2 = hh ? y_f32x2{u.z, u.w} : y_f32x2{u.x, u.y}, d2 = hh ? y_f32x2{v.z, v.w} : y_f32x2{v.x, v.y};
+                const y_f32x2 a2 = hh ? y_f32x2{gba.z, gba.w} : y_f32x2{gba.x, gba.y}, b2 = hh ? y_f32x2{gbb.z, gbb.w} : y_f32x2{gbb.x, gbb.y};
+                const y_f32x2 z = __builtin_elementwise_fma(a2, x2, b2);
+                const y_f32x2 e = z * -1.4426950408889634f;
+                const y_f32x2 p1 = y_f32x2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + 1.0f;
+                const y_f32x2 sg = y_f32x2{__builtin_amdgcn_rcpf(p1[0]), __builtin_amdgcn_rcpf(p1[1])};
+                const y_f32x2 ds = sg * (1.0f + z * (1.0f - sg));
+                const y_f32x2 dv = d2 * ds;
+                gs0[hh] += dv;
+                gs1[hh] = __builtin_elementwise_fma(dv, x2, gs1[hh]);
+              }
+            }
             if constexpr (ST) {
               st1 += (v.x + v.y) + (v.z + v.w);
               st2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, st2))));
@@ -563,6 +605,19 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
       epi_W(1); Y_EPI_FENCE epi_S(1); Y_EPI_FENCE epi_L(3); Y_EPI_FENCE
       epi_W(2); Y_EPI_FENCE epi_S(2); Y_EPI_FENCE
       epi_W(3); Y_EPI_FENCE epi_S(3); Y_EPI_FENCE
+      if constexpr (GB) {      // the eight lanes that hold a channel quad combine (fixed order), lanes 0..7 write (S0, S1) of four channels: 32 bytes
+        const float4 m_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.gb_coef, YALL), ec * 4, (int)g_co4, 0));
+        float sv8[8] = {gs0[0][0], fmaf(-m_.x, gs0[0][0], gs1[0][0]), gs0[0][1], fmaf(-m_.y, gs0[0][1], gs1[0][1]),
+                        gs0[1][0], fmaf(-m_.z, gs0[1][0], gs1[1][0]), gs0[1][1], fmaf(-m_.w, gs0[1][1], gs1[1][1])};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sv8[k] += __shfl_xor(sv8[k], 8); sv8[k] += __shfl_xor(sv8[k], 16); sv8[k] += __shfl_xor(sv8[k], 32); }
+        const unsigned g_lane = lane_e < 8 ? (unsigned)(lane_e * 32) : YOOB;
+        const unsigned g_off = (unsigned)((((m_img * P.gb_tpi + (m_y0 >> 4) * P.tiles_x + (m_x0 >> 4)) * P.Nout) + n0w) * 8);
+        const y_u32x4 w0 = {__float_as_uint(sv8[0]), __float_as_uint(sv8[1]), __float_as_uint(sv8[2]), __float_as_uint(sv8[3])};
+        const y_u32x4 w1 = {__float_as_uint(sv8[4]), __float_as_uint(sv8[5]), __float_as_uint(sv8[6]), __float_as_uint(sv8[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(w0, Y_RSB(P.gb_part, YALL), (int)g_lane, (int)g_off, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(w1, Y_RSB(P.gb_part, YALL), (int)g_lane, (int)(g_off + 16u), 0);
+      }
 #undef Y_EPI_FENCE
 #undef Y_RSB
     }
@@ -581,28 +636,64 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit * (2.0f * ascale));      // |s| <= 2 max|d| after the transform
 }
 
-template <int NS, bool GN, bool EX, bool ST> static int launch_y(const PatchParams& P, hipStream_t s) {
+template <int NS, bool GN, bool EX, bool ST, bool GB = false> static int launch_y(const PatchParams& P, hipStream_t s) {
   const size_t smem = (size_t)2 * NPL(NS) * YPLANE_B + (size_t)4 * 2 * 32 * EPW * 4 + 4 * 256;      // two patch buffers + two transposition tiles per wave + the coefficient slots (f16x3: 162304 of 163840 bytes)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN, EX, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN, EX, ST, GB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3y: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
   const long long ntiles = (long long)P.N * P.tiles_y * P.tiles_x * P.tiles_n;
   dim3 grid((unsigned)(ntiles < 256 ? ntiles : 256));
-  static int stagger = -1;
-  if (stagger < 0) { const char* e = getenv("PDAE_Y_STAGGER"); stagger = e ? atoi(e) : 0; }
+  const int stagger = pdae_knob(KNOB_Y_STAGGER);
   auto magic = [](int d) { return (unsigned)((0x100000000ull / (unsigned long long)d) + 1ull); };      // unused for d == 1
   const YDiv D{magic(P.tiles_n), magic(P.tiles_x), magic(P.tiles_y)};
   if (ntiles >= (1ll << 20) || P.tiles_n >= 4096 || P.tiles_x >= 4096 || P.tiles_y >= 4096) { pdae_set_error("conv3x3y: %lld tiles", ntiles); return 1; }
-  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX, ST>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
+  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX, ST, GB>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
   return pdae_launch_status("conv3x3y");
+}
+
+// ---- host side of the Winograd-along-x form (the decision used to live next to the two-waves-per-SIMD probe kernel conv3x3x, which is now under
+// tools/probes/r04_winograd/ together with the 2-D F(2x2, 3x3) probe: neither was launched by any plan)
+
+// Form of the prepared weights AND of the launch of a 3x3 convolution with these launch-side dimensions (C input channels, H x W output grid,
+// Nout output channels): decided from the shape and the knob PDAE_W1 alone, so that weight preparation and launch agree.  The knob is read once
+// (common.h); a prepared buffer is tagged with the form it was written in and a launch that expects the other form is refused (conv3x3p.hip).
+bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout) {
+  const int m = pdae_knob(KNOB_W1);      // 0: off; 1 (default): layers with at least a chip-full of tiles; 2: every eligible shape (tests)
+  if (m == 0) return false;
+  if (!(math == 1 || math == 2 || math == 4)) return false;
+  if ((H % 16) || (W % PTW) || (Nout % PBN) || (C & 31) || H >= 2048 || W >= 2048) return false;
+  const unsigned long long lim = 0xFFFFFFE0ull;
+  if ((unsigned long long)N * H * W * (unsigned long long)(C > Nout ? C : Nout) * 4ull >= lim) return false;
+  if (m == 2) return true;
+  const long long tiles = (long long)N * (H / 16) * (W / PTW) * (Nout / PBN);
+  const long long rounds = (tiles + 255) / 256;
+  return tiles >= 256 && tiles * 100 >= rounds * 256 * pdae_knob(KNOB_W1_EFF);      // persistent workgroups: the last round must not leave the chip idle
+}
+
+// P: as conv3x3p_launch fills it; tiles of 16 x 16 pixels x 128 channels, Winograd-along-x weights; no fused skip chunks in this form
+int conv3x3x_launch(int math, const PatchParams& P0, hipStream_t s) {
+  PatchParams P = P0;
+  P.tiles_x = P.W / PTW; P.tiles_y = P.H / 16; P.tiles_n = P.Nout / PBN; P.splits = 1; P.cps = P.C >> 5;
+  if (P.nx) { pdae_set_error("conv3x3y: fused skip chunks are not built for the Winograd form"); return PDAE_EINVAL; }
+  if (P.x1 && (P.C0 & 31)) { pdae_set_error("conv3x3y: two-source input needs C0 %% 32 == 0"); return PDAE_EINVAL; }
+  return conv3x3y_launch(math, P, s);
 }
 
 // P: as prepared by conv3x3x_launch (tiles of 16 x 16 pixels x 128 channels, Winograd-along-x weights); no fused skip chunks
 int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s) {
   if (P.res_mode && P.accumulate) { pdae_set_error("conv3x3y: residual and accumulate in one launch"); return 1; }
+  if (P.gb_part) {      // data gradient + GroupNorm-backward sums: the operand slots carry the GroupNorm input
+    if (P.res_mode || P.accumulate || P.coef || P.stat_part || (P.gb_C0 & 31) || ((P.Nout - P.gb_C0) & 31) || P.gb_tpi != P.tiles_x * P.tiles_y) {
+      pdae_set_error("conv3x3y: GroupNorm-backward sums need a plain data gradient (no residual / accumulate / fused input) and 32-channel-aligned sources");
+      return PDAE_EINVAL;
+    }
+    if (math == 1) return launch_y<1, false, true, false, true>(P, s);
+    if (math == 2) return launch_y<2, false, true, false, true>(P, s);
+    return launch_y<4, false, true, false, true>(P, s);
+  }
 #define PDAE_Y2(NS_, GN_) (ex ? (st ? launch_y<NS_, GN_, true, true>(P, s) : launch_y<NS_, GN_, true, false>(P, s))       \
                               : (st ? launch_y<NS_, GN_, false, true>(P, s) : launch_y<NS_, GN_, false, false>(P, s)))
 #define PDAE_Y3(NS_) (P.coef ? PDAE_Y2(NS_, true) : PDAE_Y2(NS_, false))

@@ -53,13 +53,17 @@ int igemm_dense(int transA, int transB, const GemmParams& P, int zdim, hipStream
 
 // conv3x3p.hip: 3x3 stride-1 "patch" kernel on the bf16 MFMA pipe (math modes 1..3)
 struct PatchSkip { const float* s0; const float* s1; int C0, C1; const unsigned short* wps; const float* bias; };   // fused 1x1 skip conv
+// GroupNorm-backward sums from a DATA-GRADIENT launch's epilogue (pdae_conv_gnbwd_arm): x = [x0 | x1] the GroupNorm's raw input (C0 + C1 = the
+// launch's output channels), coef = [mu | a | b] of its forward, part = [N][tiles per image][C][2] x (sum dv, sum dv (x - mu)), dv = dA silu'(a (x - mu) + b)
+struct PatchGnb { const float* x0; const float* x1; int C0, C1; const float* coef; float* part; };
 bool conv3x3p_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, int H, int W, int N, int Nout, bool fill);
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N);
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s, int H, int W, int N);
 int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const unsigned short* wp, int Nout,
                     float* y, const float* bias, const float* res, int res_mode, int accumulate, hipStream_t s, const float* x1 = nullptr,
                     int C0 = 0, const float* coef = nullptr, int act = 0, const PatchSkip* sk = nullptr, const float* amax = nullptr,
-                    float* stat_part = nullptr);
+                    float* stat_part = nullptr, const PatchGnb* gb = nullptr);
+int conv3x3p_gnb_tiles(int math, int C, int H, int W, int N, int Nout, int C0, int C1);      // tiles per image of PatchGnb::part, 0 = the launch cannot leave the sums
 void conv3x3p_arm_stats(float* part);          // one-shot request of pdae_conv_stats_arm (thread-local)
 float* conv3x3p_take_stats();                  // ... taken AND cleared by the next forward entry point, first thing, on every return path
 size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi);
@@ -72,7 +76,9 @@ bool conv3x3w_ok(int math, int KH, int KW, int stride, int pad, int C1, int C, i
 size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout);
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
                     int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part = nullptr, int* db_rows = nullptr,
-                    const float* dy_amax = nullptr, float* db = nullptr);
+                    const float* dy_amax = nullptr, float* db = nullptr, const float* x1 = nullptr, int C0 = 0, const float* coef = nullptr, int act = 0);
+// the same kernel with GroupNorm + SiLU recomputed on the RAW two-source input [x | x1] while it is staged (coef = [mu | a | b], pdae_gn_coef)
+bool conv3x3w_gn_ok(int math, int KH, int KW, int stride, int pad, int C0, int C1, int H, int W, int N, int Cout);
 
 // conv1x1.hip: 1x1 convolution (forward / data gradient) on prepared weights, activations staged through LDS
 bool conv1x1_ok(int math, int KH, int KW, int stride, int pad, int up, int C0, int C1, int Nout);

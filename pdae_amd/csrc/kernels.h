@@ -17,7 +17,8 @@ int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, i
 int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd, const float* gamma,
              const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p, unsigned long long seed,
              unsigned long long offset, const float* add, float* dx0, int acc0, float* dx1, int acc1, float* dgamma, float* dbeta, int acc_param,
-             float* dss, float* dzss, float* ws, hipStream_t st, float* dx0_amax = nullptr, unsigned* ticket = nullptr);
+             float* dss, float* dzss, float* ws, hipStream_t st, float* dx0_amax = nullptr, unsigned* ticket = nullptr,
+             const float* parts = nullptr, int parts_tiles = 0);
 
 int k_timestep_embedding(const long long* t, const float* freqs, int N, int dim, float* out, hipStream_t st);
 int k_mlp_modln_fwd(const float* u, const float* e, const float* gamma, const float* beta, int R, int C, int norm, int act, float eps, float* y,

@@ -680,21 +680,25 @@ int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, i
 int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,
              const float* gamma, const float* beta, const float* ss, const float* zss, const float* dA, int act, int mode, float drop_p,
              unsigned long long seed, unsigned long long offset, const float* add, float* dx0, int acc0, float* dx1, int acc1,
-             float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, float* ws, hipStream_t st, float* dx0_amax, unsigned* ticket) {
+             float* dgamma, float* dbeta, int acc_param, float* dss, float* dzss, float* ws, hipStream_t st, float* dx0_amax, unsigned* ticket,
+             const float* parts, int parts_tiles) {
   if (int e = check_c(C0, C1, G)) return e;
   const int C = C0 + C1, HW = H * W;
   unsigned* am = (dx0 && dx0_amax) ? reinterpret_cast<unsigned*>(dx0_amax) : nullptr;
   Src2 s{x0, x1, C0, C1};
   int S = stats_chunks(HW, C), chunk = cdiv(HW, S);
   S = cdiv(HW, chunk);
-  float* part = ws;                                   // [N][S][C][2]
+  // parts: the two per-(n, c) sums were left by the data gradient that wrote dA (conv3x3y GB epilogue), [N][parts_tiles][C][2] in the layout of the
+  // reduce kernel: the reduction pass over (x, dA) does not run
+  if (parts) S = parts_tiles;
+  float* part = parts ? const_cast<float*>(parts) : ws;   // [N][S][C][2]
   float* c12 = ws + (size_t)N * 64 * C * 2;           // [N][C][2]
   float* pgb = c12 + (size_t)N * C * 2;               // [N][C][2]
   if (ticket) {
     hipLaunchKernelGGL(gn_bwd_reduce_fused_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, G, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part,
                        rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am, dgamma, dbeta, acc_param, ticket);
   } else {
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
+    if (!parts) hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am);
   }
   int Sa = stream_chunks(HW, C), chunk_a = cdiv(HW, Sa);

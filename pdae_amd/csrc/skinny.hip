@@ -85,7 +85,7 @@ int skinny_group_launch(const void* items, const int* first, int n_items, int to
 }
 
 bool skinny_ok(int transA, int transB, int M, int N, int K, float alpha, long long lda, long long ldb, const float* A, const float* B, int batch) {
-  static const bool off = getenv("PDAE_NO_SKINNY") != nullptr;        // tuning aid: force the MFMA tile kernel
+  const bool off = pdae_knob(KNOB_NO_SKINNY) != 0;        // tuning aid: force the MFMA tile kernel
   if (off || transA || !transB || batch != 1 || alpha != 1.0f || M > SK_M || N < 64) return false;
   return (K & 7) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
 }

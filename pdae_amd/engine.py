@@ -180,6 +180,12 @@ class Builder:
         self.fuse_skip = os.environ.get("PDAE_FUSE_SKIP", "1") != "0"  # ResBlock skip_connection rides in conv2's K loop (conv_skip)
         self.skip_direct_ratio = float(os.environ.get("PDAE_SKIP_DIRECT_RATIO", "0"))   # > 0: skip / main channel ratio from which a Winograd-eligible conv2 keeps the direct form + fused skip (default: never)
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
+        # TRAINED in_layers stages (GroupNorm -> SiLU -> conv3x3, no dropout) run the same fused forward and their weight gradient recomputes
+        # the activation while it stages X (gn_conv_saved): the activated tensor is never written, saved or re-read
+        self.fuse_gn_train = os.environ.get("PDAE_FUSE_GN_TRAIN", "1") != "0"
+        # the two per-(n, c) sums of a GroupNorm backward come out of the epilogue of the data gradient that writes dA (conv_dgrad(gnb=...)) where
+        # the kernels build it (Winograd-form 3x3 data gradients, SiLU, no dropout): no reduction pass over (x, dA)
+        self.fuse_gn_bwd = os.environ.get("PDAE_FUSE_GN_BWD", "1") != "0"
         # forward 3x3 convolutions leave the GroupNorm partial statistics of their output behind (pdae_conv_stats_arm); the GroupNorm that
         # reads such a tensor takes them instead of a statistics pass over it
         self.fuse_stats = os.environ.get("PDAE_FUSE_GN_STATS", "1") != "0"
@@ -325,14 +331,14 @@ class Builder:
     def amax_ok(self, c):
         """True when conv c's gradient kernels take a dY abs-max (fp16 format)."""
         c = self._bwd_desc(c)
-        return bool(self.f16_grads and c.math == H.MATH_NAMES["f16x3"] and c.stride == 1 and ((c.KH == 3 and c.C1 == 0) or c.KH == 1))
+        return bool(self.f16_grads and c.math == H.MATH_NAMES["f16x3"] and c.stride == 1 and ((c.KH == 3 and (c.C1 == 0 or getattr(c, "gn_in", False))) or c.KH == 1))
 
     def dy_amax(self, c, dy):
         """Device scalar max|dy| for the fp16-format gradient kernels of conv c (None: they run the exact bf16 split).  wgrad and dgrad of
         one layer are emitted back to back on the same dy: the scalar is computed once and shared."""
         if not self.f16_grads or c.math != H.MATH_NAMES["f16x3"] or c.stride != 1:
             return None
-        if not ((c.KH == 3 and c.C1 == 0) or c.KH == 1):
+        if not ((c.KH == 3 and (c.C1 == 0 or getattr(c, "gn_in", False))) or c.KH == 1):
             return None
         if self._amax_dy is dy and self._amax_until == len(self.p.recs):
             return self._amax_buf
@@ -369,8 +375,9 @@ class Builder:
             # the bias gradient rides along: the 3x3 kernel sums dY while staging it, the other paths run the column sum themselves
             ride = self.fuse_db
             am = (amax if (amax is not None and self.amax_ok(c)) else self.dy_amax(c, dy))       # 3x3 and 1x1 weight-gradient kernels: fp16 format with dy_amax
-            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am), ws_slot=4,
-                        wsb_slot=len(c.fields()) + 1)
+            gn = getattr(cx, "gn", None)                     # (coef, act): x0 / x1 are the RAW sources of a fused-GroupNorm forward (gn_conv_saved)
+            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am,
+                                        gn_coef=gn[0] if gn else None, gn_act=gn[1] if gn else 0), ws_slot=4, wsb_slot=len(c.fields()) + 1)
             if am is not None:
                 self._amax_until = len(self.p.recs)
             if ride:
@@ -382,7 +389,9 @@ class Builder:
         if dense:
             self._dyf = (dy_small, dy, len(self.p.recs))                    # conv_dgrad may take it if it is the very next thing emitted
 
-    def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0, amax=None):
+    def conv_dgrad(self, cx, dy, ci_off=0, ci_cnt=None, out=None, accumulate=0, amax=None, gnb=None):
+        """gnb: ctx of the GroupNorm whose output this convolution read (same resolution): when the launch can, it also leaves that GroupNorm's
+        backward sums (gnb.parts = (buffer, tiles per image), consumed by gn_bwd)."""
         c = self._bwd_desc(cx.c)
         ci_cnt = c.Cin if ci_cnt is None else ci_cnt
         w = self.P[cx.wname + ".weight"]
@@ -402,7 +411,17 @@ class Builder:
         wp_t = self._wprep(c, w, 1, f16_grad=am is not None) if (whole or (c.KH == 1 and ci_off % 32 == 0 and ci_cnt % 4 == 0)) else None
         if wp_t is None:
             am = None
-        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate, wp_t=wp_t, dy_amax=am))
+        gn_arg = None
+        if (gnb is not None and self.fuse_gn_bwd and wp_t is not None and whole and not accumulate and c.KH == 3 and gnb.act == 1 and gnb.mode == 0
+                and gnb.drop_p == 0 and gnb.C0 + gnb.C1 == c.Cin):
+            cg = c if (gnb.C0, gnb.C1) == (c.C0, c.C1) else H.Conv(c.N, c.Hi, c.Wi, gnb.C0, gnb.C1, c.Cout, k=3, up=c.up, math=c.math)
+            nbytes, tiles = H.conv_gnbwd_bytes(cg, f16_grad=am is not None)
+            if nbytes:
+                part = self.p.buf(nbytes // 4)
+                gn_arg = (gnb.x0, gnb.C0, gnb.x1, gnb.C1, gnb.coef, part)
+                gnb.parts = (part, tiles)
+                c = cg
+        self.p.emit(H.op_conv_dgrad(c, dy, w, dx, ci_off=ci_off, ci_cnt=ci_cnt, accumulate=accumulate, wp_t=wp_t, dy_amax=am, gnb=gn_arg))
         if wp_t is not None:
             self.p.free(wp_t)
         return dx
@@ -582,6 +601,36 @@ class Builder:
         pl.free(mean, rstd, coef, wp)
         return y
 
+    def gn_conv_saved(self, x0, x1, gname, wname, up=False):
+        """Training form of GroupNorm + SiLU + 3x3 conv (module.py:241-242, 279-284: in_layers; no AdaGN, no dropout): the forward is the fused
+        launch of gn_conv, and the weight gradient recomputes act(a (x - mu) + b) on the raw two-source input while it stages X
+        (pdae_conv_gn_input_arm), so the activated tensor -- one write in gn_apply, one read each in the forward conv and the weight gradient, and its
+        slot among the saved activations -- does not exist.  Returns (y, GroupNorm ctx for gn_bwd, conv ctx) or None when the kernels do not
+        take the shape (the materialised form runs)."""
+        if not (self.save and self.fuse_gn and self.fuse_gn_train):
+            return None
+        N, Hh, W, C0 = x0.shape
+        C1 = 0 if x1 is None else x1.shape[3]
+        C = C0 + C1
+        w, b = self.P[wname + ".weight"], self.P[wname + ".bias"]
+        c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=3, up=up, math=self.math)
+        c.gn_in = True
+        if (wname + ".weight") not in self.Gr or c.wprep_bytes(0, gn=True) == 0 or not H.conv_wgrad_gn_ok(self._bwd_desc(c)):
+            return None
+        pl = self.p
+        gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]
+        mean, rstd, coef = pl.buf(N * GROUPS), pl.buf(N * GROUPS), pl.buf(3, N, C)
+        self._gn_stats_coef(x0, C0, x1, C1, N, Hh * W, gamma, beta, None, None, mean, rstd, coef)
+        wp = self._wprep(c, w, 0, gn=True)
+        y = pl.buf(N, c.Ho, c.Wo, c.Cout)
+        part, tpi = self._stats_buf(c)
+        pl.emit(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, b, y, stats=part))
+        self._note_stats(y, part, tpi)
+        pl.free(wp)
+        g = NS(x0=x0, x1=x1, C0=C0, C1=C1, N=N, H=Hh, W=W, gname=gname, ss=None, zss=None, act=1, mode=0, mean=mean, rstd=rstd, coef=coef, y=None,
+               xpool=None, drop_p=0.0, layer=0)
+        return y, g, NS(c=c, x0=x0, x1=x1, wname=wname, y=y, c1=None, gn=(coef, 1))
+
     def gn(self, x0, x1, gname, ss=None, zss=None, act=1, mode=0, want_xpool=False, dropout=False):
         """GroupNorm(32) [+AdaGN] [+SiLU] [+dropout] [+2x2 avg-pool].  Returns ctx with .y (.xpool)."""
         N, Hh, W, C0 = x0.shape
@@ -617,9 +666,16 @@ class Builder:
         dss = pl.buf(g.N, 2 * C) if (want_dss and g.ss is not None) else None
         dzss = pl.buf(g.N, 2 * C) if (want_dzss and g.zss is not None) else None
         pl.need_ws(H.gn_ws_bytes(g.N, C))
+        parts = getattr(g, "parts", None)                # left by the data gradient that wrote dA (conv_dgrad(gnb=g)); one use
+        if parts is not None:
+            assert bmode == 0 and g.drop_p == 0
+            g.parts = None
         idx = pl.emit(H.op_gn_bwd(g.x0, g.C0, g.x1, g.C1, g.N, g.H, g.W, GROUPS, g.coef, g.rstd, gamma, beta, g.ss, g.zss, dA, g.act,
                                   bmode, None, add=add, dx0=dx0, acc0=acc0, dx1=dx1, acc1=acc1, dgamma=dgamma, dbeta=dbeta, acc_param=self.acc, dss=dss,
-                                  dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0, dx0_amax=dx0_amax, ticket=pl.tickets(g.N)), ws_slot=16)
+                                  dzss=dzss, drop_p=g.drop_p, seed=g.layer, offset=0, dx0_amax=dx0_amax, ticket=None if parts else pl.tickets(g.N),
+                                  parts=parts[0] if parts else None, parts_tiles=parts[1] if parts else 0), ws_slot=16)
+        if parts is not None:
+            pl.free(parts[0])
         if g.drop_p > 0:
             pl.drop_ops.append((idx, 11, 12))
         return dss, dzss
@@ -632,6 +688,10 @@ class Builder:
         assert not (has_skip and (up or down)), "channel-changing up/down ResBlocks do not occur on this path"
         g1 = c1 = None
         h1 = None if down else self.gn_conv(x0, x1, pre + ".in_layers.0", pre + ".in_layers.2", up=up)       # fused when forward-only
+        if h1 is None and not down:
+            r = self.gn_conv_saved(x0, x1, pre + ".in_layers.0", pre + ".in_layers.2", up=up)                # fused in training as well
+            if r is not None:
+                h1, g1, c1 = r
         if h1 is None:
             g1 = self.gn(x0, x1, pre + ".in_layers.0", act=1, mode=1 if down else 0, want_xpool=down)
             h1, c1 = self.conv(g1.y, None, pre + ".in_layers.2", 3, up=up)
@@ -686,7 +746,7 @@ class Builder:
         C0, C1 = g1.C0, g1.C1
         # conv2
         self.conv_bwd_params(r.c2, dout, amax=dout_amax)
-        d_a2 = self.conv_dgrad(r.c2, dout, amax=dout_amax)
+        d_a2 = self.conv_dgrad(r.c2, dout, amax=dout_amax, gnb=g2)
         # channel-changing skip: 1x1 conv over the raw (concat) input
         dx0 = dx1 = None
         if r.has_skip:
@@ -707,8 +767,8 @@ class Builder:
         self.conv_bwd_params(r.c1, dh1, amax=am1)
         trainable_gn1 = (g1.gname + ".weight") in self.Gr
         if need_dx0 or need_dx1 or trainable_gn1:
-            d_a1 = self.conv_dgrad(r.c1, dh1, amax=am1)
             bmode = 1 if r.down else (2 if r.up else 0)
+            d_a1 = self.conv_dgrad(r.c1, dh1, amax=am1, gnb=g1 if bmode == 0 else None)
             if need_dx0 and dx0 is None:
                 dx0 = pl.buf(g1.N, g1.H, g1.W, C0)
             if need_dx1 and dx1 is None:

@@ -85,6 +85,8 @@ def lib():
         L.pdae_colsum_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int]
         L.pdae_colsum_workspace_bytes.restype = ctypes.c_size_t
         L.pdae_abi_version.restype = ctypes.c_int
+        L.pdae_conv_gnbwd_bytes.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p]
+        L.pdae_conv_gnbwd_bytes.restype = ctypes.c_size_t
         L.pdae_conv_stats_bytes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.pdae_conv_stats_bytes.restype = ctypes.c_size_t
         L.pdae_ssim_mse_workspace_bytes.restype = ctypes.c_size_t
@@ -98,20 +100,18 @@ def lib():
         L.pdae_image_prepare.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 9 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                                                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        L.pdae_wino_wprep_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
-        L.pdae_wino_wprep_bytes.restype = ctypes.c_size_t
-        L.pdae_wino_wprep.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        L.pdae_wino_wprep.restype = ctypes.c_int
-        L.pdae_wino_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [ctypes.c_void_p] * 5
-        L.pdae_wino_fwd.restype = ctypes.c_int
+        L.pdae_set_knob.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.pdae_set_knob.restype = ctypes.c_int
+        L.pdae_get_knob.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+        L.pdae_get_knob.restype = ctypes.c_int
         L.pdae_set_saturation_counter.argtypes = [ctypes.c_void_p]
         L.pdae_set_saturation_counter.restype = ctypes.c_int
         _lib = L
     return _lib
 
 
-EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv_wprep_bytes", "pdae_conv3x3_form", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_wino_wprep_bytes", "pdae_wino_wprep", "pdae_wino_fwd", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_knob", "pdae_get_knob", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv_gnbwd_bytes", "pdae_conv_gnbwd_arm", "pdae_gn_bwd_parts_arm", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
+           "pdae_conv2d_wgrad", "pdae_conv2d_wgrad_gn_ok", "pdae_conv_gn_input_arm", "pdae_conv_wprep_bytes", "pdae_conv3x3_form", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_subsample2", "pdae_zero_insert2", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_bwd_group", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
@@ -155,6 +155,22 @@ class SaturationGuard:
 
     def ptr(self):
         return self.t.data_ptr()
+
+
+def set_knob(name, value):
+    """Sets a tuning / A-B switch of the library (pdae_set_knob; names = the environment variables of DESIGN.md section 10, which are only read once, at
+    a knob's first use).  Do not change PDAE_W1 between preparing a convolution's weights and launching it: the launch is refused."""
+    rc = lib().pdae_set_knob(name.encode(), int(value))
+    if rc != 0:
+        raise PdaeError(f"pdae_set_knob failed ({rc}): {lib().pdae_last_error().decode()}")
+
+
+def get_knob(name):
+    v = ctypes.c_int(0)
+    rc = lib().pdae_get_knob(name.encode(), ctypes.byref(v))
+    if rc != 0:
+        raise PdaeError(f"pdae_get_knob failed ({rc}): {lib().pdae_last_error().decode()}")
+    return int(v.value)
 
 
 def saturated(device="cuda"):
@@ -305,35 +321,27 @@ def conv_fwd_skip_ok(c, cs):
     return bool(lib().pdae_conv2d_fwd_skip_ok(ctypes.byref(d), ctypes.byref(ds)))
 
 
-def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0, wp_t=None, dy_amax=None):
-    return make_op(OP_CONV_DGRAD, [dy, w, dx, wp_t, dy_amax], c.fields() + [ci_off, c.Cin if ci_cnt is None else ci_cnt, accumulate, tile])
+def op_conv_dgrad(c, dy, w, dx, ci_off=0, ci_cnt=None, accumulate=0, tile=0, wp_t=None, dy_amax=None, gnb=None):
+    """gnb = (x0, C0, x1, C1, coef, part): the launch also leaves the GroupNorm-backward sums of dx (pdae_conv_gnbwd_arm; conv_gnbwd_bytes(c) != 0)."""
+    op = make_op(OP_CONV_DGRAD, [dy, w, dx, wp_t, dy_amax], c.fields() + [ci_off, c.Cin if ci_cnt is None else ci_cnt, accumulate, tile])
+    if gnb is not None:
+        x0, C0, x1, C1, coef, part = gnb
+        op.p[5], op.p[6], op.p[7], op.p[8] = _ptr(x0), _ptr(x1), _ptr(coef), _ptr(part)
+        op.i[18], op.i[19], op.i[20] = int(C0), int(C1), 1
+    return op
+
+
+def conv_gnbwd_bytes(c, f16_grad=False):
+    """(bytes, tiles per image) of the GroupNorm-backward partial sums the data gradient of c can leave in its epilogue; (0, 0): not available."""
+    d = c.cdesc()
+    t = ctypes.c_int32(0)
+    b = lib().pdae_conv_gnbwd_bytes(ctypes.byref(d), 16 if f16_grad else 0, ctypes.byref(t))
+    return int(b), int(t.value)
 
 
 def op_amax(x, n, out):
     """out[0] = max |x| (device scalar): feeds the power-of-two dY scale of the fp16-format gradient kernels."""
     return make_op(OP_AMAX, [x, out], [n])
-
-
-def wino_wprep_bytes(c):
-    """Size of the Winograd-transformed weights of conv c (0: not eligible; pdae_wino_wprep_bytes)."""
-    d = c.cdesc()
-    return int(lib().pdae_wino_wprep_bytes(ctypes.byref(d)))
-
-
-def wino_wprep(c, w, wp, stream=None):
-    d = c.cdesc()
-    rc = lib().pdae_wino_wprep(ctypes.byref(d), ctypes.c_void_p(_ptr(w)), ctypes.c_void_p(_ptr(wp)), ctypes.c_void_p(current_stream_ptr() if stream is None else stream))
-    if rc != 0:
-        raise PdaeError(f"pdae_wino_wprep failed ({rc}): {lib().pdae_last_error().decode()}")
-
-
-def wino_fwd(c, x, wp, bias, y, stream=None):
-    """y = conv3x3(x) + bias through the Winograd F(2x2, 3x3) kernel (pdae_wino_fwd); wp from wino_wprep."""
-    d = c.cdesc()
-    rc = lib().pdae_wino_fwd(ctypes.byref(d), ctypes.c_void_p(_ptr(x)), ctypes.c_void_p(_ptr(wp)), ctypes.c_void_p(_ptr(bias) if bias is not None else None),
-                             ctypes.c_void_p(_ptr(y)), ctypes.c_void_p(current_stream_ptr() if stream is None else stream))
-    if rc != 0:
-        raise PdaeError(f"pdae_wino_fwd failed ({rc}): {lib().pdae_last_error().decode()}")
 
 
 def op_conv_wprep(c, w, transposed, wp):
@@ -382,9 +390,16 @@ def op_conv_wprep_group(jobs_t, first_t, njobs, total_blocks):
     return make_op(OP_CONV_WPREP_GROUP, [jobs_t, first_t], [njobs, total_blocks])
 
 
-def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0, db=None, dy_amax=None):
-    """dw (+)= weight gradient; db (optional): bias gradient = column sums of dy, same accumulate flag."""
-    return make_op(OP_CONV_WGRAD, [x0, x1, dy, dw, ws, db, dy_amax], c.fields() + [accumulate, ws_bytes])
+def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0, db=None, dy_amax=None, gn_coef=None, gn_act=1):
+    """dw (+)= weight gradient; db (optional): bias gradient = column sums of dy, same accumulate flag.
+    gn_coef: (x0, x1) are the RAW sources of a fused-GroupNorm forward (op_conv_fwd_gn); the kernel recomputes act(a (x - mu) + b) while it
+    stages X (pdae_conv_gn_input_arm; conv_wgrad_gn_ok(c) must hold)."""
+    return make_op(OP_CONV_WGRAD, [x0, x1, dy, dw, ws, db, dy_amax, gn_coef], c.fields() + [accumulate, ws_bytes, gn_act if gn_coef is not None else 0])
+
+
+def conv_wgrad_gn_ok(c):
+    d = c.cdesc()
+    return bool(lib().pdae_conv2d_wgrad_gn_ok(ctypes.byref(d)))
 
 
 def op_gemm(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha=1.0, bias=None, accumulate=0,
@@ -462,9 +477,11 @@ def op_gn_apply(x0, C0, x1, C1, N, H, W, coef, act, mode, y, xpool=None, drop_p=
 
 
 def op_gn_bwd(x0, C0, x1, C1, N, H, W, G, coef, rstd, gamma, beta, ss, zss, dA, act, mode, ws, add=None, dx0=None, acc0=0,
-              dx1=None, acc1=0, dgamma=None, dbeta=None, acc_param=0, dss=None, dzss=None, drop_p=0.0, seed=0, offset=0, dx0_amax=None, ticket=None):
-    return make_op(OP_GN_BWD, [x0, x1, coef, rstd, gamma, beta, ss, zss, dA, add, dx0, dx1, dgamma, dbeta, dss, dzss, ws, dx0_amax, ticket],
-                   [C0, C1, N, H, W, G, act, mode, acc0, acc1, acc_param, seed, offset], [drop_p])
+              dx1=None, acc1=0, dgamma=None, dbeta=None, acc_param=0, dss=None, dzss=None, drop_p=0.0, seed=0, offset=0, dx0_amax=None, ticket=None,
+              parts=None, parts_tiles=0):
+    """parts: the per-(n, c) sums were left by the data gradient that wrote dA (op_conv_dgrad(gnb=...)): no reduction pass (pdae_gn_bwd_parts_arm)."""
+    return make_op(OP_GN_BWD, [x0, x1, coef, rstd, gamma, beta, ss, zss, dA, add, dx0, dx1, dgamma, dbeta, dss, dzss, ws, dx0_amax, ticket, parts],
+                   [C0, C1, N, H, W, G, act, mode, acc0, acc1, acc_param, seed, offset, parts_tiles if parts is not None else 0], [drop_p])
 
 
 def op_mlp_modln_fwd(u, e, gamma, beta, R, C, norm, act, eps, y, mean, rstd):

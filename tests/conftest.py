@@ -24,6 +24,22 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture
+def knob():
+    """knob(name, value): sets a library switch through pdae_set_knob for the duration of the test (the library reads its environment only once,
+    at a knob's first use: tests cannot switch routing by editing os.environ)."""
+    from pdae_amd import hip
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = hip.get_knob(name)
+        hip.set_knob(name, int(value))
+    yield set_
+    for n, v in saved.items():
+        hip.set_knob(n, v)
+
+
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return {k: d[k] for k in d.files}

@@ -24,7 +24,7 @@ def test_header_symbols_exported(L):
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.pdae_abi_version() == 8
+    assert L.pdae_abi_version() == 9
 
 
 def test_struct_layout_matches_header():
@@ -88,12 +88,13 @@ def test_integration_md_snippet_runs_verbatim_on_gpu():
 test_integration_md_snippet_runs_verbatim_on_gpu = pytest.mark.gpu(test_integration_md_snippet_runs_verbatim_on_gpu)
 
 
-def test_winograd_form_routing_is_a_pure_function_of_descriptor_and_switch(monkeypatch):
+def test_winograd_form_routing_is_a_pure_function_of_descriptor_and_switch(knob):
     """pdae_conv3x3_form (host-only): which prepared-weight layout / kernel a 3x3 convolution gets.  Chip-filling layers of the FFHQ-128 step take the
     Winograd F(2,3)-along-x form (conv3x3y), layers with fewer than 256 tiles or a badly filled last round do not, PDAE_W1=0 switches it off,
-    PDAE_MATH_DIRECT in the descriptor pins the FORWARD form only, and preparation and launch read the same answer (it is read per call)."""
+    PDAE_MATH_DIRECT in the descriptor pins the FORWARD form only, and preparation and launch read the same answer (the knob registry; the
+    environment is read once)."""
     from pdae_amd import hip as H
-    monkeypatch.delenv("PDAE_W1", raising=False)
+    knob("PDAE_W1", 1)
     big = H.Conv(32, 128, 128, 128, 0, 128, k=3, math=4)                     # 2048 tiles
     wide32 = H.Conv(32, 32, 32, 256, 0, 256, k=3, math=4)                    # 256 tiles: one per CU
     small = H.Conv(32, 16, 16, 384, 0, 384, k=3, math=4)                     # 96 tiles
@@ -108,7 +109,7 @@ def test_winograd_form_routing_is_a_pure_function_of_descriptor_and_switch(monke
     assert pinned.fields()[13] == 4 | H.MATH_DIRECT and H.Conv(*[32, 128, 128, 128, 0, 128], math=pinned.fields()[13]).direct
     cs = H.Conv(32, 128, 128, 256, 0, 128, k=1, math=4)
     assert not H.conv_fwd_skip_ok(big, cs) and H.conv_fwd_skip_ok(pinned, cs)           # fused skip chunks: direct form only
-    monkeypatch.setenv("PDAE_W1", "0")
+    knob("PDAE_W1", 0)
     assert not big.winograd_form(0) and H.conv_fwd_skip_ok(big, cs)
-    monkeypatch.setenv("PDAE_W1", "2")
+    knob("PDAE_W1", 2)
     assert big.winograd_form(0) and not small.winograd_form(0)                          # 2 = every ELIGIBLE shape; a split-K plan stays direct

@@ -25,9 +25,9 @@ def H():
 
 
 @pytest.fixture(autouse=True)
-def _direct_form(monkeypatch):
+def _direct_form(knob):
     """These tests are about the two DIRECT kernels: the Winograd-along-x form (conv3x3y.hip, the default on chip-filling layers) is switched off."""
-    monkeypatch.setenv("PDAE_W1", "0")
+    knob("PDAE_W1", "0")
 
 
 def rn(seed, *shape, scale=1.0):
@@ -46,11 +46,11 @@ def nchw(t):
 KERNELS = ["r"]
 
 
-def _both(monkeypatch, run, kernel):
+def _both(knob, run, kernel):
     """run() under conv3x3p (PDAE_P3R=0) and under conv3x3r (PDAE_P3R=2): returns the two results."""
     out = []
     for on in (False, True):
-        monkeypatch.setenv("PDAE_P3R", "2" if on else "0")
+        knob("PDAE_P3R", "2" if on else "0")
         out.append(run())
         torch.cuda.synchronize()
     return out
@@ -76,7 +76,7 @@ def _gn_ref(x, gamma, beta, ss, G=32):
     (9, 96, 96, 32, 128, 0, 1),            # 324 tiles of 16 x 16: the persistent workgroups walk two tiles each (deferred epilogue, next-tile prefetch)
     (5, 80, 112, 64, 256, 0, 0),           # 350 tiles x 2 channel tiles = 700: three tiles per workgroup, ragged last round
 ])
-def test_forward_bit_identical_to_conv3x3p_and_close_to_fp64(H, monkeypatch, case, math_mode, kernel):
+def test_forward_bit_identical_to_conv3x3p_and_close_to_fp64(H, knob, case, math_mode, kernel):
     N, Hh, W, C, Cout, up, res_mode = case
     if N * Hh * W > 50000 and math_mode != 4:
         pytest.skip("large cases in the default arithmetic only")
@@ -100,7 +100,7 @@ def test_forward_bit_identical_to_conv3x3p_and_close_to_fp64(H, monkeypatch, cas
         y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
         H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, res=resd, res_mode=res_mode, wp=wp))
         return y
-    y_p, y_q = _both(monkeypatch, run, kernel)
+    y_p, y_q = _both(knob, run, kernel)
     assert rel_err(nchw(y_q), y_ref) < TOL[math_mode]
     assert torch.equal(y_p, y_q), float((y_p - y_q).abs().max())
 
@@ -113,7 +113,7 @@ def test_forward_bit_identical_to_conv3x3p_and_close_to_fp64(H, monkeypatch, cas
     (1, 32, 32, 32, 0, 256, 1, 2, True),       # upsampled input, half-resolution residual
     (6, 96, 128, 32, 32, 128, 0, 1, True),     # 288 tiles: two per persistent workgroup, coefficients of the NEXT image prefetched across the tile boundary
 ])
-def test_fused_groupnorm_input_bit_identical_and_close_to_fp64(H, monkeypatch, case, kernel):
+def test_fused_groupnorm_input_bit_identical_and_close_to_fp64(H, knob, case, kernel):
     N, Hh, W, C0, C1, Cout, up, res_mode, ada = case
     C, G = C0 + C1, 32
     Hs, Ws = (Hh // 2, W // 2) if up else (Hh, W)
@@ -143,14 +143,14 @@ def test_fused_groupnorm_input_bit_identical_and_close_to_fp64(H, monkeypatch, c
         y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
         H.run(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, bd, y, res=resd, res_mode=res_mode))
         return y
-    y_p, y_q = _both(monkeypatch, run, kernel)
+    y_p, y_q = _both(knob, run, kernel)
     assert rel_err(nchw(y_q), y_ref) < 1e-5
     assert torch.equal(y_p, y_q), float((y_p - y_q).abs().max())
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("case", [(16, 64, 32, 64, 64, 32, 128, True), (16, 64, 32, 32, 96, 0, 128, False), (8, 64, 64, 96, 32, 32, 256, False)])
-def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case, kernel):
+def test_fused_skip_chunks_and_output_statistics(H, knob, case, kernel):
     """conv3x3(x) + conv1x1([s0 | s1]) in one K loop (centre-tap chunks behind the main chunks), and the GroupNorm partial statistics of the
     output written by the epilogue: same tensor, and the same statistics after the reader's fp64 combine, as conv3x3p."""
     N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
@@ -189,7 +189,7 @@ def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case, kernel):
         m, r, k = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, Cout, device="cuda")
         H.run(H.op_gn_coef_from_conv_stats(N, Hh * W, Cout, 0, G, 1e-5, part, tpi, None, 0, g2, b2, None, None, m, r, k))
         return y, part, m, r
-    (y_p, part_p, m_p, r_p), (y_q, part_q, m_q, r_q) = _both(monkeypatch, run, kernel)
+    (y_p, part_p, m_p, r_p), (y_q, part_q, m_q, r_q) = _both(knob, run, kernel)
     assert rel_err(nchw(y_q), y_ref) < 1e-5
     assert torch.equal(y_p, y_q)
     assert torch.isfinite(part_q).all()
@@ -203,7 +203,7 @@ def test_fused_skip_chunks_and_output_statistics(H, monkeypatch, case, kernel):
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("gscale", [1.0, 3e-7, 2e4])
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 64), (1, 64, 32, 256, 128), (3, 160, 160, 128, 32)])
-def test_data_gradient_with_dynamic_fp16_scale(H, monkeypatch, case, gscale, kernel):
+def test_data_gradient_with_dynamic_fp16_scale(H, knob, case, gscale, kernel):
     """dX of a 3x3 convolution = the same kernel on transposed, tap-flipped prepared weights with the per-tensor power-of-two dY scale
     (pdae_amax): Cin of the convolution is the GEMM N here, so it must be a multiple of 128."""
     N, Hh, W, Cin, Cout = case
@@ -223,13 +223,13 @@ def test_data_gradient_with_dynamic_fp16_scale(H, monkeypatch, case, gscale, ker
         dx = torch.full((N, Hh, W, Cin), float("nan"), device="cuda")
         H.run(H.op_conv_dgrad(c, dyd, wd, dx, wp_t=wp_t, dy_amax=amax))
         return dx
-    dx_p, dx_q = _both(monkeypatch, run, kernel)
+    dx_p, dx_q = _both(knob, run, kernel)
     assert rel_err(nchw(dx_q), xr.grad) < 1e-5
     assert torch.equal(dx_p, dx_q)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-def test_accumulating_data_gradient(H, monkeypatch, kernel):
+def test_accumulating_data_gradient(H, knob, kernel):
     """accumulate = 1 (a second consumer's gradient joins the buffer): read-modify-write epilogue."""
     N, Hh, W, Cin, Cout = 2, 32, 16, 128, 32
     w = rn(2, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(9 * Cin))
@@ -244,16 +244,16 @@ def test_accumulating_data_gradient(H, monkeypatch, kernel):
         dx = base.clone().cuda()
         H.run(H.op_conv_dgrad(c, dyd, wd, dx, accumulate=1, wp_t=wp_t))
         return dx
-    dx_p, dx_q = _both(monkeypatch, run, kernel)
+    dx_p, dx_q = _both(knob, run, kernel)
     assert torch.equal(dx_p, dx_q)
     ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
     assert rel_err(nchw(dx_q) - base.permute(0, 3, 1, 2).double(), ref) < 1e-5
 
 
-def test_large_layers_with_default_routing(H, monkeypatch):
+def test_large_layers_with_default_routing(H, knob):
     """No override: a benchmark-sized layer (B=32, 64 x 64, 128 output channels = 512 tiles of 16 x 16) takes the default route (conv3x3r) and
     gives the tensor and the partial statistics conv3x3p gives."""
-    monkeypatch.delenv("PDAE_P3R", raising=False)
+    knob("PDAE_P3R", 1)
     N, Hh, W, C, Cout = 32, 64, 64, 32, 128
     x = rn(1, N, C, Hh, W)
     w = rn(2, Cout, C, 3, 3, scale=1.0 / math.sqrt(9 * C)); b = rn(3, Cout, scale=0.2)
@@ -265,7 +265,7 @@ def test_large_layers_with_default_routing(H, monkeypatch):
     outs = []
     for mode in (None, "0"):
         if mode is not None:
-            monkeypatch.setenv("PDAE_P3R", mode)
+            knob("PDAE_P3R", mode)
         y = torch.empty(N, Hh, W, Cout, device="cuda"); part = torch.zeros(nbytes // 4, device="cuda")
         H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, wp=wp, stats=part))
         outs.append((y, part.view(N, tpi, Cout // 4, 2)))

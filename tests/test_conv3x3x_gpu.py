@@ -36,11 +36,11 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).double().cpu()
 
 
-def _both(monkeypatch, run):
+def _both(knob, run):
     """run() = weight preparation + launch, under the direct kernels (PDAE_W1=0) and under the Winograd-along-x form (PDAE_W1=2)."""
     out = []
     for on in ("0", "2"):
-        monkeypatch.setenv("PDAE_W1", on)
+        knob("PDAE_W1", on)
         out.append(run())
         torch.cuda.synchronize()
     return out
@@ -64,7 +64,7 @@ def _gn_ref(x, gamma, beta, ss, G=32):
     (2, 96, 32, 128, 128, 0, 0),           # interior tile rows see no zero padding at top / bottom
     (5, 80, 112, 64, 256, 0, 1),           # 350 tiles x 2 channel tiles
 ])
-def test_forward_vs_fp64_and_direct(H, monkeypatch, case, math_mode):
+def test_forward_vs_fp64_and_direct(H, knob, case, math_mode):
     N, Hh, W, C, Cout, up, res_mode = case
     if N * Hh * W > 30000 and math_mode != 4:
         pytest.skip("large cases in the default arithmetic only")
@@ -88,7 +88,7 @@ def test_forward_vs_fp64_and_direct(H, monkeypatch, case, math_mode):
         y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
         H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, res=resd, res_mode=res_mode, wp=wp))
         return y
-    y_p, y_x = _both(monkeypatch, run)
+    y_p, y_x = _both(knob, run)
     e_p, e_x = rel_err(nchw(y_p), y_ref), rel_err(nchw(y_x), y_ref)
     print(f"[conv3x3x fwd math {math_mode}] {case}: vs fp64 {e_x:.2e} (direct {e_p:.2e})")
     assert e_x < TOL[math_mode], (e_x, e_p)
@@ -105,7 +105,7 @@ def test_forward_vs_fp64_and_direct(H, monkeypatch, case, math_mode):
     (1, 32, 32, 32, 0, 256, 1, 2, True),       # upsampled input, half-resolution residual
     (3, 96, 128, 32, 32, 128, 0, 1, True),
 ])
-def test_fused_groupnorm_input_vs_fp64(H, monkeypatch, case):
+def test_fused_groupnorm_input_vs_fp64(H, knob, case):
     N, Hh, W, C0, C1, Cout, up, res_mode, ada = case
     C, G = C0 + C1, 32
     Hs, Ws = (Hh // 2, W // 2) if up else (Hh, W)
@@ -135,24 +135,24 @@ def test_fused_groupnorm_input_vs_fp64(H, monkeypatch, case):
         y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
         H.run(H.op_conv_fwd_gn(c, x0, x1, coef, 1, wp, bd, y, res=resd, res_mode=res_mode))
         return y
-    y_p, y_x = _both(monkeypatch, run)
+    y_p, y_x = _both(knob, run)
     e_x = rel_err(nchw(y_x), y_ref)
     print(f"[conv3x3x fused GN] {case}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(y_p), y_ref):.2e})")
     assert e_x < 1e-5
 
 
 @pytest.mark.parametrize("case", [(16, 64, 32, 32, 96, 0, 128), (8, 64, 64, 96, 32, 32, 256)])
-def test_fused_skip_chunks_exist_in_the_direct_form_only(H, monkeypatch, case):
+def test_fused_skip_chunks_exist_in_the_direct_form_only(H, knob, case):
     """A convolution launched in the Winograd-along-x form takes no fused 1x1 skip chunks: pdae_conv2d_fwd_skip_ok says no (the caller computes the
     skip convolution separately and hands it in as the residual -- engine.resblock), pdae_conv_skip_wprep_bytes is 0 and the launch itself refuses.
     The same pair IS eligible when the form is off."""
     N, Hh, W, C, Cs0, Cs1, Cout = case
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
     cs = H.Conv(N, Hh, W, Cs0, Cs1, Cout, k=1, math=4)
-    monkeypatch.setenv("PDAE_W1", "0")
+    knob("PDAE_W1", "0")
     assert H.conv_fwd_skip_ok(c, cs) and H.conv_skip_wprep_bytes(c, cs) > 0
     nb_skip = H.conv_skip_wprep_bytes(c, cs)
-    monkeypatch.setenv("PDAE_W1", "2")
+    knob("PDAE_W1", "2")
     assert not H.conv_fwd_skip_ok(c, cs) and H.conv_skip_wprep_bytes(c, cs) == 0
     x = torch.randn(N, Hh, W, C, device="cuda"); s0 = torch.randn(N, Hh, W, Cs0, device="cuda")
     s1 = torch.randn(N, Hh, W, Cs1, device="cuda") if Cs1 else None
@@ -167,11 +167,11 @@ def test_fused_skip_chunks_exist_in_the_direct_form_only(H, monkeypatch, case):
 
 
 @pytest.mark.parametrize("case", [(16, 64, 32, 32, 96, 0, 128, False), (8, 64, 64, 96, 32, 32, 256, True)])
-def test_direct_bit_in_the_descriptor_keeps_the_fused_skip(H, monkeypatch, case):
+def test_direct_bit_in_the_descriptor_keeps_the_fused_skip(H, knob, case):
     """pdae_conv_desc.math | PDAE_MATH_DIRECT (hip.Conv(direct=True)): the FORWARD form of that convolution stays direct under PDAE_W1 -- prepared weights
     and launch agree because both read the same descriptor --, so the fused skip launch is offered and correct; the data gradient through the same
     descriptor ignores the bit and stays in the Winograd form.  (engine.Builder._skip_parts pins wide-skip ResBlocks this way.)"""
-    monkeypatch.setenv("PDAE_W1", "2")
+    knob("PDAE_W1", "2")
     N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
     Cs, G = Cs0 + Cs1, 32
     x = rn(1, N, C, Hh, W) * 1.2 + 0.3
@@ -210,7 +210,7 @@ def test_direct_bit_in_the_descriptor_keeps_the_fused_skip(H, monkeypatch, case)
 
 
 @pytest.mark.parametrize("case", [(16, 64, 32, 64, 128, True, 0), (16, 64, 32, 32, 128, False, 1), (8, 64, 64, 96, 256, True, 1)])
-def test_output_statistics_from_the_epilogue(H, monkeypatch, case):
+def test_output_statistics_from_the_epilogue(H, knob, case):
     """The GroupNorm partial statistics of the output ((sum, sum of squares) per wave tile and channel quad, written by the epilogue: plain and
     fused-GroupNorm launches, with and without a residual), after the reader's fp64 combine (pdae_gn_coef_from_conv_stats)."""
     N, Hh, W, C, Cout, use_gn, res_mode = case
@@ -245,7 +245,7 @@ def test_output_statistics_from_the_epilogue(H, monkeypatch, case):
         m, r, k = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, Cout, device="cuda")
         H.run(H.op_gn_coef_from_conv_stats(N, Hh * W, Cout, 0, G, 1e-5, part, tpi, None, 0, g2, b2, None, None, m, r, k))
         return y, part, m, r
-    (y_p, part_p, m_p, r_p), (y_x, part_x, m_x, r_x) = _both(monkeypatch, run)
+    (y_p, part_p, m_p, r_p), (y_x, part_x, m_x, r_x) = _both(knob, run)
     e_x = rel_err(nchw(y_x), y_ref)
     print(f"[conv3x3x statistics] {case}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(y_p), y_ref):.2e})")
     assert e_x < 1e-5
@@ -259,7 +259,7 @@ def test_output_statistics_from_the_epilogue(H, monkeypatch, case):
 
 @pytest.mark.parametrize("gscale", [1.0, 3e-7, 2e4])
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 64), (1, 64, 32, 256, 128), (3, 160, 160, 128, 32)])
-def test_data_gradient_with_dynamic_fp16_scale(H, monkeypatch, case, gscale):
+def test_data_gradient_with_dynamic_fp16_scale(H, knob, case, gscale):
     """dX of a 3x3 convolution = the same kernel on transposed, tap-flipped prepared weights (wprepx_slot's transposed form) with the
     per-tensor power-of-two dY scale: Cin of the convolution is the GEMM N here, so it must be a multiple of 128."""
     N, Hh, W, Cin, Cout = case
@@ -279,13 +279,13 @@ def test_data_gradient_with_dynamic_fp16_scale(H, monkeypatch, case, gscale):
         dx = torch.full((N, Hh, W, Cin), float("nan"), device="cuda")
         H.run(H.op_conv_dgrad(c, dyd, wd, dx, wp_t=wp_t, dy_amax=amax))
         return dx
-    dx_p, dx_x = _both(monkeypatch, run)
+    dx_p, dx_x = _both(knob, run)
     e_x = rel_err(nchw(dx_x), xr.grad)
     print(f"[conv3x3x dgrad] {case} x{gscale}: vs fp64 {e_x:.2e} (direct {rel_err(nchw(dx_p), xr.grad):.2e})")
     assert e_x < 1e-5
 
 
-def test_accumulating_data_gradient(H, monkeypatch):
+def test_accumulating_data_gradient(H, knob):
     """accumulate = 1 (a second consumer's gradient joins the buffer): read-modify-write epilogue."""
     N, Hh, W, Cin, Cout = 2, 32, 16, 128, 32
     w = rn(2, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(9 * Cin))
@@ -300,15 +300,15 @@ def test_accumulating_data_gradient(H, monkeypatch):
         dx = base.clone().cuda()
         H.run(H.op_conv_dgrad(c, dyd, wd, dx, accumulate=1, wp_t=wp_t))
         return dx
-    dx_p, dx_x = _both(monkeypatch, run)
+    dx_p, dx_x = _both(knob, run)
     ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)
     assert rel_err(nchw(dx_x) - base.permute(0, 3, 1, 2).double(), ref) < 1e-5
 
 
-def test_grouped_weight_preparation_uses_the_same_form(H, monkeypatch):
+def test_grouped_weight_preparation_uses_the_same_form(H, knob):
     """pdae_conv_wprep_job / pdae_conv_wprep_group (one launch for every prepared copy of a plan) must write the same Winograd-form planes as
     pdae_conv_wprep: forward, fused-GroupNorm forward and data-gradient (transposed, fp16 gradient format) jobs."""
-    monkeypatch.setenv("PDAE_W1", "2")
+    knob("PDAE_W1", "2")
     N, Hh, W, C, Cout = 32, 64, 64, 64, 128
     w = nhwc(rn(1, Cout, C, 3, 3, scale=0.05)).cuda()
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
@@ -325,7 +325,87 @@ def test_grouped_weight_preparation_uses_the_same_form(H, monkeypatch):
     torch.cuda.synchronize()
     for s_, (_, g_) in zip(singles, jobs):
         assert torch.equal(s_, g_) and float(s_.abs().max()) > 0
-    monkeypatch.setenv("PDAE_W1", "0")
+    knob("PDAE_W1", "0")
     a0 = torch.zeros_like(singles[0])
     H.run(H.op_conv_wprep(c, w, 0, a0))
     assert not torch.equal(a0, singles[0])               # the direct layout differs
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 128, 0, 32), (1, 64, 32, 128, 128, 32), (3, 48, 80, 64, 64, 32), (2, 128, 128, 128, 0, 32), (5, 32, 16, 256, 128, 32),
+                                  (8, 128, 64, 128, 0, 64)])      # (a launch the direct plan would split over K keeps the direct form: one chunk, or 512 tiles)
+def test_groupnorm_backward_sums_from_the_data_gradient_epilogue(H, knob, case):
+    """pdae_conv_gnbwd_arm (round 5): the Winograd-form data gradient leaves sum dv and sum dv (x - mu), dv = dA silu'(a (x - mu) + b), per (image,
+    16 x 16 tile, channel) while it stores dA, and pdae_gn_bwd finalizes from them (pdae_gn_bwd_parts_arm) instead of running its reduction pass
+    over (x, dA) (module.py:241,257: autograd of GroupNorm -> SiLU in front of a 3x3 convolution).  Checked: the partial sums against fp64 on the
+    SAME dA, and the whole GroupNorm backward (dx, dgamma, dbeta) against the reduction-pass form on the same tensors."""
+    N, Hh, W, C0, C1, Cout = case
+    C, G = C0 + C1, 32
+    knob("PDAE_W1", 2)
+    x = rn(1, N, C, Hh, W) * 1.5 + 0.7
+    gamma, beta = 1 + 0.2 * rn(2, C), 0.2 * rn(3, C) + 0.3
+    w = rn(4, Cout, C, 3, 3, scale=1.0 / math.sqrt(9 * C))
+    dy = rn(5, N, Cout, Hh, W) * 2e-3
+    c = H.Conv(N, Hh, W, C0, C1, Cout, k=3, math=4)
+    nb, tiles = H.conv_gnbwd_bytes(c, f16_grad=True)
+    assert nb == N * tiles * C * 2 * 4 and tiles == (Hh // 16) * (W // 16)
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous()
+    x1 = xh[..., C0:].contiguous() if C1 else None
+    mean = torch.empty(N * G, device="cuda"); rstd = torch.empty(N * G, device="cuda")
+    wsg = torch.empty(H.gn_ws_bytes(N, C) // 4 + 64, device="cuda")
+    H.run(H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, G, 1e-5, mean, rstd, wsg))
+    coef = torch.empty(3, N, C, device="cuda")
+    H.run(H.op_gn_coef(N, C, G, mean, rstd, gamma.cuda(), beta.cuda(), None, None, coef))
+    wd, dyd = nhwc(w).cuda(), nhwc(dy).cuda()
+    amax = torch.empty(4, device="cuda")
+    H.run(H.op_amax(dyd, dyd.numel(), amax))
+    wp_t = torch.empty(c.wprep_bytes(1, force=True, f16_grad=True) // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 1 | 16, wp_t))
+    dA = torch.full((N, Hh, W, C), float("nan"), device="cuda")
+    part = torch.full((nb // 4,), float("nan"), device="cuda")
+    H.run(H.op_conv_dgrad(c, dyd, wd, dA, wp_t=wp_t, dy_amax=amax, gnb=(x0, C0, x1, C1, coef, part)))
+    dA2 = torch.empty_like(dA)
+    H.run(H.op_conv_dgrad(c, dyd, wd, dA2, wp_t=wp_t, dy_amax=amax))
+    assert torch.equal(dA, dA2)                                           # the extra epilogue work does not touch the values stored
+    # the sums in fp64 from the stored dA
+    cf = coef.double().cpu()                                               # [3][N][C]
+    xd, dAd = xh.double().cpu(), dA.double().cpu()                         # [N][H][W][C]
+    xm = xd - cf[0].view(N, 1, 1, C)
+    z = cf[1].view(N, 1, 1, C) * xm + cf[2].view(N, 1, 1, C)
+    sg = torch.sigmoid(z)
+    dv = dAd * sg * (1 + z * (1 - sg))
+    s0 = dv.view(N, Hh // 16, 16, W // 16, 16, C).sum((2, 4)).reshape(N, tiles, C)
+    s1 = (dv * xm).view(N, Hh // 16, 16, W // 16, 16, C).sum((2, 4)).reshape(N, tiles, C)
+    p = part.view(N, tiles, C, 2).double().cpu()
+    scale0, scale1 = float(dv.abs().sum((1, 2)).max()) / tiles, float((dv * xm).abs().sum((1, 2)).max()) / tiles     # cancellation-free magnitudes
+    assert float((p[..., 0] - s0).abs().max()) < 2e-6 * scale0 and float((p[..., 1] - s1).abs().max()) < 2e-6 * scale1
+    # whole GroupNorm backward: finalize + apply from the epilogue's sums vs the reduction-pass form
+    outs = []
+    for use_parts in (False, True):
+        dx0 = torch.empty(N, Hh, W, C0, device="cuda"); dx1 = torch.empty(N, Hh, W, C1, device="cuda") if C1 else None
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        H.run(H.op_gn_bwd(x0, C0, x1, C1, N, Hh, W, G, coef, rstd, gamma.cuda(), beta.cuda(), None, None, dA, 1, 0, wsg, dx0=dx0, dx1=dx1, dgamma=dg, dbeta=db,
+                          parts=part if use_parts else None, parts_tiles=tiles))
+        outs.append((dx0, dx1, dg, db))
+    for a, b in zip(outs[0], outs[1]):
+        if a is not None:
+            assert rel_err(b, a) < 2e-5
+    # one-shot: nothing stays armed
+    H.run(H.op_conv_dgrad(c, dyd, wd, dA2, wp_t=wp_t, dy_amax=amax))
+    assert torch.equal(dA, dA2)
+
+
+def test_groupnorm_backward_sums_are_refused_where_not_built(H, knob):
+    knob("PDAE_W1", 2)
+    assert H.conv_gnbwd_bytes(H.Conv(2, 32, 32, 128, 0, 32, k=3, math=3))[0] == 0                   # bf16x6: the direct kernels
+    assert H.conv_gnbwd_bytes(H.Conv(2, 32, 32, 128, 0, 32, k=3, math=4), f16_grad=False)[0] == 0   # without dy_amax the data gradient runs bf16x6
+    assert H.conv_gnbwd_bytes(H.Conv(2, 32, 32, 96, 32, 32, k=3, math=4), f16_grad=True)[0] > 0
+    assert H.conv_gnbwd_bytes(H.Conv(2, 32, 32, 112, 16, 32, k=3, math=4), f16_grad=True)[0] == 0   # sources must be whole 32-channel runs
+    assert H.conv_gnbwd_bytes(H.Conv(2, 32, 32, 64, 0, 32, k=3, math=4), f16_grad=True)[0] == 0     # GEMM N = 64: not the Winograd form
+    assert H.conv_gnbwd_bytes(H.Conv(1, 144, 144, 128, 0, 32, k=3, math=4), f16_grad=True)[0] == 0  # 81 tiles per image > 64
+    c = H.Conv(2, 32, 32, 64, 0, 64, k=3, math=4)
+    x = torch.zeros(2, 32, 32, 64, device="cuda"); coef = torch.zeros(3, 2, 64, device="cuda"); w = torch.zeros(64, 3, 3, 64, device="cuda")
+    wp_t = torch.empty(c.wprep_bytes(1, force=True) // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, w, 1, wp_t))
+    with pytest.raises(H.PdaeError):
+        H.run(H.op_conv_dgrad(c, x, w, x.clone(), wp_t=wp_t, gnb=(x, 64, None, 0, coef, torch.zeros(4096, device="cuda"))))

@@ -32,13 +32,14 @@ def rel(a, b):
 
 
 def both(fn):
+    from pdae_amd import hip
     out = []
-    for sw in ("1", "0"):
-        os.environ["PDAE_EDGE"] = sw
+    for sw in (1, 0):
+        hip.set_knob("PDAE_EDGE", sw)
         try:
             out.append(fn())
         finally:
-            os.environ.pop("PDAE_EDGE", None)
+            hip.set_knob("PDAE_EDGE", 1)
     return out
 
 

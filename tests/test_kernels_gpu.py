@@ -597,10 +597,10 @@ def test_conv_with_fused_groupnorm_input(H, case, math_mode):
 
 @pytest.mark.parametrize("math_mode", [1, 3, 4])
 @pytest.mark.parametrize("case", [(16, 64, 32, 64, 64, 32, 64, True), (16, 64, 32, 64, 96, 0, 128, False), (32, 32, 32, 32, 32, 32, 32, True)])
-def test_conv_with_fused_skip_connection(H, monkeypatch, case, math_mode):
+def test_conv_with_fused_skip_connection(H, knob, case, math_mode):
     """pdae_conv2d_fwd_skip: conv3x3(in) + conv1x1([s0 | s1]) + both biases in one launch, with plain and fused-GroupNorm main input.
     (Fused skip chunks exist in the direct form only: the Winograd-along-x form of chip-filling layers is switched off here.)"""
-    monkeypatch.setenv("PDAE_W1", "0")
+    knob("PDAE_W1", "0")
     N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
     Cs, G = Cs0 + Cs1, 32
     tol = MATH_TOL[math_mode]
@@ -640,13 +640,13 @@ def test_conv_with_fused_skip_connection(H, monkeypatch, case, math_mode):
                                   # split-K launches (small layers): the statistics come from the slab reduction
                                   (32, 8, 8, 512, 0, 512, "plain"), (32, 16, 16, 384, 0, 384, "plain"), (4, 16, 16, 128, 0, 128, "gn"),
                                   (8, 32, 32, 256, 0, 256, "plain"), (3, 16, 16, 96, 32, 128, "gn")])
-def test_groupnorm_statistics_from_the_producing_convolution(H, monkeypatch, case):
+def test_groupnorm_statistics_from_the_producing_convolution(H, knob, case):
     """pdae_conv_stats_arm + pdae_gn_coef_from_conv_stats: the 3x3 forward kernels (plain, fused-GroupNorm input, fused skip, image-pair tiles,
     odd batch) leave per-wave (sum, sum of squares) of their OUTPUT behind, and the next GroupNorm's mean / rstd / coefficients computed from
     them match the statistics pass over the stored tensor -- alone and as the second source of a two-tensor concat."""
     N, Hh, W, C0, C1, Cout, form = case
     if form == "skip":
-        monkeypatch.setenv("PDAE_W1", "0")          # fused skip chunks exist in the direct form only
+        knob("PDAE_W1", "0")          # fused skip chunks exist in the direct form only
     C, G = C0 + C1, 32
     x = rn(1, N, C, Hh, W) * 1.3 + 0.4
     w = rn(2, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9)); b = rn(3, Cout, scale=0.5) + 0.8       # a mean well away from zero
@@ -821,11 +821,11 @@ def test_grouped_linear_with_a_sampling_batch_over_32_rows(H):
         assert ctx.Nb == Nb and rel_err(y, x.double() @ P[f"l{i}.weight"].double().T + P[f"l{i}.bias"].double()) < 1e-6
 
 
-def test_grouped_weight_preparation_equals_the_single_launches(H, monkeypatch):
+def test_grouped_weight_preparation_equals_the_single_launches(H, knob):
     """pdae_conv_wprep_group: every prepared-weight form the engine uses (3x3 forward, fused-GroupNorm two-source, data-gradient in the exact
     and the fp16-gradient format, 1x1 forward / data gradient, fused skip chunks; bf16 and split formats) written by ONE launch from a job
     table equals, bit for bit, what pdae_conv_wprep / pdae_conv_skip_wprep write one launch at a time."""
-    monkeypatch.setenv("PDAE_W1", "0")              # the fused-skip job below exists in the direct form only (Winograd-form jobs: tests/test_conv3x3x_gpu.py)
+    knob("PDAE_W1", "0")              # the fused-skip job below exists in the direct form only (Winograd-form jobs: tests/test_conv3x3x_gpu.py)
     jobs, singles, keep = [], [], []                # a job holds raw pointers: the weights must outlive the grouped launch
 
     def add(c, w, flags, nbytes):
@@ -860,3 +860,63 @@ def test_grouped_weight_preparation_equals_the_single_launches(H, monkeypatch):
     for k, (a, b) in enumerate(singles):
         fin = torch.isfinite(a)                     # split-K slab space behind the planes is not written by a preparation
         assert torch.equal(a[fin].view(torch.int32), b[fin].view(torch.int32)) and torch.equal(fin, torch.isfinite(b)), k
+
+
+@pytest.mark.parametrize("math_mode", [1, 3, 4])
+@pytest.mark.parametrize("case", [(8, 32, 32, 64, 32, 64, 0, 1), (16, 16, 32, 32, 0, 96, 0, 1), (8, 16, 16, 96, 64, 160, 1, 1), (8, 32, 32, 128, 128, 128, 0, 1),
+                                  (22, 24, 16, 32, 32, 36, 0, 0)])      # (the weight-gradient kernel takes launches of >= 64 pixel tiles)
+def test_weight_gradient_with_fused_groupnorm_input(H, case, math_mode):
+    """pdae_conv_gn_input_arm + pdae_conv2d_wgrad: dW / db of conv3x3(act(GroupNorm(x))) with the activation recomputed on the RAW two-source input
+    inside the weight-gradient kernel's X staging (round 5: the in_layers stage of a trained ResBlock never writes its activated tensor,
+    module.py:241-242) -- against fp64 autograd and against the same kernel fed the materialised activation."""
+    N, Hh, W, C0, C1, Cout, up, act = case
+    C, G = C0 + C1, 32
+    x = rn(1, N, C, Hh, W) * 1.5 + 0.7
+    gamma, beta = 1 + 0.2 * rn(2, C), 0.2 * rn(3, C) + 0.5          # beta offset: act(b - a mu) != 0 would expose a wrong padding
+    c = H.Conv(N, Hh, W, C0, C1, Cout, k=3, up=bool(up), math=math_mode)
+    dy = rn(5, N, Cout, c.Ho, c.Wo) * 3e-3
+    w = rn(6, Cout, C, 3, 3, scale=1.0 / math.sqrt(C * 9))
+    a_ref = _gn_ref(x.double(), gamma.double(), beta.double(), None, None, act)
+    wr = w.double().requires_grad_(True)
+    (ref_conv(a_ref, wr, None, 1, 1, up) * dy.double()).sum().backward()
+    assert H.conv_wgrad_gn_ok(c)
+    xh = nhwc(x).cuda()
+    x0 = xh[..., :C0].contiguous()
+    x1 = xh[..., C0:].contiguous() if C1 else None
+    mean = torch.empty(N * G, device="cuda"); rstd = torch.empty(N * G, device="cuda")
+    H.run(H.op_gn_stats(x0, C0, x1, C1, N, Hh * W, G, 1e-5, mean, rstd, ws(H.gn_ws_bytes(N, C))))
+    coef = torch.empty(3, N, C, device="cuda")
+    H.run(H.op_gn_coef(N, C, G, mean, rstd, gamma.cuda(), beta.cuda(), None, None, coef))
+    dyd = nhwc(dy).cuda()
+    am = torch.empty(4, device="cuda")
+    H.run(H.op_amax(dyd, dyd.numel(), am))
+    wsb = c.wgrad_ws_bytes()
+    dw, db = torch.empty(Cout, 3, 3, C, device="cuda"), torch.empty(Cout, device="cuda")
+    H.run(H.op_conv_wgrad(c, x0, x1, dyd, dw, ws(wsb), wsb, db=db, dy_amax=am if math_mode == 4 else None, gn_coef=coef, gn_act=act))
+    tol = {1: 2e-2, 3: 2e-5, 4: 2e-5}[math_mode]
+    assert rel_err(dw.permute(0, 3, 1, 2), wr.grad) < tol
+    assert rel_err(db, dy.double().sum((0, 2, 3))) < 1e-5
+    # the materialised form on the same kernel: gn_apply -> single-source weight gradient
+    a = torch.empty(N, Hh, W, C, device="cuda")
+    H.run(H.op_gn_apply(x0, C0, x1, C1, N, Hh, W, coef, act, 0, a))
+    c1 = H.Conv(N, Hh, W, C, 0, Cout, k=3, up=bool(up), math=math_mode)
+    wsb1 = c1.wgrad_ws_bytes()
+    dw2 = torch.empty_like(dw)
+    H.run(H.op_conv_wgrad(c1, a, None, dyd, dw2, ws(wsb1), wsb1, dy_amax=am if math_mode == 4 else None))
+    assert rel_err(dw, dw2) < (1e-6 if math_mode != 1 else 1e-2)
+    # the request is one-shot: the next plain launch on the raw tensor must NOT see it
+    if C1 == 0:
+        dw3 = torch.empty_like(dw)
+        H.run(H.op_conv_wgrad(c1, x0, None, dyd, dw3, ws(wsb1), wsb1, dy_amax=am if math_mode == 4 else None))
+        assert rel_err(dw3, dw2) > 1e-2
+
+
+def test_weight_gradient_gn_input_refuses_ineligible_shapes(H):
+    assert not H.conv_wgrad_gn_ok(H.Conv(2, 8, 8, 32, 0, 32, k=3, math=4))          # 8-wide: image-pair tiles
+    assert not H.conv_wgrad_gn_ok(H.Conv(2, 16, 16, 48, 16, 32, k=3, math=4))       # sources are not whole 32-channel chunks
+    assert not H.conv_wgrad_gn_ok(H.Conv(2, 16, 16, 32, 0, 32, k=1, pad=0, math=4))
+    c = H.Conv(2, 8, 8, 32, 0, 32, k=3, math=3)
+    x = torch.zeros(2, 8, 8, 32, device="cuda"); coef = torch.zeros(3, 2, 32, device="cuda"); dw = torch.zeros(32, 3, 3, 32, device="cuda")
+    wsb = c.wgrad_ws_bytes()
+    with pytest.raises(H.PdaeError):
+        H.run(H.op_conv_wgrad(c, x, None, x, dw, ws(wsb), wsb, gn_coef=coef, gn_act=1))

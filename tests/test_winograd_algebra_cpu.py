@@ -63,7 +63,7 @@ def test_weight_gradient_f32_identity():
 
 
 def test_2d_f2x2_3x3_identity_of_the_gated_probe():
-    """winograd.hip (pdae_wino_fwd): V = B^T d B, U = G g G^T, Y = A^T (U * V) A on a 4 x 4 input tile."""
+    """tools/probes/r04_winograd/winograd.hip (the gated 2-D probe of round 4, no longer in the library): V = B^T d B, U = G g G^T, Y = A^T (U * V) A on a 4 x 4 input tile."""
     rng = np.random.default_rng(2)
     d = rng.standard_normal((4, 4)); g = rng.standard_normal((3, 3))
     ref = np.array([[(d[i:i + 3, j:j + 3] * g).sum() for j in range(2)] for i in range(2)])

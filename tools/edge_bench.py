@@ -1,4 +1,4 @@
-"""The 3-channel edge layers at the bench shapes: time per launch with PDAE_EDGE=1 / 0 (same process: the switch is read per call) and the
+"""The 3-channel edge layers at the bench shapes: time per launch with PDAE_EDGE=1 / 0 (same process: pdae_set_knob) and the
 error of both against an fp64 convolution.  Usage: python tools/edge_bench.py [N] [size] [C]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -49,11 +49,11 @@ def case(name, Cin, Cout, kinds):
         op, err = ops[k]
         out = []
         for sw in ("1", "0"):
-            os.environ["PDAE_EDGE"] = sw
+            H.set_knob("PDAE_EDGE", int(sw))
             us = timed(op)
             out.append(f"EDGE={sw}: {us:7.1f} us" + (f" err {err():.2e}" if err else ""))
         print(f"{name:28s} {k:6s} " + "   ".join(out), flush=True)
-    os.environ.pop("PDAE_EDGE", None)
+    H.set_knob("PDAE_EDGE", 1)
 
 
 case(f"head {C}->3 @{S} N={N}", C, 3, ["fwd", "dgrad", "wgrad"])

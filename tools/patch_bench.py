@@ -45,7 +45,7 @@ for (N, S, C0, C1, Cout) in SHAPES:
         t = {}
         for rep in range(2):
             for mode, r_ in (("p", "0"), ("r", "2")):
-                os.environ["PDAE_P3R"] = r_
+                H.set_knob("PDAE_P3R", int(r_))
                 t[mode] = min(t.get(mode, 1e9), timeit(op))
         line += f"  {name}: p {t['p']:.3f} ms {fl/t['p']/1e9:4.0f} TF | r {t['r']:.3f} {fl/t['r']/1e9:4.0f} TF ({t['p']/t['r']:.2f}x) |"
     print(line, flush=True)

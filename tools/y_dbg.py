@@ -7,7 +7,7 @@ N, S, W, Cin, Cout = 2, 32, 16, 32, 128
 x = torch.randn(N, S, W, Cin, device="cuda"); w = torch.randn(Cout, 3, 3, Cin, device="cuda") / (Cin * 9) ** 0.5; b = torch.randn(Cout, device="cuda")
 outs = {}
 for mode in ("0", "2"):
-    os.environ["PDAE_W1"] = mode
+    H.set_knob("PDAE_W1", int(mode))
     c = H.Conv(N, S, W, Cin, 0, Cout, k=3, math=int(os.environ.get("MATH", "4")))
     wp = torch.empty(c.wprep_bytes(0, force=True) // 4, device="cuda"); H.run(H.op_conv_wprep(c, w, 0, wp))
     y = torch.full((N, S, W, Cout), float("nan"), device="cuda")
