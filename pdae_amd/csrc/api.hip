@@ -35,7 +35,7 @@ static inline hipStream_t S(pdae_stream_t s) { return (hipStream_t)s; }
 static const struct { const char* name; int def; } g_knob_def[KNOB_COUNT] = {
     {"PDAE_W1", 1}, {"PDAE_W1_EFF", 85}, {"PDAE_P3R", 1}, {"PDAE_P3R_MIN", 512}, {"PDAE_P3R_EFF", 85}, {"PDAE_EDGE", 1}, {"PDAE_P3_TH", 0},
     {"PDAE_SPLIT_STATS", 1}, {"PDAE_W3_STAGGER", 0}, {"PDAE_Y_STAGGER", 0}, {"PDAE_C1_SLAB", 1}, {"PDAE_C1_BF16", 0}, {"PDAE_NO_SKINNY", 0},
-    {"PDAE_C1_PIPE", 1}};
+    {"PDAE_C1_ROT", 1}, {"PDAE_W1_ROWS8", 1}, {"PDAE_W1_EFF8", 70}};
 static int g_knob_val[KNOB_COUNT];
 static bool g_knob_set[KNOB_COUNT];
 static std::mutex g_knob_mu;
@@ -311,7 +311,7 @@ extern "C" size_t pdae_conv_stats_bytes(const pdae_conv_desc* d, const pdae_conv
   if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || ((d->C0 + d->C1) & 31) || (d->Cout & 3)) return 0;
   if (ds ? !skip_ok_impl(d, ds, d_dflag) : (fast_kind(d, 0, false) != 3 && !gn_patch_ok(d, false))) return 0;
   int tpi = 0;
-  const size_t b = conv3x3p_stats_bytes(d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, ds ? (ds->C0 + ds->C1) >> 5 : 0, &tpi);
+  const size_t b = conv3x3p_stats_bytes(d->math | d_dflag, d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout, ds ? (ds->C0 + ds->C1) >> 5 : 0, &tpi);
   if (tiles_per_image) *tiles_per_image = b ? tpi : 0;
   return b;
 }

@@ -40,7 +40,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // convolution's weights and launching it by editing its environment (tests switch through pdae_set_knob; prepared buffers are additionally
 // tagged with their form, conv3x3p.hip).  The names are the environment variables of DESIGN.md section 10.
 enum PdaeKnob {
-  KNOB_W1 = 0,        // PDAE_W1: Winograd F(2,3)-along-x form of the 3x3 convolutions: 0 off, 1 chip-filling layers (default), 2 every eligible shape
+  KNOB_W1 = 0,        // PDAE_W1: Winograd F(2,3)-along-x form of the 3x3 convolutions: 0 off, 1 by fill rules (default), 2 / 3 every eligible shape in 16- / 8-row tiles
   KNOB_W1_EFF,        // PDAE_W1_EFF: minimum % of the CUs busy in the last round of tiles for that form (85)
   KNOB_P3R,           // PDAE_P3R: conv3x3r (direct persistent form): 0 never, 1 by fill heuristic (default), 2 every eligible shape
   KNOB_P3R_MIN,       // PDAE_P3R_MIN (512)
@@ -53,7 +53,9 @@ enum PdaeKnob {
   KNOB_C1_SLAB,       // PDAE_C1_SLAB: slab-traffic term of the conv1x1 split-K plan (1)
   KNOB_C1_BF16,       // PDAE_C1_BF16: three-plane bf16 format in the 1x1 kernels also in mode 4 (0)
   KNOB_NO_SKINNY,     // PDAE_NO_SKINNY: M <= 32 linears on the generic GEMM (0)
-  KNOB_C1_PIPE,       // PDAE_C1_PIPE: double-buffered staging of conv1x1 (1)
+  KNOB_C1_ROT,        // PDAE_C1_ROT: conv1x1 workgroups start their channel stages at different offsets (1)
+  KNOB_W1_ROWS8,      // PDAE_W1_ROWS8: 8-row tiles of the Winograd form for layers too small for 16-row tiles (1)
+  KNOB_W1_EFF8,       // PDAE_W1_EFF8: minimum % of the CUs busy in the last round of 8-row tiles when there is more than one round (70)
   KNOB_COUNT
 };
 int pdae_knob(int id);

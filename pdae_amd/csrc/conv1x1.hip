@@ -64,6 +64,7 @@ struct PointParams {
   int res_mode, H, W;                                // res_mode 2: residual stored at half resolution (needs the image geometry)
   int tiles_m, tiles_n, splits, sps;                 // split-K: `splits` ranges of `sps` 16-channel steps
   float* slab;
+  int rot;                                           // 1: workgroup (m-tile i) walks its 64-channel stages starting from stage i mod (stages), see the kernel
 };
 
 // pixel row of the half-resolution residual (x_upd(x) skip of an up-ResBlock, module.py:279-284,297)
@@ -141,9 +142,17 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  auto step = [&](int s, const uint4 (&bq)[2][QNPL(NS)], uint4 (&bn)[2][QNPL(NS)]) {
-    ldb(bn, min(s + 1, s_end - 1));                 // next step's weights, always issued (straight-line loads: counted waits)
-    const int ks = (s - s_begin) & 3;               // step inside the staged 64 channels
+  // Stage order.  All workgroups of a launch run in near lock step, and stage j of every one of them reads the SAME 256-byte slice of its pixel
+  // rows (channels 64 j .. 64 j + 63 of C0- / C1-channel rows): at any moment the chip reads every second (C = 128) or every fourth 256-byte chunk
+  // of the tensor, i.e. a fraction of the HBM channels -- the 128^2 skip convolutions sat at 3.6 - 3.8 TB/s whatever the prefetch depth (a persistent
+  // form with two stages in flight across tiles measured 0.85 - 1.03x, tools/c1_ab.py).  With P.rot the workgroup of m-tile i starts at stage
+  // i mod (stages) and wraps: neighbouring workgroups read different slices at the same time.  The accumulation order of a tile then depends on
+  // its index (deterministic; fp32 sums of the same products in another order).
+  const int nst = (s_end - s_begin + 3) >> 2;
+  const int rot = (P.rot && nst > 1) ? (int)(tm_i % nst) : 0;
+  auto stage_first = [&](int j) { int st = j + rot; if (st >= nst) st -= nst; return s_begin + 4 * st; };      // first step of the j-th stage in walk order
+  auto step = [&](int s, int ks, int s_next, const uint4 (&bq)[2][QNPL(NS)], uint4 (&bn)[2][QNPL(NS)]) {
+    ldb(bn, s_next);                                // next step's weights (in walk order), always issued (straight-line loads: counted waits)
     uint4 af[2][QNPL(NS)];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -180,25 +189,31 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #undef PDAE_BH
 #undef PDAE_B
       }
-    // tile hand-over after every 4th step
-    if (ks == 3 && s + 1 < s_end) {
-      __syncthreads();
-      a_lstore();
-      __syncthreads();
-      if (s + 5 < s_end) a_gload(s + 5);
-    }
   };
 
   uint4 q0[2][QNPL(NS)], q1[2][QNPL(NS)];
   if (s_begin < s_end) {
-    a_gload(s_begin);
-    ldb(q0, s_begin);
+    a_gload(stage_first(0));
+    ldb(q0, stage_first(0));
     a_lstore();
     __syncthreads();
-    if (s_begin + 4 < s_end) a_gload(s_begin + 4);
-    for (int s = s_begin; s < s_end; s += 2) {     // an even number of steps per split (C % 32 == 0)
-      step(s, q0, q1);
-      step(s + 1, q1, q0);
+    if (nst > 1) a_gload(stage_first(1));
+    for (int j = 0; j < nst; ++j) {                  // a stage = 4 steps, or 2 at the tail of the channel range (C % 32 == 0: an even number)
+      const int s0 = stage_first(j);
+      const int sn = j + 1 < nst ? stage_first(j + 1) : s0;      // (beyond the last stage: a harmless reload)
+      const bool four = s0 + 2 < s_end;
+      step(s0, 0, s0 + 1, q0, q1);
+      step(s0 + 1, 1, four ? s0 + 2 : sn, q1, q0);
+      if (four) {
+        step(s0 + 2, 2, s0 + 3, q0, q1);
+        step(s0 + 3, 3, sn, q1, q0);
+      }
+      if (j + 1 < nst) {                               // tile hand-over
+        __syncthreads();
+        a_lstore();
+        __syncthreads();
+        if (j + 2 < nst) a_gload(stage_first(j + 2));
+      }
     }
   }
   const long long mw = m0 + wm * 64;
@@ -416,6 +431,7 @@ int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, l
   const PointPlan q = point_plan(M, P.C, Nout);
   P.tiles_m = q.tiles_m; P.tiles_n = q.tiles_n; P.splits = q.splits; P.sps = q.sps;
   P.slab = (float*)((char*)wp + point_prep_bytes(math, Nrows, P.C));
+  P.rot = pdae_knob(KNOB_C1_ROT) != 0;
   dim3 grid(q.tiles_m * q.tiles_n * q.splits);
 #define PDAE_C1(NS_)                                                                     \
   hipLaunchKernelGGL((conv1x1_kernel<NS_>), grid, dim3(256), 0, s, P);                    \

@@ -199,8 +199,9 @@ int wprep_group_launch(const WprepJob* jobs_dev, const int* first_block_dev, int
 // conv3x3y.hip: Winograd F(2, 3) along x (two thirds of the matrix work) on the large layers; conv3x3p_form = 1 when a convolution with these
 // launch-side dimensions is prepared AND launched in that form
 bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout);
+int conv3x3x_rows(int math, int C, int H, int W, int N, int Nout);       // 0: direct form; 2: tiles of 16 rows; 1: tiles of 8 rows
 int conv3x3x_launch(int math, const PatchParams& P, hipStream_t s);
-int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s);      // conv3x3y.hip: the same form, persistent, one wave per SIMD (no fused skip chunks)
+int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s, int rows);      // conv3x3y.hip: persistent, one wave per SIMD (no fused skip chunks)
 int conv3x3p_form(int math, int C, int H, int W, int N, int Nout);
 // conv3x3r.hip: persistent workgroups with a deferred epilogue for layers with at least two 16 x 16 x 128-channel tiles per CU
 bool conv3x3r_ok(int math, int C, int H, int W, int N, int Nout, int Hs, int Ws, int C0, int Cs0, int Cs1);

@@ -559,7 +559,9 @@ static int form_check(const void* wp, int form) {
 int conv3x3p_form(int math, int C, int H, int W, int N, int Nout) {
   if (math & PDAE_MATH_DIRECT_BIT) return 0;              // the caller pinned the direct form (pdae_conv_desc.math | PDAE_MATH_DIRECT)
   if (!conv3x3x_ok(math, C, H, W, N, Nout)) return 0;
-  return patch_plan(C, H, W, N, Nout).splits == 1 ? 1 : 0;
+  // PDAE_W1 = 2 (tests of the 16-row kernel on small shapes): a launch the direct plan would split over K keeps the direct form, as in round 4
+  if (pdae_knob(KNOB_W1) == 2) return patch_plan(C, H, W, N, Nout).splits == 1 ? 1 : 0;
+  return 1;
 }
 
 // Tiles per image of the GroupNorm-backward partial sums a data gradient with these LAUNCH-side dimensions (C = dY channels, Nout = the GroupNorm's
@@ -567,7 +569,8 @@ int conv3x3p_form(int math, int C, int H, int W, int N, int Nout) {
 // kernel's workspace, k_gn_workspace_floats); both sources whole 32-channel runs.  0: not available.
 int conv3x3p_gnb_tiles(int math, int C, int H, int W, int N, int Nout, int C0, int C1) {
   if (C0 + C1 != Nout || (C0 & 31) || (C1 & 31) || !conv3x3p_form(math, C, H, W, N, Nout)) return 0;
-  const int t = (H / 16) * (W / 16);
+  const int rows = conv3x3x_rows(math & ~PDAE_MATH_DIRECT_BIT, C, H, W, N, Nout);
+  const int t = (H / (8 * rows)) * (W / 16);
   return t <= 64 ? t : 0;
 }
 
@@ -578,7 +581,8 @@ float conv3x3p_wscale(int C) { int k = 0; while ((1 << (2 * k)) < 9 * C) ++k; re
 // prepared weights + split-K slabs of the convolution (one buffer: [planes | slabs])
 // (math may carry the direct bit, exactly as for the preparation and the launch: same arguments, same layout, same size)
 size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) {
-  return prep_bytes(math & ~PDAE_MATH_DIRECT_BIT, Nout, C, conv3x3p_form(math, C, H, W, N, Nout)) + slab_bytes(C, H, W, N, Nout);
+  const int form = conv3x3p_form(math, C, H, W, N, Nout);
+  return prep_bytes(math & ~PDAE_MATH_DIRECT_BIT, Nout, C, form) + (form ? 0 : slab_bytes(C, H, W, N, Nout));      // (the Winograd form never splits over K)
 }
 
 // One-shot request (pdae_conv_stats_arm): the next forward convolution entry point on this host thread TAKES it -- on entry, before any argument
@@ -588,8 +592,13 @@ size_t conv3x3p_wprep_bytes(int math, int Nout, int C, int H, int W, int N) {
 static thread_local float* g_stat_arm = nullptr;
 void conv3x3p_arm_stats(float* part) { g_stat_arm = part; }
 float* conv3x3p_take_stats() { float* p = g_stat_arm; g_stat_arm = nullptr; return p; }
-size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi) {
+size_t conv3x3p_stats_bytes(int math, int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi) {
   if (Nout & 3) return 0;
+  if (!fused_skip_chunks && conv3x3p_form(math, C, H, W, N, Nout)) {      // Winograd form: one entry per 8 x 16 pixels and wave, whatever the tile height
+    const int t = (H / 8) * (W / PTW);
+    if (tpi) *tpi = t;
+    return (size_t)N * t * (Nout >> 2) * 2 * sizeof(float);
+  }
   PatchPlan q = patch_plan(C + 32 * fused_skip_chunks, H, W, N, Nout);
   if (fused_skip_chunks) q.splits = 1;
   const int split_stats = pdae_knob(KNOB_SPLIT_STATS);       // 0: split launches leave none (A/B aid)
@@ -635,7 +644,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (form) {
     if (sk) { pdae_set_error("conv3x3p: fused skip chunks are not built for the Winograd form (pdae_conv2d_fwd_skip_ok == 0 for this shape)"); return PDAE_EINVAL; }
     if (coef && !act) { pdae_set_error("conv3x3p: fused GroupNorm input without SiLU is not built for the Winograd form"); return PDAE_EINVAL; }
-    P.stat_tpi = (H / 16) * (W / 16) * 2;
+    P.stat_tpi = (H / 8) * (W / 16);
     return conv3x3x_launch(math, P, s);
   }
   // large layers: persistent workgroups, one wave per SIMD, epilogue of tile i inside tile i+1 (conv3x3r.hip); same parameters, same results

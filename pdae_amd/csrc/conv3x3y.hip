@@ -34,8 +34,8 @@
 #define YTHREADS 256
 #define YPW 36
 #define YROWB 48u
-#define YNPOS (18 * YPW)
-#define YPLANE_B ((unsigned)YNPOS * YROWB)         // 31104
+#define YNPOS_(RH_) ((8 * (RH_) + 2) * YPW)          // patch rows: the tile's 8 RH rows + halo
+#define YPLANE_B_(RH_) ((unsigned)YNPOS_(RH_) * YROWB)      // 31104 (RH = 2), 17280 (RH = 1)
 #define YOOB 0xFFFFFFF0u
 #define YALL 0xFFFFFFEFu
 
@@ -49,7 +49,7 @@ typedef __attribute__((address_space(3))) const y_f32x4* y_lds_f4;
 
 #define PDAE_Y_PATTERN(NV)                                                                                  \
   _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+    if (RH == 2 || (i_ & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* 12 (RH = 2) or 6 MFMAs per unit */ \
     __builtin_amdgcn_sched_group_barrier(0x006, NV, 0);                                                    \
     if (i_ < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                     \
@@ -67,10 +67,17 @@ struct YDiv { unsigned mn, mx, my; };
 // GroupNorm do not, and then the 64 VALU instructions per epilogue block that sum them do not exist either
 // GB: the launch is a data gradient that leaves the GroupNorm-backward sums of its output (PatchParams::gb_*): EX's operand slots carry the
 // GroupNorm's raw input x instead of a residual (the operand is NOT added), the sums replace ST's
-template <int NS, bool GN, bool EX, bool ST, bool GB = false>
+// RH: row halves of the tile.  2 = 16 x 16 pixels (everything above); 1 = 8 x 16 pixels (round 5): the same pipeline with ONE staging item per thread
+// (patch rows 0 .. 7; the quarter item takes rows 8, 9), 8 accumulator tiles, 6 MFMAs per unit and 2 epilogue blocks -- for layers whose 16-row
+// tiles leave most of the chip idle (16^2 at B = 32: 96 tiles of 16 x 16 x 128 against 192 of 8 x 16 x 128), which otherwise run the direct form
+// split over K with slab reductions (conv3x3p.hip) at 3 instead of 2 MFMAs per product.
+template <int NS, bool GN, bool EX, bool ST, bool GB = false, int RH = 2>
 __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams P, const int stagger, const YDiv D) {
   static_assert(!GB || (EX && !ST && !GN), "GB: a data gradient with the operand slots, no forward statistics, no fused GroupNorm input");
+  static_assert(RH == 1 || RH == 2, "tiles of 8 or 16 rows");
   constexpr int NP = NPL(NS);
+  constexpr unsigned YPLANE_B = YPLANE_B_(RH);
+  constexpr int NA = 2 * RH;                       // m-tiles of a wave: (row half a >> 1, pair half a & 1)
   constexpr unsigned BUF_B = NP * YPLANE_B;
   extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, h = lane >> 5;
@@ -89,17 +96,17 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
 #define Y_UDIV(N_, D_, M_) ((D_) == 1 ? (unsigned)(N_) : __umulhi((unsigned)(N_), (M_)))
 #define Y_DECODE(TILE, IMG, Y0, X0, N0)                                                                       \
   { const unsigned tl_ = (unsigned)(TILE), q1_ = Y_UDIV(tl_, P.tiles_n, D.mn), q2_ = Y_UDIV(q1_, P.tiles_x, D.mx), q3_ = Y_UDIV(q2_, P.tiles_y, D.my);   \
-    IMG = (int)q3_; Y0 = (int)(q2_ - q3_ * (unsigned)P.tiles_y) * 16; X0 = (int)(q1_ - q2_ * (unsigned)P.tiles_x) * 16; N0 = (int)(tl_ - q1_ * (unsigned)P.tiles_n) * 128; }
+    IMG = (int)q3_; Y0 = (int)(q2_ - q3_ * (unsigned)P.tiles_y) * (8 * RH); X0 = (int)(q1_ - q2_ * (unsigned)P.tiles_x) * 16; N0 = (int)(tl_ - q1_ * (unsigned)P.tiles_n) * 128; }
 #define Y_DECODE_N0(TILE, N0) { const unsigned tl_ = (unsigned)(TILE), q1_ = Y_UDIV(tl_, P.tiles_n, D.mn); N0 = (int)(tl_ - q1_ * (unsigned)P.tiles_n) * 128; }
 
   // ---- staging roles.  Items l = 0, 1: (patch row (t >> 5) + 8 l, pair (t >> 2) & 7, channel quad t & 3): own pixels b = 1, 2 and, for the first / last
   // pair of the row, the edge pixel.  Quarter item (patch rows 16, 17): (row 16 + (t >> 7), pair (t >> 4) & 7, quad (t >> 2) & 3, position t & 3): the
   // two pixels that position needs (c = 0: b = 0, 2; c = 1, 2: b = 1, 2; c = 3: b = 1, 3).
   const int qd = t & 3, wt = (t >> 2) & 7, r8 = t >> 5;
-  const int q_c = t & 3, q_qd = (t >> 2) & 3, q_wt = (t >> 4) & 7, q_row = 16 + (t >> 7);
+  const int q_c = t & 3, q_qd = (t >> 2) & 3, q_wt = (t >> 4) & 7, q_row = 8 * RH + (t >> 7);
   const int q_ba = q_c == 0 ? 0 : 1, q_bb = q_c == 3 ? 3 : 2;
   // per-tile pixel bookkeeping of the tile whose raw data is being LOADED (ld_*): source pixel index of b = 1 per item + validity bits
-  int ld_pb[2], ld_qa = 0, ld_qb = 0;
+  int ld_pb[RH], ld_qa = 0, ld_qb = 0;
   unsigned ld_vm = 0u;                           // bits 0, 1: items' rows valid; 2, 3: items' edge pixels valid; 4, 5: quarter item's two pixels valid
   // the neighbours' pixels come across lanes with DPP row shifts (16-lane rows = 4 pairs x 4 quads): the first / last pair of each 4-pair segment
   // loads its outer pixel itself (the tile's edge pixel for pairs 0 and 7, a pixel of the neighbouring segment for pairs 3 and 4)
@@ -111,11 +118,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     /* the lane's roles are re-derived from the thread index here: kept live across the step they were spilled in the fused-GroupNorm instantiation */ \
     int t_ = t;                                                                                               \
     asm volatile("" : "+v"(t_));                                                                              \
-    const int wt_ = (t_ >> 2) & 7, r8_ = t_ >> 5, qc_ = t_ & 3, qwt_ = (t_ >> 4) & 7, qrow_ = 16 + (t_ >> 7); \
+    const int wt_ = (t_ >> 2) & 7, r8_ = t_ >> 5, qc_ = t_ & 3, qwt_ = (t_ >> 4) & 7, qrow_ = 8 * RH + (t_ >> 7); \
     const int qba_ = qc_ == 0 ? 0 : 1, qbb_ = qc_ == 3 ? 3 : 2;                                               \
     const bool sl_ = (wt_ & 3) == 0, sh_ = (wt_ & 3) == 3;                                                    \
     ld_vm = 0u;                                                                                               \
-    _Pragma("unroll") for (int l = 0; l < 2; ++l) {                                                           \
+    _Pragma("unroll") for (int l = 0; l < RH; ++l) {                                                          \
       const int ly = (Y0) - 1 + r8_ + 8 * l, lx1 = (X0) + 2 * wt_;                                            \
       const bool rok = (LIVE) && (unsigned)ly < (unsigned)P.H;                                                \
       ld_pb[l] = ((IMG) * P.Hs + (ly >> up_sh)) * P.Ws + (lx1 >> up_sh);                                      \
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   { const int c_ = (K) << 4; const bool first_ = c_ < P.C0;                                                   \
     ld_ptr = first_ ? P.x : x1_; ld_ldb = (unsigned)(first_ ? P.C0 : C1) * 4u; ld_cb = (unsigned)(first_ ? c_ : c_ - P.C0) * 4u; }
 #define Y_RS(PTR) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((const void*)(PTR)), 0, (int)YALL, 0x00020000)
-  float4 apre[2][3], qpre[2];
+  float4 apre[RH][3], qpre[2];
   auto gload_item = [&](int l) {
     const unsigned v1 = (unsigned)ld_pb[l] * ld_ldb + (unsigned)(qd * 16);
     const bool rok = (ld_vm >> l) & 1u, eok = (ld_vm >> (2 + l)) & 1u;
@@ -259,12 +266,12 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   unsigned abase = a_lane;
   // patch fragments: ring of YRA units (requested YRA - 1 units ahead); the fused-GroupNorm instantiation has no registers for a third slot
   constexpr int YRA = GN ? 2 : 3;
-  uint4 fa[YRA][4][NP];                            // [unit mod YRA][m-tile a][plane]
+  uint4 fa[YRA][NA][NP];                           // [unit mod YRA][m-tile a][plane]
   unsigned abase_n = a_lane;                       // the other buffer: unit 0 of the NEXT step is fetched during unit 11, behind the step's barrier
-  auto lda = [&](uint4 (&af)[4][NP], unsigned base, int u) {      // unit u: ky = u >> 2, c = u & 3
+  auto lda = [&](uint4 (&af)[NA][NP], unsigned base, int u) {      // unit u: ky = u >> 2, c = u & 3
     const unsigned off = (unsigned)(((u >> 2) * YPW + (u & 3) * 8) * YROWB);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
       for (int p = 0; p < NP; ++p)
         af[a][p] = __builtin_bit_cast(uint4, *(y_lds_u4)(size_t)(base + off + (unsigned)(((a >> 1) * 8 * YPW + (a & 1) * 4) * YROWB) + (unsigned)p * YPLANE_B));
@@ -287,14 +294,14 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
 #pragma unroll
     for (int p = 0; p < NP; ++p) bq[p] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(srd_w, lane16, (int)(soff + p * ps2), 0));
   };
-  f32x16 acc[4][4];                                // [c][a]
-  auto mma = [&](const uint4 (&af)[4][NP], const uint4 (&bq)[NP], int c, bool zc) {
+  f32x16 acc[4][NA];                               // [c][a]
+  auto mma = [&](const uint4 (&af)[NA][NP], const uint4 (&bq)[NP], int c, bool zc) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define PDAE_YA(P_) __builtin_bit_cast(bf16x8, af[a][P_])
 #define PDAE_YB(P_) __builtin_bit_cast(bf16x8, bq[P_])
 #define PDAE_YAH(P_) __builtin_bit_cast(f16x8, af[a][P_])
 #define PDAE_YBH(P_) __builtin_bit_cast(f16x8, bq[P_])
-#define PDAE_Y_EACH(STMT) _Pragma("unroll") for (int a = 0; a < 4; ++a) { STMT; }
+#define PDAE_Y_EACH(STMT) _Pragma("unroll") for (int a = 0; a < NA; ++a) { STMT; }
     if constexpr (NS == 4) {
       PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(0), PDAE_YBH(1), zc ? zero : acc[c][a], 0, 0, 0))
       PDAE_Y_EACH(acc[c][a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_YAH(1), PDAE_YBH(0), acc[c][a], 0, 0, 0))
@@ -347,16 +354,17 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   // prologue: step 0 converted into buffer 0, step 1 raw in the registers with its coefficients
   Y_LD_TILE(l_img, l_y0, l_x0, true)
   Y_LD_SRC(0)
-  gload_item(0); gload_item(1); gload_quarter();
+#define Y_IF2(...) if constexpr (RH == 2) { __VA_ARGS__ }      /* the second staging item exists for 16-row tiles only */
+  gload_item(0); Y_IF2(gload_item(1);) gload_quarter();
   coef_fetch(l_img, 0); coef_stash(); coef_load(); coef_load_q();
   cv_vm = ld_vm;
   cur = 1;                                         // the conversions write buffer cur ^ 1 = 0
   conv_A(0); conv_B(0); conv_C(0, 0); conv_C(0, 2);
-  conv_A(1); conv_B(1); conv_C(1, 0); conv_C(1, 2);
+  Y_IF2(conv_A(1); conv_B(1); conv_C(1, 0); conv_C(1, 2);)
   conv_quarter();
   cur = 0;
   PDAE_Y_LD_NEXT()
-  gload_item(0); gload_item(1); gload_quarter();
+  gload_item(0); Y_IF2(gload_item(1);) gload_quarter();
   coef_fetch(l_img, l_k); coef_stash(); coef_load();      // (the quarter item's quad is read at unit 6 of the first step)
   {
     const int nt0 = (m_n0 >> 5) + wv;
@@ -385,7 +393,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
 #define PDAE_Y_DO_B(...) __VA_ARGS__
 #endif
 #ifdef PDAE_Y_PROBE_NOCONV
-#define PDAE_Y_CV(...) asm volatile("" :: "v"(apre[0][0].x), "v"(apre[1][0].x), "v"(qpre[0].x), "v"(apre[0][2].w), "v"(apre[1][2].w), "v"(qpre[1].w), "v"(apre[0][1].y), "v"(apre[1][1].y));
+#define PDAE_Y_CV(...) asm volatile("" :: "v"(apre[0][0].x), "v"(apre[RH - 1][0].x), "v"(qpre[0].x), "v"(apre[0][2].w), "v"(apre[RH - 1][2].w), "v"(qpre[1].w), "v"(apre[0][1].y), "v"(apre[RH - 1][1].y));
 #else
 #define PDAE_Y_CV(...) __VA_ARGS__
 #endif
@@ -418,11 +426,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     PDAE_Y_UNIT(1, FIRST, PDAE_Y_CV(conv_B(0);))                                                              \
     PDAE_Y_UNIT(2, FIRST, PDAE_Y_CV(conv_C(0, 0);))                                                           \
     PDAE_Y_UNIT(3, FIRST, PDAE_Y_CV(conv_C(0, 2);))                                                           \
-    PDAE_Y_UNIT(4, FIRST, PDAE_Y_CV(conv_A(1);) PDAE_Y_GL(gload_item(0);) coef_fetch(l_img, l_k);)      /* eight units ahead of its conversion */ \
-    PDAE_Y_UNIT(5, FIRST, PDAE_Y_CV(conv_B(1);))                                                              \
-    PDAE_Y_UNIT(6, FIRST, PDAE_Y_CV(conv_C(1, 0);) coef_load_q();)                                            \
-    PDAE_Y_UNIT(7, FIRST, PDAE_Y_CV(conv_C(1, 2);))                                                           \
-    PDAE_Y_UNIT(8, FIRST, PDAE_Y_CV(conv_quarter();) PDAE_Y_GL(gload_item(1);))                               \
+    PDAE_Y_UNIT(4, FIRST, PDAE_Y_CV(Y_IF2(conv_A(1);)) PDAE_Y_GL(gload_item(0);) coef_fetch(l_img, l_k);)      /* eight units ahead of its conversion */ \
+    PDAE_Y_UNIT(5, FIRST, PDAE_Y_CV(Y_IF2(conv_B(1);)))                                                       \
+    PDAE_Y_UNIT(6, FIRST, PDAE_Y_CV(Y_IF2(conv_C(1, 0);)) coef_load_q();)                                     \
+    PDAE_Y_UNIT(7, FIRST, PDAE_Y_CV(Y_IF2(conv_C(1, 2);)))                                                    \
+    PDAE_Y_UNIT(8, FIRST, PDAE_Y_CV(conv_quarter();) PDAE_Y_GL(Y_IF2(gload_item(1);)))                        \
     PDAE_Y_UNIT(9, FIRST, PDAE_Y_GL(gload_quarter();))                                                        \
     /* the step's barrier: every conversion into the other buffer is done (unit 8), every read of this one is issued (unit 12 - YRA); */ \
     /* behind it the first fragments of the NEXT step are fetched from the other buffer */                     \
@@ -453,7 +461,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
     {
       f32x16 sm = acc[0][0];
 #pragma unroll
-      for (int i = 1; i < 16; ++i) sm += acc[i >> 2][i & 3];
+      for (int i = 1; i < 4 * NA; ++i) sm += acc[i / NA][i % NA];
       float z = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) z += sm[r];
@@ -491,12 +499,12 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
       const unsigned d_rb4 = (unsigned)((((m_img * P.H + m_y0) * P.W + m_x0) * P.Nout + n0w) * 4);
       const unsigned d_xb4 = rsh ? (unsigned)((((m_img * (P.H >> 1) + (m_y0 >> 1)) * (P.W >> 1) + (m_x0 >> 1)) * xc + xn0) * 4)
                                  : (unsigned)((((m_img * P.H + m_y0) * P.W + m_x0) * xc + xn0) * 4);
-      const unsigned d_sb8 = (unsigned)(((m_img * P.stat_tpi + ((m_y0 >> 4) * P.tiles_x + (m_x0 >> 4)) * 2) * (P.Nout >> 2) + (n0w >> 2)) * 8);      // + (a >> 1): the row half's entry
+      const unsigned d_sb8 = (unsigned)(((m_img * P.stat_tpi + (m_y0 / (8 * RH) * P.tiles_x + (m_x0 >> 4)) * RH) * (P.Nout >> 2) + (n0w >> 2)) * 8);      // + (a >> 1): the row half's entry
       const unsigned s_ar = (unsigned)((P.Nout >> 2) * 8);
       const float* const extra_ = GB ? (g_first ? P.gb_x0 : P.gb_x1) : (P.res_mode ? P.res : P.y);      // residual OR (accumulate) the previous contents of y (both: conv3x3y_launch falls back)
       const unsigned extra_on = (GB || P.res_mode || P.accumulate) ? YALL : 0u, stat_on = P.stat_part ? YALL : 0u, bias_on = P.bias ? YALL : 0u;
 #define Y_RSB(PTR, BYTES) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((const void*)(PTR)), 0, (int)(BYTES), 0x00020000)
-      float4 rv[EX ? 2 : 1][2][EX ? 4 : 1];
+      float4 rv[EX ? 2 : 1][2][EX ? 4 : 1];          // (RH = 1: two blocks, both requested up front)
       float st1 = 0.f, st2 = 0.f;
       float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);      // (GB: a data gradient has no bias -- four registers the sums need)
       if constexpr (!GB) bias4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.bias, bias_on), ec * 4, (int)(n0w * 4), 0));
@@ -550,11 +558,20 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
             *(y_lds_f)(size_t)(o + TWB) = z1[q];
           }
           __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+          // (round 5) the spacer is now `s_waitcnt lgkmcnt(0)` -- the stores have COMPLETED, so their operands have certainly left the register file --
+          // and it takes the sixteen stored values as inputs, so their registers stay allocated up to it.  The 16 idle cycles of round 4 were enough for
+          // the 16-row instantiations; the 8-row ones with an epilogue operand (16 buffer loads issued right in front of these stores compete for the
+          // same operand path) still stored the NEXT half block's values in lanes 12-15 of every 16, ~1.9 % of the outputs, varying from run to run.
+          // Before that the same instantiation had formed the next store's ADDRESS in a dead data register one instruction behind the store
+          // (`ds_write2_b32 v157, v174, v176` / `v_add_u32 v176, 0x400, v83`): an ordinary VALU write is not interlocked against the operand transfer
+          // either (tools/isa_hazard.py flags any vector write now).
+          asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(z0[0]), "v"(z0[1]), "v"(z0[2]), "v"(z0[3]), "v"(z0[4]), "v"(z0[5]), "v"(z0[6]), "v"(z0[7]),
+                       "v"(z1[0]), "v"(z1[1]), "v"(z1[2]), "v"(z1[3]), "v"(z1[4]), "v"(z1[5]), "v"(z1[6]), "v"(z1[7]) : "memory");
           __builtin_amdgcn_sched_barrier(0);
         }
       };
       auto epi_S = [&](int b) {
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);      // the value stored last (see OUTPUT STORE DATA HAZARD below)
         if ((b & 1) == 0) { st1 = 0.f; st2 = 0.f; }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -567,6 +584,15 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
             if constexpr (GB) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
             else { v.x = fmaf(v.x, oscale, bb.x); v.y = fmaf(v.y, oscale, bb.y); v.z = fmaf(v.z, oscale, bb.z); v.w = fmaf(v.w, oscale, bb.w); }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(y_u32x4, v), Y_RSB(P.y, YALL), (int)lane_y, (int)(d_rb4 + it * y_it + j * y_j + (b & 1) * y_a2 + (b >> 1) * y_ar), 0);
+            // OUTPUT STORE DATA HAZARD (round 5).  The 8-row instantiation with an epilogue operand stored wrong values in lanes 12-15 of every 16 for
+            // ~1.9 % of its outputs, varying from run to run: `buffer_store_dwordx4 v[162:165]` and, two instructions later, `v_pk_add_f32 v[162:163], ..`
+            // -- the next value formed in the store's data registers while the store, queued behind the sixteen operand loads issued just before, had
+            // not yet moved its data out of the register file (the lanes transferred last got the new value; the same signature as the LDS store
+            // hazard of round 4).  A debug build with a 32-cycle spacer behind every store was correct.  The rule here: the
+            // registers of a stored value stay allocated until the NEXT store has been issued (`pv`: its computation contains an LDS round trip,
+            // >= 60 cycles), and the last one of a block is followed by an explicit spacer.  tests/test_kernel_resources_cpu.py scans for the pattern.
+            // (GB: the stored value is read again by ~30 instructions of the sums below, which keeps its registers busy for longer than that)
+            if constexpr (!GB) { asm volatile("" :: "v"(pv.x), "v"(pv.y), "v"(pv.z), "v"(pv.w)); pv = v; }
             if constexpr (GB) {
               // dv = dA * silu'(z), z = a x + b', silu'(z) = s (1 + z (1 - s)), s = 1 / (1 + 2^(-z log2 e)): the arithmetic of compute_dv (norm.hip)
               // on float pairs (packed VALU); act == 1, no dropout (launch check)
@@ -590,6 +616,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
               st2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, st2))));
             }
           }
+        if constexpr (!GB) asm volatile("s_nop 7\n\ts_nop 7" :: "v"(pv.x), "v"(pv.y), "v"(pv.z), "v"(pv.w));      // the block's last store
         if (ST && (b & 1) == 1) {      // (sum, sum of squares) of a row half's 8 x 16 pixels per channel quad: the eight lanes holding a quad combine, lanes 0..7 write
           float s1 = st1, s2 = st2;
           s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8);
@@ -597,14 +624,15 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
           const y_u32x2 sv2 = {__float_as_uint(s1), __float_as_uint(s2)};
           __builtin_amdgcn_raw_buffer_store_b64(sv2, Y_RSB(P.stat_part, stat_on), (int)lane_st, (int)(d_sb8 + (b >> 1) * s_ar), 0);
+          asm volatile("s_nop 7\n\ts_nop 7" :: "v"(sv2[0]), "v"(sv2[1]));      // (the next block's accumulator reads took these registers two instructions later: output store data hazard)
         }
       };
 #define Y_EPI_FENCE __builtin_amdgcn_sched_barrier(0);
       epi_L(0); epi_L(1); Y_EPI_FENCE
-      epi_W(0); Y_EPI_FENCE epi_S(0); Y_EPI_FENCE epi_L(2); Y_EPI_FENCE
-      epi_W(1); Y_EPI_FENCE epi_S(1); Y_EPI_FENCE epi_L(3); Y_EPI_FENCE
-      epi_W(2); Y_EPI_FENCE epi_S(2); Y_EPI_FENCE
-      epi_W(3); Y_EPI_FENCE epi_S(3); Y_EPI_FENCE
+      epi_W(0); Y_EPI_FENCE epi_S(0); Y_EPI_FENCE Y_IF2(epi_L(2);) Y_EPI_FENCE
+      epi_W(1); Y_EPI_FENCE epi_S(1); Y_EPI_FENCE Y_IF2(epi_L(3);) Y_EPI_FENCE
+      Y_IF2(epi_W(2); Y_EPI_FENCE epi_S(2); Y_EPI_FENCE
+            epi_W(3); Y_EPI_FENCE epi_S(3); Y_EPI_FENCE)
       if constexpr (GB) {      // the eight lanes that hold a channel quad combine (fixed order), lanes 0..7 write (S0, S1) of four channels: 32 bytes
         const float4 m_ = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(Y_RSB(P.gb_coef, YALL), ec * 4, (int)g_co4, 0));
         float sv8[8] = {gs0[0][0], fmaf(-m_.x, gs0[0][0], gs1[0][0]), gs0[0][1], fmaf(-m_.y, gs0[0][1], gs1[0][1]),
@@ -612,7 +640,7 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
 #pragma unroll
         for (int k = 0; k < 8; ++k) { sv8[k] += __shfl_xor(sv8[k], 8); sv8[k] += __shfl_xor(sv8[k], 16); sv8[k] += __shfl_xor(sv8[k], 32); }
         const unsigned g_lane = lane_e < 8 ? (unsigned)(lane_e * 32) : YOOB;
-        const unsigned g_off = (unsigned)((((m_img * P.gb_tpi + (m_y0 >> 4) * P.tiles_x + (m_x0 >> 4)) * P.Nout) + n0w) * 8);
+        const unsigned g_off = (unsigned)((((m_img * P.gb_tpi + m_y0 / (8 * RH) * P.tiles_x + (m_x0 >> 4)) * P.Nout) + n0w) * 8);
         const y_u32x4 w0 = {__float_as_uint(sv8[0]), __float_as_uint(sv8[1]), __float_as_uint(sv8[2]), __float_as_uint(sv8[3])};
         const y_u32x4 w1 = {__float_as_uint(sv8[4]), __float_as_uint(sv8[5]), __float_as_uint(sv8[6]), __float_as_uint(sv8[7])};
         __builtin_amdgcn_raw_buffer_store_b128(w0, Y_RSB(P.gb_part, YALL), (int)g_lane, (int)g_off, 0);
@@ -636,11 +664,11 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit * (2.0f * ascale));      // |s| <= 2 max|d| after the transform
 }
 
-template <int NS, bool GN, bool EX, bool ST, bool GB = false> static int launch_y(const PatchParams& P, hipStream_t s) {
-  const size_t smem = (size_t)2 * NPL(NS) * YPLANE_B + (size_t)4 * 2 * 32 * EPW * 4 + 4 * 256;      // two patch buffers + two transposition tiles per wave + the coefficient slots (f16x3: 162304 of 163840 bytes)
+template <int NS, bool GN, bool EX, bool ST, bool GB = false, int RH = 2> static int launch_y(const PatchParams& P, hipStream_t s) {
+  const size_t smem = (size_t)2 * NPL(NS) * YPLANE_B_(RH) + (size_t)4 * 2 * 32 * EPW * 4 + 4 * 256;      // two patch buffers + two transposition tiles per wave + the coefficient slots (f16x3, RH = 2: 162304 of 163840 bytes)
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN, EX, ST, GB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3y_kernel<NS, GN, EX, ST, GB, RH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { pdae_set_error("conv3x3y: cannot raise dynamic LDS to %zu: %s", smem, hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
@@ -650,7 +678,7 @@ template <int NS, bool GN, bool EX, bool ST, bool GB = false> static int launch_
   auto magic = [](int d) { return (unsigned)((0x100000000ull / (unsigned long long)d) + 1ull); };      // unused for d == 1
   const YDiv D{magic(P.tiles_n), magic(P.tiles_x), magic(P.tiles_y)};
   if (ntiles >= (1ll << 20) || P.tiles_n >= 4096 || P.tiles_x >= 4096 || P.tiles_y >= 4096) { pdae_set_error("conv3x3y: %lld tiles", ntiles); return 1; }
-  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX, ST, GB>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
+  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX, ST, GB, RH>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
   return pdae_launch_status("conv3x3y");
 }
 
@@ -660,42 +688,55 @@ template <int NS, bool GN, bool EX, bool ST, bool GB = false> static int launch_
 // Form of the prepared weights AND of the launch of a 3x3 convolution with these launch-side dimensions (C input channels, H x W output grid,
 // Nout output channels): decided from the shape and the knob PDAE_W1 alone, so that weight preparation and launch agree.  The knob is read once
 // (common.h); a prepared buffer is tagged with the form it was written in and a launch that expects the other form is refused (conv3x3p.hip).
-bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout) {
-  const int m = pdae_knob(KNOB_W1);      // 0: off; 1 (default): layers with at least a chip-full of tiles; 2: every eligible shape (tests)
-  if (m == 0) return false;
-  if (!(math == 1 || math == 2 || math == 4)) return false;
-  if ((H % 16) || (W % PTW) || (Nout % PBN) || (C & 31) || H >= 2048 || W >= 2048) return false;
+int conv3x3x_rows(int math, int C, int H, int W, int N, int Nout) {
+  // PDAE_W1: 0 off; 1 (default) by the fill rules below; 2: 16-row tiles on every eligible shape (8-row where H % 16 != 0); 3: 8-row tiles on every
+  // eligible shape (2, 3: tests)
+  const int m = pdae_knob(KNOB_W1);
+  if (m == 0) return 0;
+  if (!(math == 1 || math == 2 || math == 4)) return 0;
+  if ((H % 8) || (W % PTW) || (Nout % PBN) || (C & 31) || H >= 2048 || W >= 2048) return 0;
   const unsigned long long lim = 0xFFFFFFE0ull;
-  if ((unsigned long long)N * H * W * (unsigned long long)(C > Nout ? C : Nout) * 4ull >= lim) return false;
-  if (m == 2) return true;
-  const long long tiles = (long long)N * (H / 16) * (W / PTW) * (Nout / PBN);
-  const long long rounds = (tiles + 255) / 256;
-  return tiles >= 256 && tiles * 100 >= rounds * 256 * pdae_knob(KNOB_W1_EFF);      // persistent workgroups: the last round must not leave the chip idle
+  if ((unsigned long long)N * H * W * (unsigned long long)(C > Nout ? C : Nout) * 4ull >= lim) return 0;
+  const bool h16 = (H % 16) == 0;
+  if (m == 2) return h16 ? 2 : 1;
+  if (m >= 3) return 1;
+  const long long per8 = (long long)N * (W / PTW) * (Nout / PBN), tiles8 = per8 * (H / 8), tiles16 = h16 ? per8 * (H / 16) : 0;
+  // persistent workgroups, one per CU: the last round of tiles must not leave the chip idle
+  if (tiles16 >= 256 && tiles16 * 100 >= ((tiles16 + 255) / 256) * 256 * pdae_knob(KNOB_W1_EFF)) return 2;
+  // 8-row tiles for what is left (round 5): at least 5/8 of the CUs busy in a single round, or rounds filled to PDAE_W1_EFF8 %
+  if (pdae_knob(KNOB_W1_ROWS8) && tiles8 >= 160 && (tiles8 <= 256 || tiles8 * 100 >= ((tiles8 + 255) / 256) * 256 * pdae_knob(KNOB_W1_EFF8))) return 1;
+  return 0;
 }
+bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout) { return conv3x3x_rows(math, C, H, W, N, Nout) != 0; }
 
-// P: as conv3x3p_launch fills it; tiles of 16 x 16 pixels x 128 channels, Winograd-along-x weights; no fused skip chunks in this form
+// P: as conv3x3p_launch fills it; tiles of 16 x 16 (or 8 x 16) pixels x 128 channels, Winograd-along-x weights; no fused skip chunks in this form
 int conv3x3x_launch(int math, const PatchParams& P0, hipStream_t s) {
   PatchParams P = P0;
-  P.tiles_x = P.W / PTW; P.tiles_y = P.H / 16; P.tiles_n = P.Nout / PBN; P.splits = 1; P.cps = P.C >> 5;
+  const int rows = conv3x3x_rows(math, P.C, P.H, P.W, P.N, P.Nout);
+  if (!rows) { pdae_set_error("conv3x3y: shape not eligible for the Winograd form"); return PDAE_EINVAL; }
+  P.tiles_x = P.W / PTW; P.tiles_y = P.H / (8 * rows); P.tiles_n = P.Nout / PBN; P.splits = 1; P.cps = P.C >> 5;
   if (P.nx) { pdae_set_error("conv3x3y: fused skip chunks are not built for the Winograd form"); return PDAE_EINVAL; }
   if (P.x1 && (P.C0 & 31)) { pdae_set_error("conv3x3y: two-source input needs C0 %% 32 == 0"); return PDAE_EINVAL; }
-  return conv3x3y_launch(math, P, s);
+  return conv3x3y_launch(math, P, s, rows);
 }
 
 // P: as prepared by conv3x3x_launch (tiles of 16 x 16 pixels x 128 channels, Winograd-along-x weights); no fused skip chunks
-int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s) {
+int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s, int rows) {
   if (P.res_mode && P.accumulate) { pdae_set_error("conv3x3y: residual and accumulate in one launch"); return 1; }
   if (P.gb_part) {      // data gradient + GroupNorm-backward sums: the operand slots carry the GroupNorm input
     if (P.res_mode || P.accumulate || P.coef || P.stat_part || (P.gb_C0 & 31) || ((P.Nout - P.gb_C0) & 31) || P.gb_tpi != P.tiles_x * P.tiles_y) {
       pdae_set_error("conv3x3y: GroupNorm-backward sums need a plain data gradient (no residual / accumulate / fused input) and 32-channel-aligned sources");
       return PDAE_EINVAL;
     }
-    if (math == 1) return launch_y<1, false, true, false, true>(P, s);
-    if (math == 2) return launch_y<2, false, true, false, true>(P, s);
-    return launch_y<4, false, true, false, true>(P, s);
+#define PDAE_YG(NS_) (rows == 1 ? launch_y<NS_, false, true, false, true, 1>(P, s) : launch_y<NS_, false, true, false, true, 2>(P, s))
+    if (math == 1) return PDAE_YG(1);
+    if (math == 2) return PDAE_YG(2);
+    return PDAE_YG(4);
+#undef PDAE_YG
   }
-#define PDAE_Y2(NS_, GN_) (ex ? (st ? launch_y<NS_, GN_, true, true>(P, s) : launch_y<NS_, GN_, true, false>(P, s))       \
-                              : (st ? launch_y<NS_, GN_, false, true>(P, s) : launch_y<NS_, GN_, false, false>(P, s)))
+#define PDAE_Y1(NS_, GN_, EX_, ST_) (rows == 1 ? launch_y<NS_, GN_, EX_, ST_, false, 1>(P, s) : launch_y<NS_, GN_, EX_, ST_, false, 2>(P, s))
+#define PDAE_Y2(NS_, GN_) (ex ? (st ? PDAE_Y1(NS_, GN_, true, true) : PDAE_Y1(NS_, GN_, true, false))       \
+                              : (st ? PDAE_Y1(NS_, GN_, false, true) : PDAE_Y1(NS_, GN_, false, false)))
 #define PDAE_Y3(NS_) (P.coef ? PDAE_Y2(NS_, true) : PDAE_Y2(NS_, false))
   const bool ex = P.res_mode || P.accumulate, st = P.stat_part != nullptr;
   if (math == 1) return PDAE_Y3(1);
@@ -703,4 +744,5 @@ int conv3x3y_launch(int math, const PatchParams& P, hipStream_t s) {
   return PDAE_Y3(4);
 #undef PDAE_Y3
 #undef PDAE_Y2
+#undef PDAE_Y1
 }

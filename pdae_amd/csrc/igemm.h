@@ -66,7 +66,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
 int conv3x3p_gnb_tiles(int math, int C, int H, int W, int N, int Nout, int C0, int C1);      // tiles per image of PatchGnb::part, 0 = the launch cannot leave the sums
 void conv3x3p_arm_stats(float* part);          // one-shot request of pdae_conv_stats_arm (thread-local)
 float* conv3x3p_take_stats();                  // ... taken AND cleared by the next forward entry point, first thing, on every return path
-size_t conv3x3p_stats_bytes(int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi);
+size_t conv3x3p_stats_bytes(int math, int C, int H, int W, int N, int Nout, int fused_skip_chunks, int* tpi);
 size_t conv3x3p_skip_wprep_bytes(int math, int Nout, int Cs);
 int conv3x3p_skip_wprep(int math, const float* w, int Nout, int Cs, int Cmain, unsigned short* wp, hipStream_t s, int H, int W, int N);
 bool conv3x3p_skip_ok(int math, int C, int H, int W, int N, int Nout, int up, int Cs0, int Cs1);

@@ -101,7 +101,13 @@ def test_winograd_form_routing_is_a_pure_function_of_descriptor_and_switch(knob)
     ragged = H.Conv(3, 128, 128, 128, 0, 256, k=3, math=4)                   # 384 tiles: second round 50 % filled
     assert big.winograd_form(0) and big.winograd_form(0, gn=True) and big.winograd_form(1, f16_grad=True)
     assert wide32.winograd_form(0)
-    assert not small.winograd_form(0) and not ragged.winograd_form(0)
+    # round 5: layers too small for 16-row tiles take the form in 8-row tiles (16^2 x 384 channels: 192 tiles; 3 x 128^2 x 256: 768 = three full rounds) ...
+    assert small.winograd_form(0) and ragged.winograd_form(0)
+    tiny = H.Conv(32, 16, 16, 128, 0, 128, k=3, math=4)                       # 64 tiles of 8 rows: a quarter of the chip -> direct, split over K
+    assert not tiny.winograd_form(0) and not H.Conv(32, 8, 8, 512, 0, 512, k=3, math=4).winograd_form(0)
+    knob("PDAE_W1_ROWS8", 0)                                                  # ... unless switched off (the round-4 routing)
+    assert not small.winograd_form(0) and not ragged.winograd_form(0) and big.winograd_form(0)
+    knob("PDAE_W1_ROWS8", 1)
     assert not H.Conv(32, 128, 128, 128, 0, 128, k=1, pad=0, math=4).winograd_form(0)
     assert not H.Conv(32, 128, 128, 128, 0, 128, k=3, math=3).winograd_form(0)          # bf16x6: the direct kernels
     pinned = H.Conv(32, 128, 128, 128, 0, 128, k=3, math=4, direct=True)

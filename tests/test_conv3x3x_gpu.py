@@ -36,10 +36,22 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).double().cpu()
 
 
+WMODE = "2"
+
+
+@pytest.fixture(autouse=True, params=["2", "3"], ids=["rows16", "rows8"])
+def _wmode(request):
+    """Every test of this file runs twice: the Winograd form in tiles of 16 rows (PDAE_W1 = 2) and in tiles of 8 rows (PDAE_W1 = 3, round 5: the
+    variant that takes the 16 x 16-pixel layers of the FFHQ-128 step)."""
+    global WMODE
+    WMODE = request.param
+    yield
+
+
 def _both(knob, run):
-    """run() = weight preparation + launch, under the direct kernels (PDAE_W1=0) and under the Winograd-along-x form (PDAE_W1=2)."""
+    """run() = weight preparation + launch, under the direct kernels (PDAE_W1=0) and under the Winograd-along-x form (PDAE_W1 = WMODE)."""
     out = []
-    for on in ("0", "2"):
+    for on in ("0", WMODE):
         knob("PDAE_W1", on)
         out.append(run())
         torch.cuda.synchronize()
@@ -152,7 +164,7 @@ def test_fused_skip_chunks_exist_in_the_direct_form_only(H, knob, case):
     knob("PDAE_W1", "0")
     assert H.conv_fwd_skip_ok(c, cs) and H.conv_skip_wprep_bytes(c, cs) > 0
     nb_skip = H.conv_skip_wprep_bytes(c, cs)
-    knob("PDAE_W1", "2")
+    knob("PDAE_W1", WMODE)
     assert not H.conv_fwd_skip_ok(c, cs) and H.conv_skip_wprep_bytes(c, cs) == 0
     x = torch.randn(N, Hh, W, C, device="cuda"); s0 = torch.randn(N, Hh, W, Cs0, device="cuda")
     s1 = torch.randn(N, Hh, W, Cs1, device="cuda") if Cs1 else None
@@ -171,7 +183,7 @@ def test_direct_bit_in_the_descriptor_keeps_the_fused_skip(H, knob, case):
     """pdae_conv_desc.math | PDAE_MATH_DIRECT (hip.Conv(direct=True)): the FORWARD form of that convolution stays direct under PDAE_W1 -- prepared weights
     and launch agree because both read the same descriptor --, so the fused skip launch is offered and correct; the data gradient through the same
     descriptor ignores the bit and stays in the Winograd form.  (engine.Builder._skip_parts pins wide-skip ResBlocks this way.)"""
-    knob("PDAE_W1", "2")
+    knob("PDAE_W1", WMODE)
     N, Hh, W, C, Cs0, Cs1, Cout, use_gn = case
     Cs, G = Cs0 + Cs1, 32
     x = rn(1, N, C, Hh, W) * 1.2 + 0.3
@@ -308,7 +320,7 @@ def test_accumulating_data_gradient(H, knob):
 def test_grouped_weight_preparation_uses_the_same_form(H, knob):
     """pdae_conv_wprep_job / pdae_conv_wprep_group (one launch for every prepared copy of a plan) must write the same Winograd-form planes as
     pdae_conv_wprep: forward, fused-GroupNorm forward and data-gradient (transposed, fp16 gradient format) jobs."""
-    knob("PDAE_W1", "2")
+    knob("PDAE_W1", WMODE)
     N, Hh, W, C, Cout = 32, 64, 64, 64, 128
     w = nhwc(rn(1, Cout, C, 3, 3, scale=0.05)).cuda()
     c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
@@ -340,14 +352,18 @@ def test_groupnorm_backward_sums_from_the_data_gradient_epilogue(H, knob, case):
     SAME dA, and the whole GroupNorm backward (dx, dgamma, dbeta) against the reduction-pass form on the same tensors."""
     N, Hh, W, C0, C1, Cout = case
     C, G = C0 + C1, 32
-    knob("PDAE_W1", 2)
+    knob("PDAE_W1", WMODE)
     x = rn(1, N, C, Hh, W) * 1.5 + 0.7
     gamma, beta = 1 + 0.2 * rn(2, C), 0.2 * rn(3, C) + 0.3
     w = rn(4, Cout, C, 3, 3, scale=1.0 / math.sqrt(9 * C))
     dy = rn(5, N, Cout, Hh, W) * 2e-3
     c = H.Conv(N, Hh, W, C0, C1, Cout, k=3, math=4)
     nb, tiles = H.conv_gnbwd_bytes(c, f16_grad=True)
-    assert nb == N * tiles * C * 2 * 4 and tiles == (Hh // 16) * (W // 16)
+    th = 16 if WMODE == "2" else 8
+    if (Hh // th) * (W // 16) > 64:                      # more tiles per image than the finalize kernel's workspace holds: the reduction pass runs
+        assert nb == 0
+        return
+    assert nb == N * tiles * C * 2 * 4 and tiles == (Hh // th) * (W // 16)
     xh = nhwc(x).cuda()
     x0 = xh[..., :C0].contiguous()
     x1 = xh[..., C0:].contiguous() if C1 else None
@@ -374,8 +390,8 @@ def test_groupnorm_backward_sums_from_the_data_gradient_epilogue(H, knob, case):
     z = cf[1].view(N, 1, 1, C) * xm + cf[2].view(N, 1, 1, C)
     sg = torch.sigmoid(z)
     dv = dAd * sg * (1 + z * (1 - sg))
-    s0 = dv.view(N, Hh // 16, 16, W // 16, 16, C).sum((2, 4)).reshape(N, tiles, C)
-    s1 = (dv * xm).view(N, Hh // 16, 16, W // 16, 16, C).sum((2, 4)).reshape(N, tiles, C)
+    s0 = dv.view(N, Hh // th, th, W // 16, 16, C).sum((2, 4)).reshape(N, tiles, C)
+    s1 = (dv * xm).view(N, Hh // th, th, W // 16, 16, C).sum((2, 4)).reshape(N, tiles, C)
     p = part.view(N, tiles, C, 2).double().cpu()
     scale0, scale1 = float(dv.abs().sum((1, 2)).max()) / tiles, float((dv * xm).abs().sum((1, 2)).max()) / tiles     # cancellation-free magnitudes
     assert float((p[..., 0] - s0).abs().max()) < 2e-6 * scale0 and float((p[..., 1] - s1).abs().max()) < 2e-6 * scale1
@@ -396,7 +412,7 @@ def test_groupnorm_backward_sums_from_the_data_gradient_epilogue(H, knob, case):
 
 
 def test_groupnorm_backward_sums_are_refused_where_not_built(H, knob):
-    knob("PDAE_W1", 2)
+    knob("PDAE_W1", WMODE)
     assert H.conv_gnbwd_bytes(H.Conv(2, 32, 32, 128, 0, 32, k=3, math=3))[0] == 0                   # bf16x6: the direct kernels
     assert H.conv_gnbwd_bytes(H.Conv(2, 32, 32, 128, 0, 32, k=3, math=4), f16_grad=False)[0] == 0   # without dy_amax the data gradient runs bf16x6
     assert H.conv_gnbwd_bytes(H.Conv(2, 32, 32, 96, 32, 32, k=3, math=4), f16_grad=True)[0] > 0

@@ -107,9 +107,73 @@ def lds_store_hazard_sites(asm, window=6):
         if op in ("ds_write_b64", "ds_write_b128", "ds_write_b96") and len(last) > 1:
             last = {max(last)}
         for j in range(1, window + 1):
-            if k + j < len(ins) and ins[k + j][2].startswith("v_accvgpr_read_b32") and regs(ins[k + j][2].split()[1].rstrip(",")) & last:
-                hits.append((kern, ln, t, ins[k + j][2]))
+            if k + j >= len(ins):
+                break
+            t2 = ins[k + j][2]
+            op2 = t2.split()[0]
+            # round 4: an accumulator read into the register, up to `window` instructions behind any multi-dword store.  Round 5: behind a TWO-ADDRESS
+            # dword store (ds_write2_b32: the second dword leaves the register file last) an ORDINARY vector write is not interlocked either --
+            # `ds_write2_b32 v157, v174, v176` / `v_add_u32 v176, 0x400, v83` (the next store's address formed in the dead data register) stored the
+            # address in lanes 12-15 of every 16, deterministically, in the 8-row instantiation with an epilogue operand
+            hit = op2 == "v_accvgpr_read_b32" or (op in ("ds_write2_b32", "ds_write2st64_b32") and j <= 3 and op2.startswith("v_") and not op2.startswith("v_cmp")
+                                                 and not op2.startswith("v_accvgpr_write"))
+            if hit and len(t2.split()) > 1 and regs(t2.split()[1].rstrip(",")) & last:
+                hits.append((kern, ln, t, t2))
     return hits
+
+
+def output_store_hazard_sites(asm, window=2):
+    """[(kernel, line, store, overwriting instruction)]: a multi-dword GLOBAL store (buffer_store_dwordx2..4 / global_store_dwordx2..4) whose data registers a
+    vector instruction overwrites within `window` instructions.  Round 5, conv3x3y<.., RH = 1> with an epilogue operand: `buffer_store_dwordx4 v[162:165]`
+    followed two instructions later by `v_pk_add_f32 v[162:163], ..` stored the NEW values in lanes 12-15 of every 16 for ~1.9 % of the outputs, varying from
+    run to run, while the store sat in the vector-memory queue behind sixteen operand loads (a build with a spacer behind every store was correct)."""
+    def regs(tok):
+        tok = tok.strip()
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+    ins, kern, hits = [], None, []
+    for i, l in enumerate(asm.split("\n")):
+        if re.match(r"^_Z\w+:", l):
+            kern = l.split(":")[0]
+        t = l.strip().split(";")[0].strip()
+        if t and not t.startswith(".") and not t.endswith(":"):
+            ins.append((i + 1, kern, t))
+    for k, (ln, kern, t) in enumerate(ins):
+        op = t.split()[0]
+        if op.startswith("buffer_store_dwordx"):
+            data = regs(t[len(op):].split(",")[0])
+        elif op.startswith("global_store_dwordx"):
+            data = regs(t[len(op):].split(",")[1])
+        else:
+            continue
+        for j in range(1, window + 1):
+            if k + j >= len(ins):
+                break
+            t2 = ins[k + j][2]
+            op2 = t2.split()[0]
+            if op2.startswith("v_") and not op2.startswith("v_cmp") and len(t2.split()) > 1 and regs(t2.split()[1].rstrip(",")) & data:
+                hits.append((kern, ln, t, t2))
+                break
+    return hits
+
+
+@pytest.mark.timeout(900)
+def test_no_output_store_data_hazard_sites_in_conv3x3y():
+    """The kernel in which the corruption was observed (and every instantiation of it) must not contain the pattern; the other hot sources are scanned
+    and reported: conv3x3r (the PDAE_W1 = 0 / bf16x6 fallback) has such sites in its drain, has never been seen to fail (43 bit-identity cases against
+    conv3x3p) and is listed in DESIGN.md section 6 as an open item."""
+    if "conv3x3y.hip" not in _ASM:
+        resource_table("conv3x3y.hip")
+    sites = output_store_hazard_sites(_ASM["conv3x3y.hip"])
+    assert not sites, sites[:4]
+    demo = "_Zk:\n\tbuffer_store_dwordx4 v[162:165], v82, s[28:31], s11 offen\n\tv_pk_add_f32 v[92:93], v[24:25], v[80:81]\n\tv_pk_add_f32 v[162:163], v[22:23], v[78:79]\n"
+    assert len(output_store_hazard_sites(demo)) == 1
+    for src in ("conv3x3r.hip", "conv3x3p.hip"):
+        if src in _ASM:
+            print(f"[store-data pattern] {src}: {len(output_store_hazard_sites(_ASM[src]))} sites (informational)")
 
 
 @pytest.mark.timeout(900)
@@ -120,7 +184,9 @@ def test_no_lds_store_source_hazard_sites_in_hot_kernels():
         with ThreadPoolExecutor(max_workers=len(missing)) as ex:
             list(ex.map(resource_table, missing))
     bad = {s: lds_store_hazard_sites(_ASM[s])[:3] for s in srcs if lds_store_hazard_sites(_ASM[s])}
-    assert not bad, f"multi-dword LDS stores whose last data register an accumulator read overwrites within 6 instructions: {bad}"
+    assert not bad, f"multi-dword LDS stores whose last data register is overwritten before the store has drained: {bad}"
     # the scan does see the pattern (the shape that failed on the GPU)
     demo = "_Zk:\n\tds_write2_b32 v40, v41, v42 offset1:36\n\tv_sub_f32_e32 v41, v43, v44\n\tv_accvgpr_read_b32 v42, a98\n"
     assert len(lds_store_hazard_sites(demo)) == 1
+    demo5 = "_Zk:\n\tds_write2_b32 v157, v174, v176 offset0:44 offset1:224\n\tv_add_u32_e32 v176, 0x400, v83\n\tds_write2_b32 v176, v175, v177 offset0:32 offset1:68\n"
+    assert len(lds_store_hazard_sites(demo5)) == 1
