@@ -379,30 +379,46 @@ def main():
         comm["per_rank_ms_per_step"] = [round(v / args.steps * 1e3, 3) for v in per_rank]
         comm["exchange_path"] = "fallback: one all-reduce per gradient buffer after the backward" if getattr(st, "_comm_fallback", False) else "bucketed, overlapped with the backward"
         comm["comm_retries"] = int(getattr(st, "comm_retries", 0))
+        comm["adam_grad_scale"] = float(st.plan.arr[st.adam_idx[0][0]].f[7])      # the mean over ranks = sum x (1 / world), folded into the Adam kernel
     loss_val = 0.0 if dry else st.last_loss
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     ms_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
     sat = st.saturation()
 
-    if world > 1 and not dry:                      # after the timed region: collective tail of one step, and the all-reduce alone
-        ev = st.enable_comm_timing()
+    if world > 1:                                  # after the timed region: collective tail of one step (per bucket), and the all-reduce alone
+        st.enable_comm_timing()
         st.step(x0); sync()
-        exposed = ev["bwd_done"].elapsed_time(ev["comm_done"])
+        tm = st.comm_timing_ms()
         st.comm_events = None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dist.barrier(); sync()
-        e0.record()
-        for _, v in st.buckets:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        e1.record(); sync()
-        alone = e0.elapsed_time(e1)
-        tt = torch.tensor([exposed, alone], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        exposed, alone = [float(v) for v in tt.tolist()]
-        comm.update(allreduce_ms_per_step=round(alone, 3), allreduce_exposed_ms_per_step=round(exposed, 3),
-                    overlap_frac=round(max(0.0, 1.0 - exposed / max(alone, 1e-9)), 4),
-                    allreduce_bus_gbps=round(2 * (world - 1) / world * comm["grad_bytes_per_step"] / max(alone, 1e-9) / 1e6, 1))
+        if tm is not None:                           # (None on the fall-back path: there are no buckets then)
+            nb = len(tm["bucket_enqueue_to_complete"])
+            tt = torch.tensor([tm["exposed"], tm["backward"]] + tm["bucket_enqueue_to_complete"] + tm["bucket_complete_after_bwd"], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            v = [float(x) for x in tt.tolist()]
+            exposed = v[0]
+            comm.update(allreduce_exposed_ms_per_step=round(exposed, 3), backward_ms=round(v[1], 3),
+                        bucket_enqueue_to_complete_ms=[round(x, 3) for x in v[2:2 + nb]],          # all-reduce of bucket k seen from the compute stream (max over ranks)
+                        bucket_complete_after_backward_ms=[round(x, 3) for x in v[2 + nb:2 + 2 * nb]])  # how much of it was still running when the backward had ended
+            if not dry:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                dist.barrier(); sync()
+                e0.record()
+                for _, bv in st.buckets:
+                    dist.all_reduce(bv, op=dist.ReduceOp.SUM)
+                e1.record(); sync()
+                alone = e0.elapsed_time(e1)
+            else:
+                dist.barrier()
+                ta = time.perf_counter()
+                for _, bv in st.buckets:
+                    dist.all_reduce(bv, op=dist.ReduceOp.SUM)
+                alone = (time.perf_counter() - ta) * 1e3
+            tt = torch.tensor([alone], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            alone = float(tt.item())
+            comm.update(allreduce_ms_per_step=round(alone, 3), overlap_frac=round(max(0.0, 1.0 - exposed / max(alone, 1e-9)), 4),
+                        allreduce_bus_gbps=round(2 * (world - 1) / world * comm["grad_bytes_per_step"] / max(alone, 1e-9) / 1e6, 1))
 
     wl = "config/ffhq_representation_learning.yml: PDAE representation learning, FFHQ-128 [ASSUMED denoise_fn_config], encoder FFHQEncoder + ShiftUNet, " \
          f"Adam lr {oc['lr']}, EMA {rc['ema_decay']}, dropout {ddpm_cfg['dropout']}"

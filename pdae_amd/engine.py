@@ -197,7 +197,12 @@ class Builder:
         self.fuse_attn = os.environ.get("PDAE_FUSE_ATTN", "1") != "0"  # QK^T -> softmax -> PV (and its backward) as one kernel (pdae_attn_fwd / _bwd)
         self.group_wprep = os.environ.get("PDAE_GROUP_WPREP", "1") != "0"   # prepared copies of trainable weights: one grouped launch per run (Plan.pre_arr)
         self.frozen_of = frozen_of      # FlatModule owning `params`: enables the persistent prepared-weight cache for its frozen part
-        self._frozen_wp = {}
+        # prepared copies of FROZEN weights are shared by every plan of the module (the eps-only sampling plan used to hold a second copy
+        # of the whole trunk's prepared weights): the buffers live on the module, each plan still registers its own (re)preparation ops
+        if frozen_of is not None and not hasattr(frozen_of, "_wp_cache"):
+            object.__setattr__(frozen_of, "_wp_cache", {})
+        self._frozen_wp = frozen_of._wp_cache if frozen_of is not None else {}
+        self._frozen_emitted = set()
         self.acc = int(bool(acc_grads))     # parameter gradients accumulate into (pre-zeroed) buffers
         self.math = H.MATH_NAMES[H.default_math()] if math is None else (H.MATH_NAMES[math] if isinstance(math, str) else int(math))
         self.P = params
@@ -310,12 +315,14 @@ class Builder:
             # per plan into a persistent buffer; Plan.run refreshes them when the module reports a parameter (re)load
             key = (w.data_ptr(), tuple(c.fields()), int(transposed))
             wp = self._frozen_wp.get(key)
-            if wp is None:
+            if wp is None or wp.device != self.p.device:
                 wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)
-                self.p.live.append(wp)
                 self.p.bytes_alloc += wp.numel() * 4
-                self.p.emit_init(H.op_conv_wprep(c, w, transposed, wp), self.frozen_of)
                 self._frozen_wp[key] = wp
+            if key not in self._frozen_emitted:
+                self.p.live.append(wp)
+                self.p.emit_init(H.op_conv_wprep(c, w, transposed, wp), self.frozen_of)
+                self._frozen_emitted.add(key)
             return NoFree(wp)
         if self.group_wprep and self.p.device.type == "cuda":
             # persistent copy, refreshed at the head of every plan run together with all others (they change once per optimizer step)
@@ -522,20 +529,25 @@ class Builder:
         # residual.  PDAE_SKIP_DIRECT_RATIO = r pins the direct form + fused skip (PDAE_MATH_DIRECT in the descriptor, BEFORE the main weights are
         # prepared) where the skip input has >= r x the main input's channels; measured on the FFHQ-128 step (one box): never 51.42 ms, r = 2
         # 51.93, r = 1.4 52.07, always 52.07 -- so the default is never.
+        pinned = False
         if self.skip_direct_ratio > 0 and c.winograd_form(0, gn=gn) and cs.Cin >= self.skip_direct_ratio * c.Cin:
-            c.direct = True
+            c.direct = pinned = True
         nbytes = H.conv_skip_wprep_bytes(c, cs)
         if nbytes == 0:
+            if pinned:
+                c.direct = False                 # (a caller that keeps using c must not lose the Winograd form for nothing)
             return None
         if self.frozen_of is not None and self.frozen_of.is_frozen_storage(ws):
             key = (ws.data_ptr(), tuple(c.fields()), "skip")
             wps = self._frozen_wp.get(key)
-            if wps is None:
+            if wps is None or wps.device != self.p.device:
                 wps = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)
-                self.p.live.append(wps)
                 self.p.bytes_alloc += wps.numel() * 4
-                self.p.emit_init(H.op_conv_skip_wprep(c, cs, ws, wps), self.frozen_of)
                 self._frozen_wp[key] = wps
+            if key not in self._frozen_emitted:
+                self.p.live.append(wps)
+                self.p.emit_init(H.op_conv_skip_wprep(c, cs, ws, wps), self.frozen_of)
+                self._frozen_emitted.add(key)
             wps = NoFree(wps)
         elif self.group_wprep and self.p.device.type == "cuda":
             wps = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)

@@ -32,6 +32,7 @@ class FlatModule(nn.Module):
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_plans", {})
+        object.__setattr__(self, "_wp_cache", {})           # prepared copies of frozen convolution weights, shared by all plans of this module (engine.Builder)
         object.__setattr__(self, "_frozen_version", 0)      # bumped whenever the frozen parameters may have changed (see Plan.watch)
 
     # ------------------------------------------------------------------ construction
@@ -119,6 +120,7 @@ class FlatModule(nn.Module):
 
     def invalidate_plans(self):
         self._plans.clear()
+        self._wp_cache.clear()
 
     def frozen_changed(self):
         """Call after writing frozen parameters by any route other than load_state_dict / reset_parameters: plans keep prepared

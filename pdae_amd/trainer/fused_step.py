@@ -143,6 +143,12 @@ class _FusedStep:
             except (RuntimeError, H.PdaeError):
                 if self.num_iterations != 1 or not getattr(self, "_comm_fallback", False):
                     raise
+                # the retry must not start on one rank while its peers still sit in (or have yet to time out of) their bucketed
+                # collectives -- the fall-back's whole-buffer all-reduces would pair with collectives of another size.  Every rank that abandoned
+                # the bucketed exchange of THIS step meets the others in the rendezvous store first; a rank that never arrives (its step
+                # succeeded?  a sub-group?) makes the others give up and raise
+                if not self._fallback_rendezvous():
+                    raise
                 self.comm_retries = getattr(self, "comm_retries", 0) + 1
                 self.backward_with_allreduce(p.run)          # fall-back path: the whole forward + backward again, then one all-reduce per buffer
         else:
@@ -154,6 +160,30 @@ class _FusedStep:
             self.step_count += 1
             self.micro = 0
         return self.loss
+
+    def _fallback_rendezvous(self):
+        """Store-based meeting point of the ranks that abandoned the bucketed exchange of the current step (world 1: nothing to agree on).  Returns
+        False when the others do not show up within the collective timeout + 60 s (the caller then raises instead of retrying alone)."""
+        if not dist.is_initialized():
+            return True
+        n_ranks = dist.get_world_size(self.pg)
+        if n_ranks <= 1:
+            return True
+        import time
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            key = f"pdae_amd/comm_fallback/step{self.step_count}"
+            n = store.add(key, 1)
+            deadline = time.time() + float(os.environ.get("PDAE_COMM_TIMEOUT_S", "300")) + 60.0
+            while n < n_ranks:
+                if time.time() > deadline:
+                    return False
+                time.sleep(0.02)
+                n = store.add(key, 0)
+            return True
+        except Exception as e:                        # noqa: BLE001  (no store: no agreement, no retry)
+            print(f"[pdae_amd] fallback rendezvous unavailable ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+            return False
 
     def backward_with_allreduce(self, run):
         """Issues the forward+backward op list in segments; as soon as a bucket's gradients are final its all-reduce(sum) is
@@ -187,18 +217,22 @@ class _FusedStep:
         works, cur = [], 0
         ev = self.comm_events
         nc = self.ncomm
+        mark = (lambda: None) if ev is None else ev["mark"]
         if ev is not None:
-            ev["t0"].record()
+            ev["t0"] = mark()
+            ev["enqueue"], ev["complete"] = [], []
         for op_idx, view in self.buckets:
             run(cur, op_idx)
             cur = op_idx
+            if ev is not None:
+                ev["enqueue"].append(mark())             # the bucket's gradients are final at this point of the compute stream
             if nc is not None:
                 nc.all_reduce(view)                      # side stream, behind an event of the compute stream
             else:
                 works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         run(cur, self.n_bwd)
         if ev is not None:
-            ev["bwd_done"].record()
+            ev["bwd_done"] = mark()
         if self.guard is not None and self.math_name == "f16x3":
             if nc is not None:
                 nc.all_reduce(self.guard.t[0:1], op="max")
@@ -206,15 +240,41 @@ class _FusedStep:
                 works.append(dist.all_reduce(self.guard.t[0:1], op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
         if nc is not None:
             nc.wait()
-        for w in works:
+        for k, w in enumerate(works):
             w.wait()
+            if ev is not None and k < len(self.buckets):
+                ev["complete"].append(mark())            # the compute stream has passed bucket k's completion (in bucket order: an upper bound)
         if ev is not None:
-            ev["comm_done"].record()
+            ev["comm_done"] = mark()
 
     def enable_comm_timing(self):
-        """Event triple around one step's backward / collective tail (bench.py: exposed all-reduce time = comm_done - bwd_done)."""
-        self.comm_events = {k: torch.cuda.Event(enable_timing=True) for k in ("t0", "bwd_done", "comm_done")}
+        """Time marks around one step's backward / collective tail (bench.py): t0, per-bucket `enqueue` (gradients final on the compute stream) and
+        `complete` (the compute stream has waited for the bucket's all-reduce), bwd_done, comm_done.  CUDA events on a ROCm device, host clocks in the
+        CPU dry run.  comm_timing_ms() converts them after a synchronisation."""
+        if self.flat_nets[0].device.type == "cuda":
+            def mark():
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                return e
+        else:
+            mark = time.perf_counter
+        self.comm_events = {"mark": mark}
         return self.comm_events
+
+    def comm_timing_ms(self):
+        """{exposed: comm_done - bwd_done, bucket_enqueue_to_complete: [...], bucket_complete_after_bwd: [...]} in ms from the marks of the last step."""
+        ev = self.comm_events
+        if ev is None or "comm_done" not in ev:
+            return None
+        if self.flat_nets[0].device.type == "cuda":
+            torch.cuda.synchronize()
+            d = lambda a, b: float(a.elapsed_time(b))
+        else:
+            d = lambda a, b: (b - a) * 1e3
+        n = min(len(ev["enqueue"]), len(ev["complete"]))
+        return {"exposed": d(ev["bwd_done"], ev["comm_done"]), "backward": d(ev["t0"], ev["bwd_done"]),
+                "bucket_enqueue_to_complete": [round(d(ev["enqueue"][k], ev["complete"][k]), 3) for k in range(n)],
+                "bucket_complete_after_bwd": [round(max(0.0, d(ev["bwd_done"], ev["complete"][k])), 3) for k in range(n)]}
 
     @property
     def last_loss(self):

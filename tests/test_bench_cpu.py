@@ -61,6 +61,28 @@ def test_bench_self_launches_two_ranks_dry():
     assert set(c["bucket_sweep_ms_per_step"]) == {"16", "48", "96"} and c["bucket_mb"] in (16.0, 48.0, 96.0)
 
 
+def test_bench_self_launches_eight_ranks_dry():
+    """the driver's 8-GPU run is the first time RCCL sees more than one rank, so everything around it runs here at the REAL world size:
+    eight gloo ranks, the bucket boundaries of the dry network, the 1 / 8 fold into Adam (rank 0 checks the op record), max-over-ranks timing, and the
+    per-bucket report (enqueue -> complete as the compute stream sees it, what was still running when the backward had ended, overlap fraction)."""
+    import json
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--dry", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dry"] is True and out["scaling"] == "weak" and out["config"]["global_batch"] == 8 * out["config"]["per_gpu_batch"]
+    c = out["comm"]
+    assert c["rccl_ranks"] == 8 and len(c["per_rank_ms_per_step"]) == 8 and abs(out["ms_per_step"] - max(c["per_rank_ms_per_step"])) < 1e-2
+    assert c["buckets"] >= 2 and sum(c["bucket_bytes"]) == c["grad_bytes_per_step"] and c["exchange_path"].startswith("bucketed")
+    assert len(c["bucket_enqueue_to_complete_ms"]) == c["buckets"] == len(c["bucket_complete_after_backward_ms"])
+    assert all(v >= 0 for v in c["bucket_enqueue_to_complete_ms"]) and 0.0 <= c["overlap_frac"] <= 1.0
+    assert c["allreduce_ms_per_step"] > 0 and c["allreduce_exposed_ms_per_step"] >= 0 and c["adam_grad_scale"] == 0.125
+    # the timed region starts right behind the warm-up steps: no sweep, no extra steps in front of it (stderr timeline)
+    assert r.stderr.count("warm-up step done") == 8 * 1
+
+
 def test_bench_workload_comes_from_the_yaml_files():
     sys.path.insert(0, ROOT)
     import bench

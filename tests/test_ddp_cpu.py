@@ -166,3 +166,69 @@ def test_failed_bucketed_exchange_is_retried_through_the_fallback_when_the_plan_
     res = q.get(timeout=300)
     p.join(timeout=60)
     assert res == "ok", res
+
+
+def _two_rank_retry_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), PDAE_COMM_TIMEOUT_S="20")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from pdae_amd.utils import set_seed
+        from pdae_amd.model.shift_unet import ShiftUNet
+        from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
+        from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+        from pdae_amd.trainer.fused_step import FusedRLStep
+        set_seed(0)
+        gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device("cpu"))
+        enc = CELEBA64Encoder(device="cpu", latent_dim=512)
+        dec = ShiftUNet(device="cpu", latent_dim=512, **C.CFG_SHIFT_64)
+        dec.set_train_mode()
+        st = FusedRLStep(gd, enc, dec, copy.deepcopy(enc), copy.deepcopy(dec), 2, 64, 64, bucket_mb=1)
+        runs = []
+
+        def fake_run(first=0, last=None, stream=None, prep=True):       # the "backward": rank-dependent gradients, written by the segment that ends the backward
+            runs.append((first, last))
+            if last == st.n_bwd:
+                dec.flat_grad.copy_(torch.arange(dec.flat_grad.numel(), dtype=torch.float32) % 5 + rank)
+                enc.flat_grad.fill_(float(rank + 1))
+        st.plan.run = fake_run
+        calls = {"n": 0}
+
+        def failing(run):
+            calls["n"] += 1
+            run(0, 5)
+            if rank == 1:
+                raise RuntimeError("simulated RCCL enqueue error on rank 1")                 # fails at once, mid-bucket
+            time.sleep(1.0)                                                                  # its peer: stuck in the collective until the group's timeout
+            raise RuntimeError("simulated collective timeout on rank 0")
+        st._bucketed = failing
+        t0 = time.time()
+        st._run_micro()
+        # both ranks met in the store BEFORE either issued a fall-back collective (rank 1 waited for rank 0's "timeout"), then re-ran the step together
+        assert st._comm_fallback and st.comm_retries == 1 and st.step_count == 1 and calls["n"] == 1
+        assert time.time() - t0 >= (0.9 if rank == 1 else 0.0)
+        exp = sum((torch.arange(dec.flat_grad.numel(), dtype=torch.float32) % 5 + rk) for rk in range(world))
+        assert torch.equal(dec.flat_grad, exp) and torch.equal(enc.flat_grad, torch.full_like(enc.flat_grad, 3.0))
+        st._run_micro()                                                                      # later steps: fall-back, no rendezvous, no retry
+        assert st.comm_retries == 1 and st.step_count == 2
+        q.put((rank, "ok"))
+    except Exception:                             # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_agree_on_the_fallback_before_either_retries():
+    """one rank's bucket enqueue fails mid-backward, its peer leaves the collective later (timeout): the retry on the fall-back path starts
+    only after BOTH have reached the rendezvous, so whole-buffer all-reduces never pair with bucket-sized ones; gradients are the exact sums."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_two_rank_retry_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+    assert res == {0: "ok", 1: "ok"}, res

@@ -134,6 +134,58 @@ def test_f128_train_step_full_topology_vs_oracle(gd):
     _check_grads(got32["grads"], {k: v.cpu() for k, v in got["grads"].items()}, 2e-4)
 
 
+def _plan_census(plan):
+    """Counts, over a plan's op records, the launches that take the round-4 / round-5 forms: Winograd-form 3x3 convolutions (forward incl. fused GroupNorm,
+    data gradient), data gradients that leave GroupNorm-backward sums, weight gradients that recompute a fused GroupNorm input."""
+    from pdae_amd import hip as H
+    n = dict(wino_fwd=0, wino_dgrad=0, gnb=0, wgrad_gn=0, gn_bwd_parts=0, conv3=0)
+    for k in range(plan.n):
+        op = plan.arr[k]
+        i = op.i
+        if op.kind in (H.OP_CONV_FWD, H.OP_CONV_FWD_GN, H.OP_CONV_DGRAD) and i[8] == 3 and i[10] == 1:
+            n["conv3"] += 1
+            c = H.Conv(i[0], i[1], i[2], i[3], i[4], i[7], k=3, up=bool(i[12]), math=i[13])
+            if op.kind == H.OP_CONV_DGRAD:
+                w = c.winograd_form(1, f16_grad=bool(op.p[4]))
+                n["wino_dgrad"] += int(w)
+                n["gnb"] += int(bool(op.p[8]))
+                assert not op.p[8] or w, "GroupNorm-backward sums armed on a launch that is not in the Winograd form"
+            else:
+                n["wino_fwd"] += int(c.winograd_form(0, gn=op.kind == H.OP_CONV_FWD_GN))
+        elif op.kind == H.OP_CONV_WGRAD:
+            n["wgrad_gn"] += int(bool(op.p[7]))
+        elif op.kind == H.OP_GN_BWD:
+            n["gn_bwd_parts"] += int(bool(op.p[19]))
+    return n
+
+
+def test_f128_b32_gradients_directly_vs_oracle_and_the_forms_the_plans_launch(gd):
+    """the per-GPU batch of the benchmark (B = 32, 32 DISTINCT images) against the oracle directly -- this is the only batch at which the
+    F128 step runs the Winograd-form kernels (conv3x3y, 16- and 8-row tiles), the data gradients that leave the GroupNorm-backward sums and the
+    weight gradients that recompute their GroupNorm input -- and an assertion on WHICH forms the training plan and the B = 100 sampling plan launch, so
+    that a routing change cannot silently move these tests back onto the direct kernels."""
+    c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml")
+    x0, t, noise = _batch(32, 3, 128, seed=5)
+    _guard().reset()
+    st, got = _run_rl(gd, enc, dec, 32, 128, x0, t, noise)
+    assert _guard().read()[0] == 0
+    n = _plan_census(st.plan)
+    print("[F128 B=32 training plan]", n)
+    assert n["wino_fwd"] >= 60 and n["wino_dgrad"] >= 25, n                # the 128^2 / 64^2 / wide 32^2 layers (16-row tiles) + the 16^2 layers (8-row tiles)
+    assert n["gnb"] >= 8 and n["gnb"] == n["gn_bwd_parts"], n            # in_layers GroupNorms of the shift branch (dropout is 0 here: out_layers too)
+    assert n["wgrad_gn"] >= 8, n
+    z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise)
+    assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
+    assert abs(got["loss"] - loss) < 1e-4 * abs(loss), (got["loss"], loss)
+    _check_grads(got["grads"], grads, 1e-3)
+    del st
+    # the evaluator's sampling batch (sampler/autoencoding_eval.py:125): the plan of one denoising step
+    dec.set_eval_mode()
+    ns = _plan_census(dec.plan(100, 128, 128, False))
+    print("[F128 B=100 sampling plan]", ns)
+    assert ns["wino_fwd"] >= 100 and ns["wino_fwd"] >= 0.8 * ns["conv3"], ns
+
+
 def test_f128_ddim10_encode_sample_psnr_vs_oracle(gd):
     """ddim5 encode + ddim5 decode (10 decoder passes) at 128x128, B=1: PSNR vs the oracle trajectory > 60 dB on [-1,1] images (stated)."""
     c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml")
