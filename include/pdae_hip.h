@@ -139,6 +139,10 @@ int pdae_conv2d_fwd_skip(const pdae_conv_desc* d, const float* x0, const float* 
  *   pdae_gn_coef_from_conv_stats(...)            mean / rstd / coef ([mu | a | b], as pdae_gn_stats_coef) of the virtual concat of one or two such
  *                                                tensors from their partial sums (fp64 combine); C / G and C0 must be multiples of 4. */
 size_t pdae_conv_stats_bytes(const pdae_conv_desc* d, const pdae_conv_desc* ds, int32_t* tiles_per_image);
+/* The same partial sums for a tensor x[N][HW][C] whose producer cannot leave them (ABI 9; the 3 -> 128 stem runs on the edge kernel): one pass,
+ * part[N][tiles_per_image][C / 4] x (sum, sum of squares) over HW / tiles_per_image pixels each; every GroupNorm that reads x (alone or as one source of a
+ * concat) then takes pdae_gn_coef_from_conv_stats instead of its own statistics pass.  C % 4 == 0.  pdae_op: p[0] = x, p[1] = part, i = N, HW, C, tiles. */
+int pdae_gn_stats_quads(const float* x, int N, int HW, int C, int tiles_per_image, float* part, pdae_stream_t stream);
 int pdae_conv_stats_arm(float* part);
 int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G, float eps, const float* part0, int tpi0, const float* part1, int tpi1,
                                  const float* gamma, const float* beta, const float* ss, const float* zss, float* mean, float* rstd, float* coef,
@@ -339,7 +343,7 @@ enum {
   PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
   PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP,
   PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP, PDAE_OP_GN_COEF_FROM_CONV_STATS, PDAE_OP_CONV_WPREP_GROUP,
-  PDAE_OP_SUBSAMPLE2, PDAE_OP_ZERO_INSERT2
+  PDAE_OP_SUBSAMPLE2, PDAE_OP_ZERO_INSERT2, PDAE_OP_GN_STATS_QUADS
 };
 typedef struct pdae_op {
   int32_t kind;

@@ -561,6 +561,9 @@ extern "C" int pdae_gn_stats(const float* x0, int C0, const float* x1, int C1, i
   PDAE_CHECK_ARG(x0 && mean && rstd && ws && (C1 == 0 || x1), "gn_stats: null pointer");
   return k_gn_stats(x0, C0, x1, C1, N, HW, G, eps, mean, rstd, (float*)ws, S(stream));
 }
+extern "C" int pdae_gn_stats_quads(const float* x, int N, int HW, int C, int tiles_per_image, float* part, pdae_stream_t stream) {
+  return k_gn_stats_quads(x, N, HW, C, tiles_per_image, part, S(stream));
+}
 extern "C" int pdae_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma,
                                   const float* beta, const float* ss, const float* zss, float* mean, float* rstd, float* coef, void* ws,
                                   uint32_t* ticket, pdae_stream_t stream) {
@@ -820,6 +823,7 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
       return pdae_conv2d_fwd_skip(&d, F(0), F(1), F(2), (int)i[14], p[3], F(4), &ds, F(5), F(6), p[7], F(8), FM(9), st);
     }
     case PDAE_OP_SUBSAMPLE2: return pdae_subsample2(F(0), (int)i[0], (int)i[1], (int)i[2], (int)i[3], FM(1), st);
+    case PDAE_OP_GN_STATS_QUADS: return pdae_gn_stats_quads(F(0), (int)i[0], (int)i[1], (int)i[2], (int)i[3], FM(1), st);
     case PDAE_OP_ZERO_INSERT2: return pdae_zero_insert2(F(0), (int)i[0], (int)i[1], (int)i[2], (int)i[3], FM(1), st);
     case PDAE_OP_CONV_WPREP_GROUP: return pdae_conv_wprep_group((const pdae_wprep_job*)p[0], (const int32_t*)p[1], (int)i[0], (int)i[1], st);
     case PDAE_OP_CONV_SKIP_WPREP: {

@@ -76,17 +76,21 @@ __device__ __forceinline__ long long half_row(long long row, int H, int W) {
 #define QLDH 72                                          // bf16 per LDS row: 64 channels + 8 pad = 144 bytes
 template <int NS>
 __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
-  constexpr int SA_PLANES = QNPL(NS) * 128 * QLDH, SA_EPI = 4 * 32 * 68 * 2;        // operand planes | epilogue transpose tiles (4 waves x 32 x 68 fp32)
+  constexpr int SA_PLANES = QNPL(NS) * 128 * QLDH, SA_EPI = 4 * 32 * 36 * 2;        // operand planes | epilogue transpose tiles (4 waves x 32 x 36 fp32)
   __shared__ __attribute__((aligned(16))) unsigned short sA[SA_PLANES > SA_EPI ? SA_PLANES : SA_EPI];
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, h = lane >> 5;   // wave id in an SGPR: everything derived from it is scalar
-  const int wm = wv >> 1, wn = wv & 1;
+  // Wave tile = ALL 128 pixels x 32 output channels (round 5; it was 64 px x 64 ch): every weight fragment is fetched by ONE wave and used for four
+  // products.  The 64 x 64 tile had pairs of waves fetch identical fragments: 64 + 32 one-KB vector-memory instructions per 64-channel stage and
+  // workgroup at ~35 cycles of the CU's vector-memory path each (tools/micro/unit_pipe.hip) -- more than half of the ~6900 cycles a stage took on
+  // the 128^2 skip convolutions (MFMA busy 0.17, 3.7 TB/s: neither roof).  Now 32 + 32; the activation fragments (LDS) double instead.
+  const int wn = wv;
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, loc = bid >> 3;
   int tid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
   const int tn_i = tid % P.tiles_n; tid /= P.tiles_n;
   const int tm_i = tid % P.tiles_m; const int sp = tid / P.tiles_m;
   const long long m0 = (long long)tm_i * 128;
-  const int n0 = tn_i * 128 + wn * 64;
+  const int n0 = tn_i * 128 + wn * 32;
   const int nsteps = P.C >> 4;
   const int s_begin = sp * P.sps, s_end = min(nsteps, s_begin + P.sps);      // 16-channel steps; sps is a multiple of 2
 
@@ -123,24 +127,18 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 
   const int nt_end = P.nt_off + ((P.Nout + 31) >> 5);
   const int nt0 = min(P.nt_off + (n0 >> 5), nt_end - 1);          // tiles beyond the last are clamped onto it: those columns are never stored
-  const int bofs[2] = {0, (nt0 + 1 < nt_end) ? 512 : 0};
   const size_t plane_stride = (size_t)nsteps * P.NT * 512;
-  auto ldb = [&](uint4 (&bq)[2][QNPL(NS)], int s) {
+  auto ldb = [&](uint4 (&bq)[QNPL(NS)], int s) {
     const unsigned short* base = P.wp + ((size_t)s * P.NT + nt0) * 512 + lane * 8;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int p = 0; p < QNPL(NS); ++p)
-        bq[b][p] = *reinterpret_cast<const uint4*>(base + p * plane_stride + bofs[b]);       // branch-free (clamped tile): counted vmcnt waits
+    for (int p = 0; p < QNPL(NS); ++p) bq[p] = *reinterpret_cast<const uint4*>(base + p * plane_stride);       // branch-free (clamped tile): counted vmcnt waits
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[4];                                  // m-tiles a = pixel rows 32 a .. 32 a + 31
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
   // Stage order.  All workgroups of a launch run in near lock step, and stage j of every one of them reads the SAME 256-byte slice of its pixel
   // rows (channels 64 j .. 64 j + 63 of C0- / C1-channel rows): at any moment the chip reads every second (C = 128) or every fourth 256-byte chunk
@@ -151,47 +149,45 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   const int nst = (s_end - s_begin + 3) >> 2;
   const int rot = (P.rot && nst > 1) ? (int)(tm_i % nst) : 0;
   auto stage_first = [&](int j) { int st = j + rot; if (st >= nst) st -= nst; return s_begin + 4 * st; };      // first step of the j-th stage in walk order
-  auto step = [&](int s, int ks, int s_next, const uint4 (&bq)[2][QNPL(NS)], uint4 (&bn)[2][QNPL(NS)]) {
+  auto step = [&](int s, int ks, int s_next, const uint4 (&bq)[QNPL(NS)], uint4 (&bn)[QNPL(NS)]) {
     ldb(bn, s_next);                                // next step's weights (in walk order), always issued (straight-line loads: counted waits)
-    uint4 af[2][QNPL(NS)];
+    uint4 af[4][QNPL(NS)];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int p = 0; p < QNPL(NS); ++p)
-        af[a][p] = *reinterpret_cast<const uint4*>(&sA[(p * 128 + wm * 64 + a * 32 + li) * QLDH + ks * 16 + h * 8]);
+        af[a][p] = *reinterpret_cast<const uint4*>(&sA[(p * 128 + a * 32 + li) * QLDH + ks * 16 + h * 8]);
     __builtin_amdgcn_sched_barrier(0);              // loads first, then the MFMA cluster (the scheduler would sink them behind it)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
 #define PDAE_A(P_) __builtin_bit_cast(bf16x8, af[a][P_])
-#define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[b][P_])
+#define PDAE_B(P_) __builtin_bit_cast(bf16x8, bq[P_])
 #define PDAE_AH(P_) __builtin_bit_cast(f16x8, af[a][P_])
-#define PDAE_BH(P_) __builtin_bit_cast(f16x8, bq[b][P_])
-        if constexpr (NS == 4) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(1), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(1), PDAE_BH(0), acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(0), acc[a][b], 0, 0, 0);
-        } else {
-          if constexpr (NS == 3) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(1), acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(2), acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(2), PDAE_B(0), acc[a][b], 0, 0, 0);
-          }
-          if constexpr (NS >= 2) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(1), acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(0), acc[a][b], 0, 0, 0);
-          }
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(0), acc[a][b], 0, 0, 0);
-        }
+#define PDAE_BH(P_) __builtin_bit_cast(f16x8, bq[P_])
+#define PDAE_EACH(STMT) _Pragma("unroll") for (int a = 0; a < 4; ++a) { STMT; }
+    // product-major over the four accumulators: a dependent pair is four issues apart
+    if constexpr (NS == 4) {
+      PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(1), acc[a], 0, 0, 0))
+      PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(1), PDAE_BH(0), acc[a], 0, 0, 0))
+      PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(PDAE_AH(0), PDAE_BH(0), acc[a], 0, 0, 0))
+    } else {
+      if constexpr (NS == 3) {
+        PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(1), acc[a], 0, 0, 0))
+        PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(2), acc[a], 0, 0, 0))
+        PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(2), PDAE_B(0), acc[a], 0, 0, 0))
+      }
+      if constexpr (NS >= 2) {
+        PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(1), acc[a], 0, 0, 0))
+        PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(1), PDAE_B(0), acc[a], 0, 0, 0))
+      }
+      PDAE_EACH(acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PDAE_A(0), PDAE_B(0), acc[a], 0, 0, 0))
+    }
+#undef PDAE_EACH
 #undef PDAE_A
 #undef PDAE_AH
 #undef PDAE_BH
 #undef PDAE_B
-      }
   };
 
-  uint4 q0[2][QNPL(NS)], q1[2][QNPL(NS)];
+  uint4 q0[QNPL(NS)], q1[QNPL(NS)];
   if (s_begin < s_end) {
     a_gload(stage_first(0));
     ldb(q0, stage_first(0));
@@ -216,69 +212,65 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
       }
     }
   }
-  const long long mw = m0 + wm * 64;
-
-  // ---- epilogue: each wave transposes its 32-pixel x 64-channel accumulator groups through a private LDS tile (the activation tile is
-  // dead by now) so that global traffic is float4 per lane in 256-byte runs; residual / accumulate operands are loaded up front
+  // ---- epilogue: each wave transposes its four 32-pixel x 32-channel accumulators through a private LDS tile (the activation tile is dead by now)
+  // so that global traffic is float4 per lane in 128-byte runs; residual / accumulate operands are loaded up front
   const float oscale = NS == 4 ? P.woscale / ascale : 1.0f;      // exact: powers of two
   if constexpr (NS == 4) pdae_sat_report(P.sat, sat_hit);
   __syncthreads();
-  float* tw = reinterpret_cast<float*>(sA) + wv * (32 * 68);
-  const int er = lane >> 4, ec = (lane & 15) * 4;
+  float* tw = reinterpret_cast<float*>(sA) + wv * (32 * 36);
+  const int er = lane >> 3, ec = (lane & 7) * 4;
   const int colb = n0 + ec;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (P.bias && P.splits == 1 && colb < P.Nout) bias4 = *reinterpret_cast<const float4*>(P.bias + colb);      // Nout % 4 == 0
   const bool col_ok = colb < P.Nout;
-  const unsigned lane_d = (unsigned)(er * P.Nout + (col_ok ? colb : 0));     // the lane's offset inside a 4-row group: the only per-lane address term
-  const size_t row4 = (size_t)4 * P.Nout;
+  const unsigned lane_d = (unsigned)(er * P.Nout + (col_ok ? colb : 0));     // the lane's offset inside an 8-row group: the only per-lane address term
+  const size_t row8 = (size_t)8 * P.Nout;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const long long rbase = mw + a * 32;                                     // wave-uniform first row of this 32-row group
-    float4 rv[8];
+  for (int a = 0; a < 4; ++a) {
+    const long long rbase = m0 + a * 32;                                     // wave-uniform first row of this 32-row group
+    float4 rv[4];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) rv[it] = bias4;
+    for (int it = 0; it < 4; ++it) rv[it] = bias4;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + li] = acc[a][b][r];
+    for (int r = 0; r < 16; ++r) tw[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + li] = acc[a][r];
     if (rbase + 32 <= P.M && P.res_mode != 2) {
       // whole group, same-resolution operands: scalar 64-bit bases + lane_d, no per-row index arithmetic (see conv3x3p.hip)
       const size_t eb = (size_t)rbase * P.Nout;
       if (P.splits == 1 && P.res) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const float4 u = *reinterpret_cast<const float4*>(P.res + eb + it * row4 + lane_d);
+        for (int it = 0; it < 4; ++it) {
+          const float4 u = *reinterpret_cast<const float4*>(P.res + eb + it * row8 + lane_d);
           rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
         }
       }
       if (P.splits == 1 && P.accumulate) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const float4 u = *reinterpret_cast<const float4*>(P.y + eb + it * row4 + lane_d);
+        for (int it = 0; it < 4; ++it) {
+          const float4 u = *reinterpret_cast<const float4*>(P.y + eb + it * row8 + lane_d);
           rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
         }
       }
       float* dst = P.splits > 1 ? P.slab + (size_t)sp * P.M * P.Nout + eb + lane_d : P.y + eb + lane_d;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * 68 + ec]);
+      for (int it = 0; it < 4; ++it) {
+        float4 v = *reinterpret_cast<const float4*>(&tw[(it * 8 + er) * 36 + ec]);
         // the operand scales are powers of two: scaling after the transpose, fused with the bias / residual add, is exact
         if (P.splits > 1) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
         else { v.x = fmaf(v.x, oscale, rv[it].x); v.y = fmaf(v.y, oscale, rv[it].y); v.z = fmaf(v.z, oscale, rv[it].z); v.w = fmaf(v.w, oscale, rv[it].w); }
-        if (col_ok) *reinterpret_cast<float4*>(dst + it * row4) = v;
+        if (col_ok) *reinterpret_cast<float4*>(dst + it * row8) = v;
       }
       continue;
     }
     // partial last group or half-resolution residual: per-row indices
-    long long rowv[8];
+    long long rowv[4];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const long long row = rbase + it * 4 + er;
+    for (int it = 0; it < 4; ++it) {
+      const long long row = rbase + it * 8 + er;
       rowv[it] = (row >= P.M || !col_ok) ? -1 : row;
     }
     if (P.splits == 1 && P.res) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < 4; ++it) {
         const long long row = rowv[it] < 0 ? 0 : rowv[it];
         const float4 u = *reinterpret_cast<const float4*>(P.res + (P.res_mode == 2 ? half_row(row, P.H, P.W) : row) * P.Nout + (col_ok ? colb : 0));
         rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
@@ -286,14 +278,14 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
     }
     if (P.splits == 1 && P.accumulate) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < 4; ++it) {
         const float4 u = *reinterpret_cast<const float4*>(P.y + (rowv[it] < 0 ? 0 : rowv[it]) * P.Nout + (col_ok ? colb : 0));
         rv[it].x += u.x; rv[it].y += u.y; rv[it].z += u.z; rv[it].w += u.w;
       }
     }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      float4 v = *reinterpret_cast<const float4*>(&tw[(it * 4 + er) * 68 + ec]);
+    for (int it = 0; it < 4; ++it) {
+      float4 v = *reinterpret_cast<const float4*>(&tw[(it * 8 + er) * 36 + ec]);
       if (rowv[it] < 0) continue;
       if (P.splits > 1) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; *reinterpret_cast<float4*>(P.slab + ((long long)sp * P.M + rowv[it]) * P.Nout + colb) = v; continue; }
       v.x = fmaf(v.x, oscale, rv[it].x); v.y = fmaf(v.y, oscale, rv[it].y); v.z = fmaf(v.z, oscale, rv[it].z); v.w = fmaf(v.w, oscale, rv[it].w);

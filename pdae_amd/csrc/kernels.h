@@ -8,6 +8,7 @@ int k_gn_stats(const float* x0, int C0, const float* x1, int C1, int N, int HW, 
 int k_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G, float eps, const float* part0, int tpi0, const float* part1, int tpi1,
                               const float* gamma, const float* beta, const float* ss, const float* zss, float* mean, float* rstd, float* coef,
                               hipStream_t st);
+int k_gn_stats_quads(const float* x, int N, int HW, int C, int tpi, float* part, hipStream_t st);
 int k_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma, const float* beta,
                     const float* ss, const float* zss, float* mean, float* rstd, float* coef, float* ws, hipStream_t st, unsigned* ticket = nullptr);
 int k_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss, const float* zss,

@@ -270,6 +270,34 @@ __global__ void __launch_bounds__(256) gn_coef_from_conv_stats_kernel(int N, int
   }
 }
 
+// Partial statistics of a tensor whose producer could not leave them (the 3 -> 128 stem on the edge kernel), in the FORMAT the convolution epilogues
+// write -- part[image][tpi runs of `run` pixels][C / 4] x (sum, sum of squares), unshifted fp32 over run x 4 values, combined in fp64 by
+// gn_coef_from_conv_stats_kernel.  One pass serves every GroupNorm that reads the tensor: the stem output feeds input_blocks.1 and, as the last skip,
+// the final output block of BOTH branches of ShiftUNet -- three statistics passes over 128 x 128 x 128 x N floats (two of them over a 256-channel
+// concat) became one.  block = (run, image), threads = channel quads x pixel lanes.
+__global__ void __launch_bounds__(256) gn_stats_quads_kernel(const float* __restrict__ x, int HW, int C, int run, float2* __restrict__ part) {
+  __shared__ float2 red[256];
+  const int NQ = C >> 2, PL = 256 / NQ, t = threadIdx.x, q = t % NQ, pl = t / NQ;
+  const int n = blockIdx.y, k = blockIdx.x, tpi = gridDim.x;
+  const int p0 = k * run, p1 = min(HW, p0 + run);
+  float s1 = 0.f, s2 = 0.f;
+  if (pl < PL) {
+    const float* b = x + ((size_t)n * HW) * C + q * 4;
+    for (int p = p0 + pl; p < p1; p += PL) {
+      const float4 v = *reinterpret_cast<const float4*>(b + (size_t)p * C);
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, s2))));
+    }
+    red[pl * NQ + q] = make_float2(s1, s2);
+  }
+  __syncthreads();
+  if (t < NQ) {
+    float a = 0.f, b2 = 0.f;
+    for (int l = 0; l < PL; ++l) { const float2 v = red[l * NQ + t]; a += v.x; b2 += v.y; }
+    part[((size_t)n * tpi + k) * NQ + t] = make_float2(a, b2);
+  }
+}
+
 // statistics + finalize + coefficient fold in ONE launch: the partial-sum kernel, whose last block per sample finishes that sample
 __global__ void __launch_bounds__(256) gn_stats_coef_fused_kernel(Src2 s, int N, int HW, int C, int G, int chunk, float eps, float* __restrict__ part,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -633,6 +661,12 @@ int k_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G, float eps, c
   hipLaunchKernelGGL(gn_coef_from_conv_stats_kernel, dim3(N * ((G + 7) / 8)), dim3(256), 0, st, N, HW, C0, C1, G, eps, reinterpret_cast<const float2*>(part0), tpi0,
                      reinterpret_cast<const float2*>(part1), tpi1, gamma, beta, ss, zss, mean, rstd, coef);
   return pdae_launch_status("gn_coef_from_conv_stats");
+}
+
+int k_gn_stats_quads(const float* x, int N, int HW, int C, int tpi, float* part, hipStream_t st) {
+  PDAE_CHECK_ARG(x && part && N > 0 && HW > 0 && C >= 4 && C <= 1024 && (C & 3) == 0 && tpi > 0 && tpi <= HW, "gn_stats_quads: need C %% 4 == 0, C <= 1024, 0 < tpi <= HW");
+  hipLaunchKernelGGL(gn_stats_quads_kernel, dim3(tpi, N), dim3(256), 0, st, x, HW, C, cdiv(HW, tpi), reinterpret_cast<float2*>(part));
+  return pdae_launch_status("gn_stats_quads");
 }
 
 int k_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int HW, int G, float eps, const float* gamma, const float* beta,

@@ -183,6 +183,9 @@ class Builder:
         # TRAINED in_layers stages (GroupNorm -> SiLU -> conv3x3, no dropout) run the same fused forward and their weight gradient recomputes
         # the activation while it stages X (gn_conv_saved): the activated tensor is never written, saved or re-read
         self.fuse_gn_train = os.environ.get("PDAE_FUSE_GN_TRAIN", "1") != "0"
+        # ... where it pays: the weight gradient stages (and now maps) X once per 64 output channels, the forward once per 128, while the pass it
+        # replaces costs two tensor passes whatever the width -- so the form is taken up to this many output channels (measured)
+        self.fuse_gn_train_max_cout = int(os.environ.get("PDAE_FUSE_GN_TRAIN_MAXCOUT", "128"))
         # the two per-(n, c) sums of a GroupNorm backward come out of the epilogue of the data gradient that writes dA (conv_dgrad(gnb=...)) where
         # the kernels build it (Winograd-form 3x3 data gradients, SiLU, no dropout): no reduction pass over (x, dA)
         self.fuse_gn_bwd = os.environ.get("PDAE_FUSE_GN_BWD", "1") != "0"
@@ -228,6 +231,23 @@ class Builder:
     def _note_stats(self, y, part, tpi):
         if part is not None:
             self._ystats[id(y)] = (y, part, tpi)
+
+    def stats_pass(self, y, min_elems=1 << 20):
+        """One pass that leaves the partial statistics of y [N,H,W,C] in the producers' format (pdae_gn_stats_quads) when y has none -- for a large
+        tensor that several GroupNorms read (the stem output: input_blocks.1 and, as the last skip, the final output block of each branch), each of
+        which would otherwise run its own statistics pass over it (or over the concat that contains it)."""
+        if not self.fuse_stats or self._stats_of(y) is not None or y.numel() < min_elems or self.p.device.type != "cuda":
+            return
+        N, Hh, W, C = y.shape
+        HW = Hh * W
+        if (C // GROUPS) % 4 or HW % 128:
+            return
+        tiles = HW // 128
+        part = torch.empty(N * tiles * (C // 4) * 2, dtype=torch.float32, device=self.p.device)
+        self.p.live.append(part)
+        self.p.bytes_alloc += part.numel() * 4
+        self.p.emit(H.op_gn_stats_quads(y, N, HW, C, tiles, part))
+        self._note_stats(y, part, tiles)
 
     def _stats_of(self, x):
         e = self._ystats.get(id(x)) if x is not None else None
@@ -627,7 +647,7 @@ class Builder:
         w, b = self.P[wname + ".weight"], self.P[wname + ".bias"]
         c = H.Conv(N, Hh, W, C0, C1, w.shape[0], k=3, up=up, math=self.math)
         c.gn_in = True
-        if (wname + ".weight") not in self.Gr or c.wprep_bytes(0, gn=True) == 0 or not H.conv_wgrad_gn_ok(self._bwd_desc(c)):
+        if (wname + ".weight") not in self.Gr or c.Cout > self.fuse_gn_train_max_cout or c.wprep_bytes(0, gn=True) == 0 or not H.conv_wgrad_gn_ok(self._bwd_desc(c)):
             return None
         pl = self.p
         gamma, beta = self.P[gname + ".weight"], self.P[gname + ".bias"]

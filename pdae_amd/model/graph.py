@@ -183,6 +183,8 @@ def _run_block(B, cfg, pre, layers, x0, x1, ea, eza, dropout):
         p = f"{pre}.{j}"
         if kind == "conv":
             out, c = B.conv(h0, None, p, 3)
+            if pre == "input_blocks.0":
+                B.stats_pass(out)                     # the stem (edge kernel: no statistics epilogue) feeds three GroupNorms
         elif kind == "res":
             out, c = B.resblock(p, h0, h1, ea, eza, up=d.get("up", False), down=d.get("down", False), dropout=dropout)
         else:

@@ -173,7 +173,7 @@ def test_f128_b32_gradients_directly_vs_oracle_and_the_forms_the_plans_launch(gd
     print("[F128 B=32 training plan]", n)
     assert n["wino_fwd"] >= 60 and n["wino_dgrad"] >= 25, n                # the 128^2 / 64^2 / wide 32^2 layers (16-row tiles) + the 16^2 layers (8-row tiles)
     assert n["gnb"] >= 8 and n["gnb"] == n["gn_bwd_parts"], n            # in_layers GroupNorms of the shift branch (dropout is 0 here: out_layers too)
-    assert n["wgrad_gn"] >= 8, n
+    assert n["wgrad_gn"] >= 6, n                                             # in_layers stages up to 128 output channels (PDAE_FUSE_GN_TRAIN_MAXCOUT)
     z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise)
     assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
     assert abs(got["loss"] - loss) < 1e-4 * abs(loss), (got["loss"], loss)
@@ -183,7 +183,7 @@ def test_f128_b32_gradients_directly_vs_oracle_and_the_forms_the_plans_launch(gd
     dec.set_eval_mode()
     ns = _plan_census(dec.plan(100, 128, 128, False))
     print("[F128 B=100 sampling plan]", ns)
-    assert ns["wino_fwd"] >= 100 and ns["wino_fwd"] >= 0.8 * ns["conv3"], ns
+    assert ns["wino_fwd"] >= 80 and ns["wino_fwd"] >= 0.7 * ns["conv3"], ns      # everything but the 29 convolutions of the 8 x 8 level (image-pair tiles)
 
 
 def test_f128_ddim10_encode_sample_psnr_vs_oracle(gd):

@@ -920,3 +920,34 @@ def test_weight_gradient_gn_input_refuses_ineligible_shapes(H):
     wsb = c.wgrad_ws_bytes()
     with pytest.raises(H.PdaeError):
         H.run(H.op_conv_wgrad(c, x, None, x, dw, ws(wsb), wsb, gn_coef=coef, gn_act=1))
+
+
+@pytest.mark.parametrize("case", [(3, 32, 32, 128, 0), (2, 16, 64, 64, 192), (2, 64, 64, 128, 128)])
+def test_statistics_pass_in_the_producers_format(H, case):
+    """pdae_gn_stats_quads (round 5): one pass leaves (sum, sum of squares) per (image, run of pixels, channel quad) for a tensor whose producer has no
+    statistics epilogue (the stem); pdae_gn_coef_from_conv_stats on them (alone, or as the SECOND source of a concat whose first source has its own
+    partials from another run length) equals the statistics pass pdae_gn_stats_coef on the same tensors."""
+    N, Hh, W, C, C0 = case                       # C0 > 0: the tensor is the second source behind a C0-channel first one
+    G, HW = 32, Hh * W
+    x = (rn(1, N, Hh, W, C) * 1.3 + 0.4).cuda()
+    x0 = (rn(2, N, Hh, W, C0) * 0.7 - 0.2).cuda() if C0 else None
+    Ct = C + C0
+    gamma, beta = (1 + 0.1 * rn(3, Ct)).cuda(), (0.1 * rn(4, Ct)).cuda()
+    tiles = HW // 128
+    part = torch.empty(N * tiles * (C // 4) * 2, device="cuda")
+    H.run(H.op_gn_stats_quads(x, N, HW, C, tiles, part))
+    ref = x.double().view(N, tiles, 128, C // 4, 4)
+    p = part.view(N, tiles, C // 4, 2).double()
+    assert rel_err(p[..., 0], ref.sum((2, 4))) < 1e-5 and rel_err(p[..., 1], (ref * ref).sum((2, 4))) < 1e-5
+    mean, rstd, coef = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda"), torch.empty(3, N, Ct, device="cuda")
+    mean2, rstd2, coef2 = torch.empty_like(mean), torch.empty_like(rstd), torch.empty_like(coef)
+    if C0:
+        t0 = HW // 64                                # the first source's partials come in runs of 64 pixels
+        part0 = torch.empty(N * t0 * (C0 // 4) * 2, device="cuda")
+        H.run(H.op_gn_stats_quads(x0, N, HW, C0, t0, part0))
+        H.run(H.op_gn_coef_from_conv_stats(N, HW, C0, C, G, 1e-5, part0, t0, part, tiles, gamma, beta, None, None, mean, rstd, coef))
+        H.run(H.op_gn_stats_coef(x0, C0, x, C, N, HW, G, 1e-5, gamma, beta, None, None, mean2, rstd2, coef2, ws(H.gn_ws_bytes(N, Ct))))
+    else:
+        H.run(H.op_gn_coef_from_conv_stats(N, HW, C, 0, G, 1e-5, part, tiles, None, 0, gamma, beta, None, None, mean, rstd, coef))
+        H.run(H.op_gn_stats_coef(x, C, None, 0, N, HW, G, 1e-5, gamma, beta, None, None, mean2, rstd2, coef2, ws(H.gn_ws_bytes(N, Ct))))
+    assert rel_err(mean, mean2) < 5e-6 and rel_err(rstd, rstd2) < 2e-5 and rel_err(coef, coef2) < 2e-5
