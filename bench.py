@@ -511,7 +511,7 @@ def main():
         traffic, traffic_src = None, None
         try:                                          # PMC counters cannot be read from inside the process: committed rocprofv3 --pmc passes
             prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            pmc_file = next(f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof, f)))
+            pmc_file = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof, f)))
             pmc = json.load(open(os.path.join(prof, pmc_file)))
             kk = [v for k_, v in pmc["kernels"].items()
                   if k_.startswith("void conv3x3y_kernel<") or k_.startswith("void conv3x3r_kernel<") or (k_.startswith("void conv3x3p_kernel<") and ", 8, false" in k_)]   # every non-pair instantiation
