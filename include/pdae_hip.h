@@ -99,7 +99,10 @@ int pdae_conv2d_fwd(const pdae_conv_desc* d, const float* x0, const float* x1, c
 /* Forward 3x3 convolution of act(a[n,c] * (x - mu[n,c]) + b[n,c]) -- GroupNorm / AdaGN (+ SiLU, act = 1) of module.py:241,257-263,
  * 293-294,379-381 applied while the LDS patch is staged, so the normalised activation never exists in HBM (used where nothing is kept
  * for a backward pass: the frozen trunk, sampling).  coef = [mu | a | b], each [N][C0+C1], from pdae_gn_coef; zero padding applies to the
- * activated tensor; wp = pdae_conv_wprep(d, w, PDAE_WPREP_GN). */
+ * activated tensor; wp = pdae_conv_wprep(d, w, PDAE_WPREP_GN).  act = 0 (the affine map alone) exists in the DIRECT form only: where
+ * pdae_conv3x3_form(d, PDAE_WPREP_GN) == 1 the call fails with PDAE_EINVAL -- OR PDAE_MATH_DIRECT into d->math (before the weights are prepared) to
+ * pin the direct form for such a stage.  Since ABI 9 the same launch also serves TRAINED stages: pair it with pdae_conv_gn_input_arm on the weight
+ * gradient, which recomputes the activation instead of reading a saved copy. */
 int pdae_conv2d_fwd_gn(const pdae_conv_desc* d, const float* x0, const float* x1, const float* coef, int act, const void* wp, const float* bias,
                        const float* res, int res_mode, float* y, pdae_stream_t stream);
 /* ResBlock tail in one launch (module.py:265,276,297):  y = conv3x3_d(in) + bias + conv1x1_ds([s0 | s1]) + bias_s,  in = coef ?
