@@ -36,17 +36,19 @@ static const struct { const char* name; int def; } g_knob_def[KNOB_COUNT] = {
     {"PDAE_W1", 1}, {"PDAE_W1_EFF", 85}, {"PDAE_P3R", 1}, {"PDAE_P3R_MIN", 512}, {"PDAE_P3R_EFF", 85}, {"PDAE_EDGE", 1}, {"PDAE_P3_TH", 0},
     {"PDAE_SPLIT_STATS", 1}, {"PDAE_W3_STAGGER", 0}, {"PDAE_Y_STAGGER", 0}, {"PDAE_C1_SLAB", 1}, {"PDAE_C1_BF16", 0}, {"PDAE_NO_SKINNY", 0},
     {"PDAE_C1_ROT", 1}, {"PDAE_W1_ROWS8", 1}, {"PDAE_W1_EFF8", 70}};
-static int g_knob_val[KNOB_COUNT];
-static bool g_knob_set[KNOB_COUNT];
+#include <atomic>
+static std::atomic<int> g_knob_val[KNOB_COUNT];
+static std::atomic<bool> g_knob_set[KNOB_COUNT];
 static std::mutex g_knob_mu;
 int pdae_knob(int id) {
+  if (g_knob_set[id].load(std::memory_order_acquire)) return g_knob_val[id].load(std::memory_order_relaxed);      // the per-launch path: no lock
   std::lock_guard<std::mutex> lk(g_knob_mu);
-  if (!g_knob_set[id]) {
+  if (!g_knob_set[id].load(std::memory_order_relaxed)) {
     const char* e = getenv(g_knob_def[id].name);
-    g_knob_val[id] = (e && *e) ? atoi(e) : g_knob_def[id].def;
-    g_knob_set[id] = true;
+    g_knob_val[id].store((e && *e) ? atoi(e) : g_knob_def[id].def, std::memory_order_relaxed);
+    g_knob_set[id].store(true, std::memory_order_release);
   }
-  return g_knob_val[id];
+  return g_knob_val[id].load(std::memory_order_relaxed);
 }
 static int knob_id(const char* name) {
   if (name)
@@ -58,7 +60,8 @@ extern "C" int pdae_set_knob(const char* name, int value) {
   const int id = knob_id(name);
   PDAE_CHECK_ARG(id >= 0, "set_knob: unknown knob '%s'", name ? name : "(null)");
   std::lock_guard<std::mutex> lk(g_knob_mu);
-  g_knob_val[id] = value; g_knob_set[id] = true;
+  g_knob_val[id].store(value, std::memory_order_relaxed);
+  g_knob_set[id].store(true, std::memory_order_release);
   return PDAE_OK;
 }
 extern "C" int pdae_get_knob(const char* name, int* value) {
