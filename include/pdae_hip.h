@@ -43,7 +43,7 @@ const char* pdae_last_error(void);
 int pdae_abi_version(void);
 
 /* Tuning / A-B switches (PDAE_W1, PDAE_W1_EFF, PDAE_P3R, PDAE_P3R_MIN, PDAE_P3R_EFF, PDAE_EDGE, PDAE_P3_TH, PDAE_SPLIT_STATS,
- * PDAE_W3_STAGGER, PDAE_Y_STAGGER, PDAE_C1_SLAB, PDAE_C1_BF16, PDAE_NO_SKINNY, PDAE_C1_ROT, PDAE_W1_ROWS8, PDAE_W1_EFF8).  A knob's value is pdae_set_knob() > the environment variable of
+ * PDAE_W3_STAGGER, PDAE_Y_STAGGER, PDAE_C1_SLAB, PDAE_C1_BF16, PDAE_NO_SKINNY, PDAE_C1_ROT, PDAE_W1_ROWS8, PDAE_W1_EFF8, PDAE_W1_MIN8).  A knob's value is pdae_set_knob() > the environment variable of
  * the same name, read ONCE at the knob's first use > the default; the library never re-reads its environment.  Unknown name: PDAE_EINVAL.
  * Changing PDAE_W1 between pdae_conv_wprep and the launch that takes the copy makes that launch fail (form tag), it does not corrupt results. */
 int pdae_set_knob(const char* name, int value);

@@ -56,6 +56,7 @@ enum PdaeKnob {
   KNOB_C1_ROT,        // PDAE_C1_ROT: conv1x1 workgroups start their channel stages at different offsets (1)
   KNOB_W1_ROWS8,      // PDAE_W1_ROWS8: 8-row tiles of the Winograd form for layers too small for 16-row tiles (1)
   KNOB_W1_EFF8,       // PDAE_W1_EFF8: minimum % of the CUs busy in the last round of 8-row tiles when there is more than one round (70)
+  KNOB_W1_MIN8,       // PDAE_W1_MIN8: minimum number of 8-row tiles of a launch for that form (160)
   KNOB_COUNT
 };
 int pdae_knob(int id);

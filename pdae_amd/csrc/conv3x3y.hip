@@ -703,8 +703,8 @@ int conv3x3x_rows(int math, int C, int H, int W, int N, int Nout) {
   const long long per8 = (long long)N * (W / PTW) * (Nout / PBN), tiles8 = per8 * (H / 8), tiles16 = h16 ? per8 * (H / 16) : 0;
   // persistent workgroups, one per CU: the last round of tiles must not leave the chip idle
   if (tiles16 >= 256 && tiles16 * 100 >= ((tiles16 + 255) / 256) * 256 * pdae_knob(KNOB_W1_EFF)) return 2;
-  // 8-row tiles for what is left (round 5): at least 5/8 of the CUs busy in a single round, or rounds filled to PDAE_W1_EFF8 %
-  if (pdae_knob(KNOB_W1_ROWS8) && tiles8 >= 160 && (tiles8 <= 256 || tiles8 * 100 >= ((tiles8 + 255) / 256) * 256 * pdae_knob(KNOB_W1_EFF8))) return 1;
+  // 8-row tiles for what is left (round 5): at least PDAE_W1_MIN8 (160 = 5/8 of the CUs) tiles in a single round, or rounds filled to PDAE_W1_EFF8 %
+  if (pdae_knob(KNOB_W1_ROWS8) && tiles8 >= pdae_knob(KNOB_W1_MIN8) && (tiles8 <= 256 || tiles8 * 100 >= ((tiles8 + 255) / 256) * 256 * pdae_knob(KNOB_W1_EFF8))) return 1;
   return 0;
 }
 bool conv3x3x_ok(int math, int C, int H, int W, int N, int Nout) { return conv3x3x_rows(math, C, H, W, N, Nout) != 0; }
