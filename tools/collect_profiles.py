@@ -50,7 +50,7 @@ for src in HOT:
 DYN_LDS = {"conv3x3y_kernel<4": 2 * 2 * 31104 + 4 * 2 * 32 * 36 * 4 + 1024, "conv3x3y_kernel<2": 2 * 2 * 31104 + 4 * 2 * 32 * 36 * 4 + 1024, "conv3x3y_kernel<1": 2 * 1 * 31104 + 4 * 2 * 32 * 36 * 4 + 1024,
            "conv3x3r_kernel<4": 2 * 2 * 30720 + 4 * 32 * 36 * 4, "conv3x3r_kernel<1": 2 * 1 * 30720 + 4 * 32 * 36 * 4, "conv3x3r_kernel<2": 2 * 2 * 30720 + 4 * 32 * 36 * 4,
            "conv3x3p_kernel<4, 8": 2 * 200 * 80, "conv3x3p_kernel<4, 16": 2 * 360 * 80, "conv3x3w_kernel<4, false": (2 * 180 * 32 + 2 * 128 * 64) * 2 + 256 * 16, "conv3x3w_kernel<4, true": (2 * 200 * 32 + 2 * 128 * 64) * 2 + 256 * 16,
-           "conv1x1_kernel<4": 2 * 128 * 72 * 2, "wino8_kernel": 162176, "wino_kernel": 162176, "conv3x3x_kernel<4": 2 * 51840}
+           "conv1x1_kernel<4": 2 * 128 * 72 * 2}
 
 
 def res_of(kname):
@@ -61,6 +61,9 @@ def res_of(kname):
     for pre, b in DYN_LDS.items():
         if kname.startswith("void " + pre):
             lds = max(lds, b)
+    if kname.startswith("void conv3x3y_kernel<") and ", 1>(" in kname:        # 8-row tiles (RH = 1): 10 x 36 positions per plane instead of 18 x 36
+        planes = 1 if kname.startswith("void conv3x3y_kernel<1") else 2
+        lds = 2 * planes * 17280 + 4 * 2 * 32 * 36 * 4 + 1024
     return r["vgpr"], r["agpr"], r["scratch"], lds
 
 
