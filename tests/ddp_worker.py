@@ -71,6 +71,8 @@ def main():
         loss = st.step(x0[sl], t=t[sl], noise=noise[sl]).detach().clone()
         dist.all_reduce(loss)                                                 # mean of the rank losses = loss of the global batch
         losses.append(float(loss.item()) / world)
+    # the time marks bench.py reports for the data-parallel exchange (round 5): one more step with them armed -- after the state below has been
+    # captured, so that the comparison against the single-process run still sees `--steps` steps
     torch.cuda.synchronize()
     state = {"dec": dec.flat_train, "enc": enc.flat_train, "ema_dec": st.ema_dec.flat_train, "ema_enc": st.ema_enc.flat_train,
              "m_dec": st.m[0], "v_dec": st.v[0], "m_enc": st.m[1], "v_enc": st.v[1]}
@@ -81,9 +83,17 @@ def main():
         same = same and bool(torch.equal(ref, v))
     flag = torch.tensor([int(same)], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    saved = {k: v.cpu().clone() for k, v in state.items()}
+    st.enable_comm_timing()
+    st.step(x0[sl], t=t[sl], noise=noise[sl])
+    tm = st.comm_timing_ms()
+    st.comm_events = None
+    if st.ncomm is None:
+        assert tm is not None and len(tm["bucket_enqueue_to_complete"]) == len(st.buckets) == len(tm["bucket_complete_after_bwd"]), tm
+        assert tm["backward"] > 0 and tm["exposed"] >= 0 and all(v >= 0 for v in tm["bucket_enqueue_to_complete"]), tm
     if rank == 0:
         torch.save({"identical": bool(flag.item()), "losses": losses, "guard": st.saturation(), "backend": a.backend, "native": a.native,
-                    "state": {k: v.cpu() for k, v in state.items()}}, os.path.join(a.out, "result.pt"))
+                    "state": saved, "comm_timing": tm}, os.path.join(a.out, "result.pt"))
     dist.barrier()
     if st.ncomm is not None:
         st.ncomm.close()
