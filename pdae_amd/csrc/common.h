@@ -29,7 +29,7 @@ static inline int pdae_launch_status(const char* what) {
 
 // Timing-probe macros compile pieces of a kernel out (WRONG RESULTS by design).  They are only legal in the side builds of tools/probe_build.py,
 // which defines PDAE_PROBE_BUILD: a product build that picks one up by accident does not compile.
-#if (defined(PDAE_AT_PROBE_NNNOLOAD) || defined(PDAE_AT_PROBE_NNNOMMA) || defined(PDAE_AT_PROBE_NONN) || defined(PDAE_AT_PROBE_NONT) || defined(PDAE_AT_PROBE_NOSCHED) || defined(PDAE_PROBE_NOA) || defined(PDAE_PROBE_NOB) || defined(PDAE_PROBE_NOSTAGE) || defined(PDAE_R_PROBE_24U) || defined(PDAE_R_PROBE_NOA) || defined(PDAE_R_PROBE_NOB) || defined(PDAE_R_PROBE_NOCONV) || defined(PDAE_R_PROBE_NODRAIN) || defined(PDAE_R_PROBE_NOGLOAD) || defined(PDAE_W3_PROBE_6TAPS) || defined(PDAE_W3_PROBE_NOLOAD) || defined(PDAE_W3_PROBE_NOMMA) || defined(PDAE_W3_PROBE_NOSTAGE) || defined(PDAE_Y_PROBE_NOA) || defined(PDAE_Y_PROBE_NOB) || defined(PDAE_Y_PROBE_NOCONV) || defined(PDAE_Y_PROBE_NOEPI) || defined(PDAE_Y_PROBE_NOGLOAD)) && !defined(PDAE_PROBE_BUILD)
+#if (defined(PDAE_C1_PROBE_NOB) || defined(PDAE_C1_PROBE_NOMMA) || defined(PDAE_C1_PROBE_NOCONV) || defined(PDAE_C1_PROBE_NOSTORE) || defined(PDAE_AT_PROBE_NNNOLOAD) || defined(PDAE_AT_PROBE_NNNOMMA) || defined(PDAE_AT_PROBE_NONN) || defined(PDAE_AT_PROBE_NONT) || defined(PDAE_AT_PROBE_NOSCHED) || defined(PDAE_PROBE_NOA) || defined(PDAE_PROBE_NOB) || defined(PDAE_PROBE_NOSTAGE) || defined(PDAE_R_PROBE_24U) || defined(PDAE_R_PROBE_NOA) || defined(PDAE_R_PROBE_NOB) || defined(PDAE_R_PROBE_NOCONV) || defined(PDAE_R_PROBE_NODRAIN) || defined(PDAE_R_PROBE_NOGLOAD) || defined(PDAE_W3_PROBE_6TAPS) || defined(PDAE_W3_PROBE_NOLOAD) || defined(PDAE_W3_PROBE_NOMMA) || defined(PDAE_W3_PROBE_NOSTAGE) || defined(PDAE_Y_PROBE_NOA) || defined(PDAE_Y_PROBE_NOB) || defined(PDAE_Y_PROBE_NOCONV) || defined(PDAE_Y_PROBE_NOEPI) || defined(PDAE_Y_PROBE_NOGLOAD)) && !defined(PDAE_PROBE_BUILD)
 #error "PDAE_*_PROBE_* macros give wrong results by design: build probes with tools/probe_build.py (-DPDAE_PROBE_BUILD), never the product library"
 #endif
 

@@ -74,7 +74,7 @@ __device__ __forceinline__ long long half_row(long long row, int H, int W) {
 }
 
 #define QLDH 72                                          // bf16 per LDS row: 64 channels + 8 pad = 144 bytes
-template <int NS>
+template <int NS, bool GEN>
 __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   constexpr int SA_PLANES = QNPL(NS) * 128 * QLDH, SA_EPI = 4 * 32 * 36 * 2;        // operand planes | epilogue transpose tiles (4 waves x 32 x 36 fp32)
   __shared__ __attribute__((aligned(16))) unsigned short sA[SA_PLANES > SA_EPI ? SA_PLANES : SA_EPI];
@@ -96,30 +96,59 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 
   const float ascale = NS == 4 ? (P.amax ? q_pow2_scale(*P.amax) : 1.0f) : 1.0f;
   // ---- A staging: thread -> (pixel row = idx >> 4, channel quad = idx & 15), 8 float4 per thread and stage
-  float4 apre[8];
+  float4 apre0[8];
   float sat_hit = 0.f;                            // fp16 format: lanes with a value clamped into the window (common.h)
-  auto a_gload = [&](int s0) {                     // stage starting at step s0 (4 steps = 64 channels, fewer at the tail)
+  // Buffer loads (round 5, GEN = false): the lane's offset inside a source (row t >> 4 of the tile, channel quad t & 15) is computed ONCE; the
+  // m-tile, the stage's channel offset and the 16-row step between a lane's eight loads are scalar offsets; rows beyond M and channel quads
+  // beyond the range get an out-of-range lane offset (the scalar offset is not relied on for the range check) and return zeros; the source
+  // is a scalar select of the descriptor.  ONE straight-line sequence of eight loads whatever the stage: the compiler's wait counts stay exact
+  // (see the weight ring below).  Needs every 64-channel stage inside one source (C0 % 64 == 0 or C1 == 0) and M * C_src * 4 < 4 GiB;
+  // GEN = true is the pointer form for everything else (64-bit address arithmetic and a predicated branch per load: 346 of the 830
+  // instructions of a stage).
+  constexpr unsigned G_OOB = 0xfffffff0u, G_ALL = 0xffffffefu;
+  const unsigned g_row = (unsigned)(t >> 4), g_qd = (unsigned)(t & 15);
+  const unsigned g_v0 = g_row * (unsigned)P.C0 * 4u + g_qd * 16u, g_v1 = g_row * (unsigned)P.C1 * 4u + g_qd * 16u;
+  const unsigned g_t0 = (unsigned)m0 * (unsigned)P.C0 * 4u, g_t1 = (unsigned)m0 * (unsigned)P.C1 * 4u;      // (m0 < M: below 4 GiB)
+  const int g_lim = (int)min((long long)128, P.M - m0) - (int)g_row;         // the lane's load l (row g_row + 16 l) exists iff 16 l < g_lim
+  auto a_gload = [&](float4 (&apre)[8], int s0, bool dead) {       // stage starting at step s0 (4 steps = 64 channels, fewer at the tail); dead: all zeros, no traffic
+    if constexpr (!GEN) {
+      const int c0 = s0 << 4, cend = min(s_end << 4, c0 + 64);
+      const unsigned live = dead ? 0u : (unsigned)(cend - c0) >> 2;           // channel quads of this stage that exist
+      const bool second = c0 >= P.C0;
+      const float* base = second ? P.x1 : P.x0;
+      const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)G_ALL, 0x00020000);
+      const unsigned vo = g_qd < live ? (second ? g_v1 : g_v0) : G_OOB;
+      const unsigned so = second ? g_t1 + (unsigned)(c0 - P.C0) * 4u : g_t0 + (unsigned)c0 * 4u;
+      const unsigned rs = (unsigned)(second ? P.C1 : P.C0) * 64u;            // 16 rows
 #pragma unroll
-    for (int l = 0; l < 8; ++l) {
-      const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
-      const int c = (s0 << 4) + qd * 4;
-      const long long p = m0 + row;
-      const bool ok = p < P.M && c < (s_end << 4);
-      const long long pp = ok ? p : 0;               // unconditional load from a clamped address, zeroed afterwards
-      const int cq = ok ? c : 0;
-      const bool first = cq < P.C0;
-      const float4 v = *reinterpret_cast<const float4*>(first ? P.x0 + pp * P.C0 + cq : P.x1 + pp * P.C1 + (cq - P.C0));
-      apre[l] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int l = 0; l < 8; ++l) apre[l] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(srd, (int)(16 * l < g_lim ? vo : G_OOB), (int)(so + l * rs), 0));
+    } else {
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
+        const int c = (s0 << 4) + qd * 4;
+        const long long p = m0 + row;
+        const bool ok = p < P.M && c < (s_end << 4) && !dead;
+        const long long pp = ok ? p : 0;               // unconditional load from a clamped address, zeroed afterwards
+        const int cq = ok ? c : 0;
+        const bool first = cq < P.C0;
+        const float4 v = *reinterpret_cast<const float4*>(first ? P.x0 + pp * P.C0 + cq : P.x1 + pp * P.C1 + (cq - P.C0));
+        apre[l] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
-  auto a_lstore = [&]() {
+  auto a_lstore = [&](float4 (&apre)[8]) {
 #pragma unroll
     for (int l = 0; l < 8; ++l) {
       const int idx = t + 256 * l, row = idx >> 4, qd = idx & 15;
-      if constexpr (NS == 4) pdae_f16_amax4(apre[l], ascale, sat_hit);
       unsigned a[QNPL(NS)], b[QNPL(NS)];
+#ifdef PDAE_C1_PROBE_NOCONV
+      for (int p = 0; p < QNPL(NS); ++p) { a[p] = __builtin_bit_cast(unsigned, apre[l].x) + p; b[p] = __builtin_bit_cast(unsigned, apre[l].z) + p; }
+#else
+      if constexpr (NS == 4) pdae_f16_amax4(apre[l], ascale, sat_hit);
       q_split2<NS>(apre[l].x, apre[l].y, a, ascale);
       q_split2<NS>(apre[l].z, apre[l].w, b, ascale);
+#endif
 #pragma unroll
       for (int p = 0; p < QNPL(NS); ++p) *reinterpret_cast<uint2*>(&sA[(p * 128 + row) * QLDH + qd * 4]) = make_uint2(a[p], b[p]);
     }
@@ -130,6 +159,9 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   const size_t plane_stride = (size_t)nsteps * P.NT * 512;
   auto ldb = [&](uint4 (&bq)[QNPL(NS)], int s) {
     const unsigned short* base = P.wp + ((size_t)s * P.NT + nt0) * 512 + lane * 8;
+#ifdef PDAE_C1_PROBE_NOB
+    if (s != s_begin) return;
+#endif
 #pragma unroll
     for (int p = 0; p < QNPL(NS); ++p) bq[p] = *reinterpret_cast<const uint4*>(base + p * plane_stride);       // branch-free (clamped tile): counted vmcnt waits
   };
@@ -149,8 +181,15 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
   const int nst = (s_end - s_begin + 3) >> 2;
   const int rot = (P.rot && nst > 1) ? (int)(tm_i % nst) : 0;
   auto stage_first = [&](int j) { int st = j + rot; if (st >= nst) st -= nst; return s_begin + 4 * st; };      // first step of the j-th stage in walk order
-  auto step = [&](int s, int ks, int s_next, const uint4 (&bq)[QNPL(NS)], uint4 (&bn)[QNPL(NS)]) {
-    ldb(bn, s_next);                                // next step's weights (in walk order), always issued (straight-line loads: counted waits)
+  // Weight fragments: a ring of four steps (one whole stage).  Slot k is refilled with step k of the NEXT stage right after the products that
+  // read it, so every fragment a stage waits for was requested before that stage's activation prefetch: vector-memory results return in
+  // order, and the two-slot ring this replaces (fragment of step k+1 requested in step k, i.e. AFTER the prefetch of the next stage) made the
+  // `s_waitcnt vmcnt(2)` of every step wait for the whole HBM prefetch in front of it -- the prefetch distance was one step, not one stage,
+  // and the kernel streamed at 4 TB/s whatever else was changed (tools/c1_probe.py).
+  auto step = [&](int ks, uint4 (&bq)[QNPL(NS)], int s_refill) {
+#ifdef PDAE_C1_PROBE_NOMMA
+    if (P.C >= 0) { acc[0][0] += __builtin_bit_cast(float, bq[0].x); ldb(bq, s_refill); return; }
+#endif
     uint4 af[4][QNPL(NS)];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -185,32 +224,34 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
 #undef PDAE_AH
 #undef PDAE_BH
 #undef PDAE_B
+    ldb(bq, s_refill);                              // always issued (straight-line loads: counted waits); beyond the range: a harmless reload
   };
 
-  uint4 q0[QNPL(NS)], q1[QNPL(NS)];
+  uint4 q0[QNPL(NS)], q1[QNPL(NS)], q2[QNPL(NS)], q3[QNPL(NS)];
   if (s_begin < s_end) {
-    a_gload(stage_first(0));
-    ldb(q0, stage_first(0));
-    a_lstore();
+    const int sl = s_end - 1;
+    { const int f = stage_first(0); ldb(q0, f); ldb(q1, f + 1); ldb(q2, min(f + 2, sl)); ldb(q3, min(f + 3, sl)); }
+    a_gload(apre0, stage_first(0), false);
+    a_lstore(apre0);
     __syncthreads();
-    if (nst > 1) a_gload(stage_first(1));
-    for (int j = 0; j < nst; ++j) {                  // a stage = 4 steps, or 2 at the tail of the channel range (C % 32 == 0: an even number)
-      const int s0 = stage_first(j);
-      const int sn = j + 1 < nst ? stage_first(j + 1) : s0;      // (beyond the last stage: a harmless reload)
-      const bool four = s0 + 2 < s_end;
-      step(s0, 0, s0 + 1, q0, q1);
-      step(s0 + 1, 1, four ? s0 + 2 : sn, q1, q0);
-      if (four) {
-        step(s0 + 2, 2, s0 + 3, q0, q1);
-        step(s0 + 3, 3, sn, q1, q0);
-      }
-      if (j + 1 < nst) {                               // tile hand-over
-        __syncthreads();
-        a_lstore();
-        __syncthreads();
-        if (j + 2 < nst) a_gload(stage_first(j + 2));
-      }
+    a_gload(apre0, stage_first(nst > 1 ? 1 : 0), nst <= 1);
+    // A stage = 4 steps.  At the tail of the channel range (2 steps: C % 32 == 0) the last two run on zero activations (a_gload) and a clamped
+    // weight step.  The loop body is branch-free on purpose (the prefetch beyond the last stage is a dead load, the last stage's refills
+    // harmless reloads): with a short stage's refills or the prefetch under a branch, the compiler's wait insertion takes the minimum over the
+    // paths and the fragment waits of the common path drain the prefetch again (and once, with refill targets shared with fragment
+    // temporaries of the other path, put an `s_waitcnt vmcnt(0)` into every stage).
+    for (int j = 0; j + 1 < nst; ++j) {
+      const int sn = stage_first(j + 1);
+      step(0, q0, sn);
+      step(1, q1, sn + 1);
+      step(2, q2, min(sn + 2, sl));
+      step(3, q3, min(sn + 3, sl));
+      __syncthreads();                                 // tile hand-over
+      a_lstore(apre0);
+      __syncthreads();
+      a_gload(apre0, stage_first(j + 2 < nst ? j + 2 : 0), j + 2 >= nst);
     }
+    step(0, q0, sl); step(1, q1, sl); step(2, q2, sl); step(3, q3, sl);
   }
   // ---- epilogue: each wave transposes its four 32-pixel x 32-channel accumulators through a private LDS tile (the activation tile is dead by now)
   // so that global traffic is float4 per lane in 128-byte runs; residual / accumulate operands are loaded up front
@@ -257,7 +298,11 @@ __global__ void __launch_bounds__(256) conv1x1_kernel(const PointParams P) {
         // the operand scales are powers of two: scaling after the transpose, fused with the bias / residual add, is exact
         if (P.splits > 1) { v.x *= oscale; v.y *= oscale; v.z *= oscale; v.w *= oscale; }
         else { v.x = fmaf(v.x, oscale, rv[it].x); v.y = fmaf(v.y, oscale, rv[it].y); v.z = fmaf(v.z, oscale, rv[it].z); v.w = fmaf(v.w, oscale, rv[it].w); }
+#ifdef PDAE_C1_PROBE_NOSTORE
+        if (col_ok && v.x == 1.2345e37f) *reinterpret_cast<float4*>(dst + it * row8) = v;
+#else
         if (col_ok) *reinterpret_cast<float4*>(dst + it * row8) = v;
+#endif
       }
       continue;
     }
@@ -424,9 +469,12 @@ int conv1x1_launch(int math, const float* x0, int C0, const float* x1, int C1, l
   P.tiles_m = q.tiles_m; P.tiles_n = q.tiles_n; P.splits = q.splits; P.sps = q.sps;
   P.slab = (float*)((char*)wp + point_prep_bytes(math, Nrows, P.C));
   P.rot = pdae_knob(KNOB_C1_ROT) != 0;
+  // general (pointer) form: a 64-channel stage would straddle the two sources, or a source reaches 4 GiB
+  const bool gen = (P.C1 > 0 && (P.C0 & 63)) || (unsigned long long)M * (unsigned)(P.C0 > P.C1 ? P.C0 : P.C1) * 4ull >= 0xfff00000ull;
   dim3 grid(q.tiles_m * q.tiles_n * q.splits);
 #define PDAE_C1(NS_)                                                                     \
-  hipLaunchKernelGGL((conv1x1_kernel<NS_>), grid, dim3(256), 0, s, P);                    \
+  if (gen) hipLaunchKernelGGL((conv1x1_kernel<NS_, true>), grid, dim3(256), 0, s, P);    \
+  else hipLaunchKernelGGL((conv1x1_kernel<NS_, false>), grid, dim3(256), 0, s, P);                    \
   if (P.splits > 1) {                                                                    \
     long long nb = (M * (Nout >> 2) + 255) / 256; if (nb > 4096) nb = 4096;              \
     hipLaunchKernelGGL(conv1x1_reduce_kernel, dim3((int)nb), dim3(256), 0, s, P);        \

@@ -479,10 +479,13 @@ def test_conv_bf16_split_modes(H, case, math_mode):
 
 
 @pytest.mark.parametrize("math_mode", [1, 3, 4])
-@pytest.mark.parametrize("case", [(3, 16, 16, 128, 64, 96), (1, 8, 8, 256, 0, 64), (2, 12, 20, 64, 32, 36), (4, 32, 32, 64, 64, 160), (2, 16, 16, 96, 0, 64)])
+@pytest.mark.parametrize("case", [(3, 16, 16, 128, 64, 96), (1, 8, 8, 256, 0, 64), (2, 12, 20, 64, 32, 36), (4, 32, 32, 64, 64, 160), (2, 16, 16, 96, 0, 64),
+                                  (2, 12, 20, 96, 32, 64), (1, 16, 16, 32, 96, 96)])
 def test_conv1x1_kernel(H, case, math_mode):
     """conv1x1.hip: dual-source 1x1 conv with bias / residual (full and half resolution), split-K on small layers, and the data
-    gradient on the whole channel range and on one 32-aligned concat source, against fp64."""
+    gradient on the whole channel range and on one 32-aligned concat source, against fp64.  The last two cases have a 64-channel stage
+    straddling the two sources (C0 % 64 != 0): the general (pointer) instantiation; the others run the buffer-load one, with a short
+    last stage (C % 64 == 32) and a partial last pixel tile among them."""
     N, Hh, W, C0, C1, Cout = case
     Cin = C0 + C1
     tol = MATH_TOL[math_mode]

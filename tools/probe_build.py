@@ -4,7 +4,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pdae_amd.build import CSRC, LIBDIR, SOURCES, HIPCC, FLAGS
-P3, W3, R3, AT, Y3 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip", "attention.hip", "conv3x3y.hip"
+P3, W3, R3, AT, Y3, C1 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip", "attention.hip", "conv3x3y.hip", "conv1x1.hip"
 # (the wn_* / x_* variants of round 4 built winograd.hip / conv3x3x.hip, which left the library in round 5: tools/probes/r04_winograd/README.md)
 VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"]), "nostage": (P3, ["-DPDAE_PROBE_NOSTAGE"]),
             "mfma": (P3, ["-DPDAE_PROBE_NOB", "-DPDAE_PROBE_NOA", "-DPDAE_PROBE_NOSTAGE"]), "clustered": (P3, ["-DPDAE_P3_CLUSTERED"]),
@@ -20,6 +20,9 @@ VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"])
             "y_nobgl": (Y3, ["-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOGLOAD"]), "y_noabgl": (Y3, ["-DPDAE_Y_PROBE_NOA", "-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOGLOAD"]),
             "y_noepi": (Y3, ["-DPDAE_Y_PROBE_NOEPI"]),
             "y_mfma": (Y3, ["-DPDAE_Y_PROBE_NOA", "-DPDAE_Y_PROBE_NOB", "-DPDAE_Y_PROBE_NOCONV", "-DPDAE_Y_PROBE_NOGLOAD", "-DPDAE_Y_PROBE_NOEPI"]),
+            "c1_nob": (C1, ["-DPDAE_C1_PROBE_NOB"]), "c1_nomma": (C1, ["-DPDAE_C1_PROBE_NOMMA"]), "c1_noconv": (C1, ["-DPDAE_C1_PROBE_NOCONV"]),
+            "c1_nostore": (C1, ["-DPDAE_C1_PROBE_NOSTORE"]), "c1_stream": (C1, ["-DPDAE_C1_PROBE_NOB", "-DPDAE_C1_PROBE_NOMMA", "-DPDAE_C1_PROBE_NOCONV"]),
+            "c1_loadonly": (C1, ["-DPDAE_C1_PROBE_NOB", "-DPDAE_C1_PROBE_NOMMA", "-DPDAE_C1_PROBE_NOCONV", "-DPDAE_C1_PROBE_NOSTORE"]),
             "r_24u": (R3, ["-DPDAE_R_PROBE_24U"]),
             "r_mfma": (R3, ["-DPDAE_R_PROBE_NOA", "-DPDAE_R_PROBE_NOB", "-DPDAE_R_PROBE_NOGLOAD", "-DPDAE_R_PROBE_NOCONV", "-DPDAE_R_PROBE_NODRAIN"])}
 only = sys.argv[1:]
