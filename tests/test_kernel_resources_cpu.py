@@ -190,3 +190,48 @@ def test_no_lds_store_source_hazard_sites_in_hot_kernels():
     assert len(lds_store_hazard_sites(demo)) == 1
     demo5 = "_Zk:\n\tds_write2_b32 v157, v174, v176 offset0:44 offset1:224\n\tv_add_u32_e32 v176, 0x400, v83\n\tds_write2_b32 v176, v175, v177 offset0:32 offset1:68\n"
     assert len(lds_store_hazard_sites(demo5)) == 1
+
+
+def mfma_loop_waits(asm, kernel_re):
+    """{kernel: [vmcnt values of the s_waitcnt instructions inside its innermost loops that contain MFMAs]} for the kernels matching kernel_re.
+    Vector-memory results return in order: a wait for an L2-resident weight fragment that was requested AFTER an HBM prefetch drains the prefetch
+    (conv1x1) -- a small vmcnt inside an MFMA loop that also prefetches is the signature."""
+    out, kern, body, label, last_label = {}, None, None, None, None
+    for line in asm.split("\n"):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kern = m.group(1) if re.search(kernel_re, m.group(1)) else None
+            body = None
+            continue
+        if kern is None:
+            continue
+        m = re.match(r"^(\.LBB\w+):", line)
+        if m:
+            last_label = m.group(1)
+        if "Inner Loop Header" in line:                # (on the label's line, or on a comment line of its own under a "Parent Loop" line)
+            body, label = [], last_label
+            continue
+        t = line.strip().split(";")[0].strip()
+        if body is None or not t:
+            continue
+        body.append(t)
+        if t.startswith("s_cbranch") and t.split()[-1] == label:          # the loop's back edge
+            if any(b.startswith("v_mfma") for b in body):
+                out.setdefault(kern, []).extend(int(re.search(r"vmcnt\((\d+)\)", b).group(1)) for b in body if b.startswith("s_waitcnt") and "vmcnt" in b)
+            body = None
+    return out
+
+
+@pytest.mark.timeout(900)
+def test_conv1x1_stage_loop_does_not_drain_its_prefetch():
+    """The buffer-load instantiations of conv1x1_kernel: inside the stage loop every fragment wait leaves the eight prefetch loads of the next stage
+    (and the six younger refills) in flight -- vmcnt(14) --, the hand-over waits for the prefetch with the eight refills behind it in flight, and
+    nothing in the loop waits for an empty queue.  (Round 5: a two-slot weight ring made every step wait with vmcnt(2), i.e. for the whole prefetch.)"""
+    if "conv1x1.hip" not in _ASM:
+        resource_table("conv1x1.hip")
+    waits = mfma_loop_waits(_ASM["conv1x1.hip"], r"conv1x1_kernelILi\dELb0E")
+    assert len(waits) == 4, sorted(waits)
+    for k, w in waits.items():
+        planes = {"1": 1, "2": 2, "4": 2, "3": 3}[re.search(r"ILi(\d)E", k).group(1)]
+        # a step's wait: the 8 prefetch loads + the refills of the three other ring slots (the compiler may issue a slot's refill before or after the wait)
+        assert w and min(w) >= 3 * planes and sum(v >= 8 + 3 * planes - 1 for v in w) >= 3, (k, w)
