@@ -542,6 +542,26 @@ def main():
                                      "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s", "frac": round(w_fl / w_ms / 1e9 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
                                      "launches_per_step": len(wk), "avg_launch_ms": round(w_ms / len(wk), 4), "kernel_ms_per_step": round(w_ms, 3),
                                      "algorithmic_bytes_per_launch": round(w_by / len(wk)), "traffic": w_tr}
+        # the HBM-bound convolution kernel: 1x1 forward launches on the prepared-weight path (conv1x1_kernel), algorithmic bytes = every operand once
+        ck = [k for k in range(st.n_bwd) if st.plan.arr[k].kind == H.OP_CONV_FWD and st.plan.arr[k].i[8] == 1 and bool(st.plan.arr[k].p[6])]
+        if ck:
+            def point_bytes(op):
+                i = op.i
+                return 4.0 * i[0] * (i[1] * i[2] * (i[3] + i[4]) + i[5] * i[6] * i[7] * (2 if bool(op.p[4]) else 1)) + 4.0 * i[7] * (i[3] + i[4])
+            c_ms, c_by = sum(durs[k] for k in ck), sum(point_bytes(st.plan.arr[k]) for k in ck)
+            kb = max(ck, key=lambda k: point_bytes(st.plan.arr[k]))
+            c_tr = None
+            try:
+                cv = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv1x1_kernel<")]
+                c_tr = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in cv) / sum(v["dispatches"] for v in cv)) if cv else None
+            except (NameError, KeyError, ZeroDivisionError):
+                pass
+            out["roofline_1x1"] = {"bound": "hbm", "kernel": "conv1x1_kernel, forward launches (ResBlock skip convolutions, attention qkv / proj_out)", "achieved": round(c_by / c_ms / 1e6, 1),
+                                   "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": round(c_by / c_ms / 1e6 / (PEAK_HBM_TBS * 1e3), 4), "launches_per_step": len(ck),
+                                   "avg_launch_ms": round(c_ms / len(ck), 4), "kernel_ms_per_step": round(c_ms, 3), "algorithmic_bytes_per_launch": round(c_by / len(ck)),
+                                   "traffic": c_tr, "traffic_note": "PMC average over ALL conv1x1_kernel dispatches (forward and data gradient)",
+                                   "largest_launch": {"bytes": round(point_bytes(st.plan.arr[kb])), "ms": round(durs[kb], 4),
+                                                      "gb_per_s": round(point_bytes(st.plan.arr[kb]) / durs[kb] / 1e6, 1)}}
         out["roofline"] = {"bound": "mfma", "kernel": kname,
                            "math": math, "achieved": round(p_fl / p_ms / 1e9, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                            "frac": round(p_fl / p_ms / 1e9 / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
