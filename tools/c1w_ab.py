@@ -10,7 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     for (N, S, C0, C1, Cout) in [(32, 128, 128, 128, 128), (32, 64, 256, 128, 256), (32, 32, 384, 256, 256), (32, 16, 384, 0, 1152), (32, 16, 512, 384, 384), (32, 8, 512, 512, 512)]:
         x0 = torch.randn(N, S, S, C0, device="cuda"); x1 = torch.randn(N, S, S, C1, device="cuda") if C1 else None
         dy = torch.randn(N, S, S, Cout, device="cuda")
-        c = H.Conv(N, S, S, C0, C1, Cout, k=1, math=4)
+        c = H.Conv(N, S, S, C0, C1, Cout, k=1, math=int(os.environ.get("C1W_MATH", "4")))
         wsb = c.wgrad_ws_bytes()
         ws = torch.empty(max(wsb, 4) // 4, device="cuda"); dw = torch.empty(Cout, 1, 1, C0 + C1, device="cuda"); db = torch.empty(Cout, device="cuda")
         am = torch.zeros(4, device="cuda"); H.run(H.op_amax(dy, dy.numel(), am))
