@@ -29,7 +29,9 @@ extern "C" {
 typedef void* pdae_stream_t; /* hipStream_t */
 
 const char* pdae_last_error(void);
-/* ABI history.  9 (round 5): - pdae_wino_* (the gated 2-D Winograd probe left the library: tools/probes/r04_winograd/); + pdae_set_knob / pdae_get_knob
+/* ABI history.  10 (round 5): pdae_op.reserved became pdae_op.flags (PDAE_OPF_SIDE: the executor's second stream) + PDAE_OP_JOIN + knob
+ *   PDAE_SIDE_STREAM; arrays written for ABI 9 (flags = 0) run unchanged.
+ * 9 (round 5): - pdae_wino_* (the gated 2-D Winograd probe left the library: tools/probes/r04_winograd/); + pdae_set_knob / pdae_get_knob
  *   (the library no longer reads its environment per call); + pdae_conv_gn_input_arm / pdae_conv2d_wgrad_gn_ok (weight gradient that recomputes a fused
  *   GroupNorm input); + pdae_conv_gnbwd_bytes / pdae_conv_gnbwd_arm / pdae_gn_bwd_parts_arm (GroupNorm-backward sums from the data
  *   gradient's epilogue); prepared 3x3 weights are TAGGED with their form and a launch that expects the other form fails with PDAE_EINVAL; the
@@ -346,11 +348,17 @@ enum {
   PDAE_OP_SOFTMAX_BWD, PDAE_OP_COLSUM, PDAE_OP_MEMSET, PDAE_OP_COPY, PDAE_OP_CONV_WPREP, PDAE_OP_MLP_MODLN_FWD, PDAE_OP_MLP_MODLN_BWD, PDAE_OP_CONV_FWD_GN, PDAE_OP_CONV_FWD_SKIP, PDAE_OP_GN_STATS_COEF, PDAE_OP_CONV_SKIP_WPREP, PDAE_OP_AMAX,
   PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP,
   PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP, PDAE_OP_GN_COEF_FROM_CONV_STATS, PDAE_OP_CONV_WPREP_GROUP,
-  PDAE_OP_SUBSAMPLE2, PDAE_OP_ZERO_INSERT2, PDAE_OP_GN_STATS_QUADS
+  PDAE_OP_SUBSAMPLE2, PDAE_OP_ZERO_INSERT2, PDAE_OP_GN_STATS_QUADS,
+  PDAE_OP_JOIN     /* (ABI 10) the caller's stream waits for every PDAE_OPF_SIDE op issued so far; no arguments */
 };
+/* pdae_op.flags (ABI 10; the field was `reserved`, always 0).  PDAE_OPF_SIDE: issue this op on the executor's second (low-priority) stream.
+ * It starts when the ops in front of it in the array have finished, and runs beside the ops behind it until the next PDAE_OP_JOIN or the end
+ * of the pdae_run_ops call (which joins).  The caller guarantees that no op between a side op and the next join overwrites the side op's
+ * inputs or touches its outputs.  Knob PDAE_SIDE_STREAM=0: the flag is ignored (everything in order on the caller's stream). */
+#define PDAE_OPF_SIDE 1
 typedef struct pdae_op {
   int32_t kind;
-  int32_t reserved;
+  int32_t flags;   /* PDAE_OPF_* (0: none) */
   void* p[20];     /* pointer arguments, in the order of the corresponding function's pointer parameters */
   int64_t i[24];   /* integer arguments, in order (a pdae_conv_desc is flattened to its 14 fields) */
   double f[12];    /* floating-point arguments, in order */

@@ -20,7 +20,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 9; }
+extern "C" int pdae_abi_version(void) { return 10; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -35,7 +35,7 @@ static inline hipStream_t S(pdae_stream_t s) { return (hipStream_t)s; }
 static const struct { const char* name; int def; } g_knob_def[KNOB_COUNT] = {
     {"PDAE_W1", 1}, {"PDAE_W1_EFF", 85}, {"PDAE_P3R", 1}, {"PDAE_P3R_MIN", 512}, {"PDAE_P3R_EFF", 85}, {"PDAE_EDGE", 1}, {"PDAE_P3_TH", 0},
     {"PDAE_SPLIT_STATS", 1}, {"PDAE_W3_STAGGER", 0}, {"PDAE_Y_STAGGER", 0}, {"PDAE_C1_SLAB", 1}, {"PDAE_C1_BF16", 0}, {"PDAE_NO_SKINNY", 0},
-    {"PDAE_C1_ROT", 1}, {"PDAE_W1_ROWS8", 1}, {"PDAE_W1_EFF8", 70}, {"PDAE_W1_MIN8", 160}};
+    {"PDAE_C1_ROT", 1}, {"PDAE_W1_ROWS8", 1}, {"PDAE_W1_EFF8", 70}, {"PDAE_W1_MIN8", 160}, {"PDAE_SIDE_STREAM", 1}};
 #include <atomic>
 static std::atomic<int> g_knob_val[KNOB_COUNT];
 static std::atomic<bool> g_knob_set[KNOB_COUNT];
@@ -852,17 +852,58 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
 #undef FM
 }
 
+// ---- second stream of the executor.  Ops flagged PDAE_OPF_SIDE (pdae_op.flags) are launched on a low-priority stream owned by the library:
+// each of them first waits for the caller's stream at its position in the op array (its inputs are complete), PDAE_OP_JOIN -- and the end of
+// every pdae_run_ops call -- makes the caller's stream wait for everything launched on the side stream so far.  What the plan builder has to
+// guarantee between a side op and the next join: nothing on the caller's stream overwrites its inputs or reads its outputs (engine.py defers
+// the recycling of such buffers to the join).  Used for the weight gradients: they feed nothing in the backward chain, and the chain's
+// HBM-bound passes (GroupNorm backward, 1x1 data gradients, reductions) leave the matrix pipes idle.
+struct SideStream { int dev = -1; hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool dirty = false; };
+static SideStream g_side[16];
+static SideStream* side_of_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SideStream& q = g_side[dev];
+  if (!q.s) {
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);                    // lo = least priority: the backward chain on the caller's stream goes first
+    const int mode = pdae_knob(KNOB_SIDE_STREAM);                 // 1: least priority, 2: the default priority, 3: highest
+    if (hipStreamCreateWithPriority(&q.s, hipStreamNonBlocking, mode == 2 ? 0 : (mode == 3 ? hi : lo)) != hipSuccess) { q.s = nullptr; return nullptr; }
+    if (hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    q.dev = dev;
+  }
+  return &q;
+}
+static int side_join(SideStream* q, pdae_stream_t stream) {
+  if (!q || !q->dirty) return PDAE_OK;
+  hipError_t e = hipEventRecord(q->join, q->s);
+  if (e == hipSuccess) e = hipStreamWaitEvent(S(stream), q->join, 0);
+  q->dirty = false;
+  if (e != hipSuccess) { pdae_set_error("side stream join: %s", hipGetErrorString(e)); return (int)e; }
+  return PDAE_OK;
+}
+
 extern "C" int pdae_run_ops(const pdae_op* ops, int n, pdae_stream_t stream) {
+  SideStream* side = nullptr;
+  const bool use_side = pdae_knob(KNOB_SIDE_STREAM) != 0;
   for (int k = 0; k < n; ++k) {
-    int e = run_one(ops[k], stream);
+    int e;
+    if (ops[k].kind == PDAE_OP_JOIN) e = side_join(side, stream);
+    else if ((ops[k].flags & PDAE_OPF_SIDE) && use_side && (side || (side = side_of_current_device()))) {
+      hipError_t he = hipEventRecord(side->fork, S(stream));
+      if (he == hipSuccess) he = hipStreamWaitEvent(side->s, side->fork, 0);
+      if (he != hipSuccess) { pdae_set_error("side stream fork: %s", hipGetErrorString(he)); e = (int)he; }
+      else { side->dirty = true; e = run_one(ops[k], (pdae_stream_t)side->s); }
+    } else e = run_one(ops[k], stream);
     if (e != PDAE_OK) {
       conv3x3p_take_stats();                // a statistics request armed for an op that failed before its entry point must not reach a later launch
       { int a_; take_wgn(&a_); PatchGnb g_; take_gnb(&g_); g_gnparts = nullptr; }
       char msg[400];
       snprintf(msg, sizeof(msg), "%s", g_err);
       pdae_set_error("op %d (kind %d): %s", k, ops[k].kind, msg);
+      side_join(side, stream);
       return e;
     }
   }
-  return PDAE_OK;
+  return side_join(side, stream);
 }

@@ -57,6 +57,7 @@ enum PdaeKnob {
   KNOB_W1_ROWS8,      // PDAE_W1_ROWS8: 8-row tiles of the Winograd form for layers too small for 16-row tiles (1)
   KNOB_W1_EFF8,       // PDAE_W1_EFF8: minimum % of the CUs busy in the last round of 8-row tiles when there is more than one round (70)
   KNOB_W1_MIN8,       // PDAE_W1_MIN8: minimum number of 8-row tiles of a launch for that form (160)
+  KNOB_SIDE_STREAM,   // PDAE_SIDE_STREAM: ops flagged PDAE_OPF_SIDE run on the library's second stream (1); 0: on the caller's stream, in order
   KNOB_COUNT
 };
 int pdae_knob(int id);

@@ -45,6 +45,15 @@ class Plan:
         self._tickets = None    # zeroed uint32 words for the "last block finishes" GroupNorm kernels (one stream runs a plan: shared by all its ops)
         self.wprep_jobs = []    # prepared copies of TRAINABLE conv weights: refreshed by ONE grouped launch at the head of every run (compile)
         self.pre_arr = None
+        # second stream (H.OPF_SIDE, emit_side): storage pointers a pending side op reads -> free() parks such buffers until the next join
+        self.side_busy = set()
+        self.side_parked = []
+        self.side_parked_bytes = 0
+        self.side_budget = int(os.environ.get("PDAE_SIDE_BUDGET_MB", "6144")) << 20
+        self.ws_side_bytes = 0
+        self.ws_side = None
+        self.ws_patch_side = []
+        self.n_side = 0
 
     def tickets(self, n):
         """>= n + 1 zero-initialised ticket words (pdae_gn_stats_coef / pdae_gn_bwd) with PDAE_GN_TICKETS=1, else None (default).
@@ -78,7 +87,38 @@ class Plan:
     def free(self, *ts):
         for t in ts:
             if t is not None and not isinstance(t, NoFree) and id(t) not in self.pinned:
-                self.pool.setdefault((t.numel(), t.dtype), []).append(t)
+                if self.side_busy and t.untyped_storage().data_ptr() in self.side_busy:
+                    self.side_parked.append(t)                      # a pending side-stream op still reads it: recycled at the next join
+                    self.side_parked_bytes += t.numel() * t.element_size()
+                else:
+                    self.pool.setdefault((t.numel(), t.dtype), []).append(t)
+
+    # ---- second stream (pdae_hip.h: PDAE_OPF_SIDE / PDAE_OP_JOIN)
+    def emit_side(self, op, reads, ws_slot=None, wsb_slot=None, ws_bytes=0):
+        """Appends `op` flagged for the executor's second stream.  It starts when everything emitted before it has finished and runs beside
+        what is emitted after it, until the next join.  reads: the pooled tensors it reads -- free() parks them until that join, so nothing
+        emitted in between can be handed their memory (the write-after-read hazard of a recycled buffer; the plan's buffers are only ever
+        rewritten through recycling).  Its workspace is the plan's SECOND workspace.  Nothing emitted before the join may read its outputs."""
+        op.flags = H.OPF_SIDE
+        self.recs.append(op)
+        self.n_side += 1
+        for t in reads:
+            if t is not None and not isinstance(t, NoFree):
+                self.side_busy.add(t.untyped_storage().data_ptr())
+        if ws_slot is not None:
+            self.ws_side_bytes = max(self.ws_side_bytes, int(ws_bytes))
+            self.ws_patch_side.append((len(self.recs) - 1, ws_slot, wsb_slot))
+        return len(self.recs) - 1
+
+    def join(self, force=True):
+        """The main stream waits for the side ops emitted so far; their parked inputs return to the pool.  force=False: only when the parked
+        bytes exceed the budget (PDAE_SIDE_BUDGET_MB)."""
+        if not self.side_busy or (not force and self.side_parked_bytes <= self.side_budget):
+            return
+        self.recs.append(H.op_join())
+        self.side_busy.clear()
+        parked, self.side_parked, self.side_parked_bytes = self.side_parked, [], 0
+        self.free(*parked)
 
     def need_ws(self, nbytes):
         self.ws_bytes = max(self.ws_bytes, int(nbytes))
@@ -102,7 +142,10 @@ class Plan:
 
     def compile(self):
         self.guard = H.SaturationGuard.get(self.device)       # arms the fp16-window counter of the math-4 kernels on this device
+        self.join()                                           # (every pdae_run_ops call joins at its end anyway: this returns the parked buffers)
         self.ws = torch.empty(self.ws_bytes // 4 + 64, dtype=torch.float32, device=self.device)
+        if self.ws_patch_side:
+            self.ws_side = torch.empty(self.ws_side_bytes // 4 + 64, dtype=torch.float32, device=self.device)
         self.arr = H.ops_array(self.recs)
         self.n = len(self.recs)
         self.init_arr = H.ops_array(self.init_recs) if self.init_recs else None
@@ -114,6 +157,10 @@ class Plan:
             self.arr[idx].p[ws_slot] = self.ws.data_ptr()
             if wsb_slot is not None:
                 self.arr[idx].i[wsb_slot] = self.ws_bytes
+        for idx, ws_slot, wsb_slot in self.ws_patch_side:
+            self.arr[idx].p[ws_slot] = self.ws_side.data_ptr()
+            if wsb_slot is not None:
+                self.arr[idx].i[wsb_slot] = self.ws_side_bytes
         return self
 
     def pin(self, *ts):
@@ -189,6 +236,8 @@ class Builder:
         # the two per-(n, c) sums of a GroupNorm backward come out of the epilogue of the data gradient that writes dA (conv_dgrad(gnb=...)) where
         # the kernels build it (Winograd-form 3x3 data gradients, SiLU, no dropout): no reduction pass over (x, dA)
         self.fuse_gn_bwd = os.environ.get("PDAE_FUSE_GN_BWD", "1") != "0"
+        # weight gradients on the executor's second stream (Plan.emit_side): beside the GroupNorm-backward / data-gradient chain instead of inside it
+        self.side_wgrad = os.environ.get("PDAE_SIDE_WGRAD", "1") != "0"
         # forward 3x3 convolutions leave the GroupNorm partial statistics of their output behind (pdae_conv_stats_arm); the GroupNorm that
         # reads such a tensor takes them instead of a statistics pass over it
         self.fuse_stats = os.environ.get("PDAE_FUSE_GN_STATS", "1") != "0"
@@ -403,8 +452,15 @@ class Builder:
             ride = self.fuse_db
             am = (amax if (amax is not None and self.amax_ok(c)) else self.dy_amax(c, dy))       # 3x3 and 1x1 weight-gradient kernels: fp16 format with dy_amax
             gn = getattr(cx, "gn", None)                     # (coef, act): x0 / x1 are the RAW sources of a fused-GroupNorm forward (gn_conv_saved)
-            self.p.emit(H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am,
-                                        gn_coef=gn[0] if gn else None, gn_act=gn[1] if gn else 0), ws_slot=4, wsb_slot=len(c.fields()) + 1)
+            wop = H.op_conv_wgrad(c, cx.x0, cx.x1, dy, gw, None, 0, accumulate=self.acc, db=gb if ride else None, dy_amax=am,
+                                  gn_coef=gn[0] if gn else None, gn_act=gn[1] if gn else 0)
+            if self.side_wgrad:
+                # the weight gradient feeds nothing in the backward chain: second stream, beside the GroupNorm-backward / data-gradient ops
+                # emitted next (Plan.emit_side).  It reads x (a saved forward tensor, never recycled), dy and the abs-max scalar.
+                self.p.emit_side(wop, [cx.x0, cx.x1, dy, am, gn[0] if gn else None], ws_slot=4, wsb_slot=len(c.fields()) + 1, ws_bytes=wsb)
+                self.p.join(force=False)
+            else:
+                self.p.emit(wop, ws_slot=4, wsb_slot=len(c.fields()) + 1)
             if am is not None:
                 self._amax_until = len(self.p.recs)
             if ride:

@@ -16,11 +16,12 @@ LIB_PATH = os.environ.get("PDAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpdae
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
  OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX,
  OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD, OP_LINEAR_BWD_GROUP, OP_GN_COEF_FROM_CONV_STATS, OP_CONV_WPREP_GROUP, OP_SUBSAMPLE2,
- OP_ZERO_INSERT2, OP_GN_STATS_QUADS) = range(1, 47)
+ OP_ZERO_INSERT2, OP_GN_STATS_QUADS, OP_JOIN) = range(1, 48)
+OPF_SIDE = 1            # PdaeOp.flags: issue on the executor's second stream (pdae_hip.h)
 
 
 class PdaeOp(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("p", ctypes.c_void_p * 20),
+    _fields_ = [("kind", ctypes.c_int32), ("flags", ctypes.c_int32), ("p", ctypes.c_void_p * 20),
                 ("i", ctypes.c_int64 * 24), ("f", ctypes.c_double * 12)]
 
 
@@ -197,6 +198,11 @@ def make_op(kind, p=(), i=(), f=()):
     for k, v in enumerate(f):
         o.f[k] = float(v)
     return o
+
+
+def op_join():
+    """The caller's stream waits for every side-stream op issued so far (PDAE_OP_JOIN)."""
+    return make_op(OP_JOIN)
 
 
 def current_stream_ptr():
