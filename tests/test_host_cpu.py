@@ -210,3 +210,47 @@ def test_eps_only_sampling_plan_shares_the_input_buffers_and_has_no_shift_ops():
     # x is an input of both op lists and must never have been handed back to either buffer pool
     for pl in (full, pe):
         assert all(t is not full.x and t is not full.t for ts in pl.pool.values() for t in ts)
+
+
+def test_plan_parks_what_a_side_stream_op_reads_until_the_join():
+    """Plan.emit_side / join (the executor's second stream, pdae_hip.h PDAE_OPF_SIDE / PDAE_OP_JOIN), on CPU tensors: a buffer that a pending side op
+    reads is not handed out again by buf() -- neither as itself nor through a view of its storage -- until a join has been emitted; the join
+    is an op of its own; side ops get the SECOND workspace; compile() leaves nothing parked."""
+    import torch
+    from pdae_amd import hip as H
+    from pdae_amd.engine import Plan
+    p = Plan(torch.device("cpu"))
+    a, b = p.buf(8, 8), p.buf(8, 8)
+    main_op = H.make_op(H.OP_MEMSET, [a], [256])
+    side_op = H.make_op(H.OP_COPY, [a, b], [256])
+    p.emit(main_op)
+    k = p.emit_side(side_op, [a.view(64)], ws_slot=5, wsb_slot=3, ws_bytes=1 << 16)       # a VIEW of `a`: the storage is what counts
+    assert p.recs[k].flags == H.OPF_SIDE and p.recs[0].flags == 0
+    p.free(a)
+    c = p.buf(8, 8)
+    assert c.data_ptr() != a.data_ptr(), "the side op's input was recycled before the join"
+    assert p.side_parked and p.side_parked_bytes == 256
+    p.join(force=False)                                         # below the budget: nothing happens
+    assert p.side_parked and p.recs[-1].kind != H.OP_JOIN
+    p.join()
+    assert p.recs[-1].kind == H.OP_JOIN and not p.side_parked and not p.side_busy
+    d = p.buf(8, 8)
+    assert d.data_ptr() == a.data_ptr()                         # now it is back in the pool
+    p.free(b)                                                   # (b is an OUTPUT of the side op: not parked, the builder never reads it before a join)
+    p.emit_side(H.make_op(H.OP_COPY, [c, d], [256]), [c])
+    p.free(c)
+    n = len(p.recs)
+    p.compile()
+    assert p.ws_side is not None and p.arr[k].p[5] == p.ws_side.data_ptr() and p.arr[k].i[3] == p.ws_side_bytes and p.ws_side_bytes == 1 << 16
+    assert len(p.recs) == n + 1 and p.recs[-1].kind == H.OP_JOIN and not p.side_parked
+
+
+def test_builder_switch_for_side_stream_weight_gradients(monkeypatch):
+    """PDAE_SIDE_WGRAD is read when a Builder is created (the census over a real training plan runs in the GPU suite, tests/test_side_stream_gpu.py)."""
+    import torch
+    from pdae_amd.engine import Plan, Builder
+    monkeypatch.setenv("PDAE_SIDE_WGRAD", "0")
+    b0 = Builder(Plan(torch.device("cpu")), {}, grads={}, save=True)
+    monkeypatch.setenv("PDAE_SIDE_WGRAD", "1")
+    b1 = Builder(Plan(torch.device("cpu")), {}, grads={}, save=True)
+    assert b0.side_wgrad is False and b1.side_wgrad is True

@@ -1,0 +1,74 @@
+"""GPU: the executor's second stream (include/pdae_hip.h: PDAE_OPF_SIDE, PDAE_OP_JOIN; pdae_amd/engine.py: Plan.emit_side / join).
+(a) ordering of a hand-made op array: a side op sees what the ops in front of it wrote, a join makes its result visible to the ops behind it,
+    and every pdae_run_ops call joins at its end;
+(b) the representation-learning step: which ops of its plan carry the flag, and parameters / EMA / Adam moments after three steps BIT-IDENTICAL
+    with the flag honoured (PDAE_SIDE_STREAM=1) and ignored (=0) -- the weight gradients only moved in time."""
+import copy
+import pytest
+import torch
+
+from tests.conftest import load_golden, T
+from tests.golden import make_fixtures_cfg as C
+from oracle import pdae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_side_op_ordering_fork_and_join():
+    from pdae_amd import hip as H
+    n = 1 << 24                                            # 64 MB per buffer: the copies take long enough to expose a missing dependency
+    a = torch.zeros(n, device=DEV); b = torch.zeros(n, device=DEV); c = torch.zeros(n, device=DEV); src = torch.full((n,), 3.0, device=DEV)
+    side = H.make_op(H.OP_COPY, [a, b], [4 * n]); side.flags = H.OPF_SIDE
+    ops = [H.make_op(H.OP_COPY, [src, a], [4 * n]),       # main: a = 3
+           side,                                           # side: b = a        (must wait for the op in front of it)
+           H.op_join(),
+           H.make_op(H.OP_COPY, [b, c], [4 * n])]          # main: c = b        (must wait for the side op)
+    for _ in range(5):
+        for t in (a, b, c):
+            t.zero_()
+        H.run_ops(H.ops_array(ops), len(ops))
+        torch.cuda.synchronize()
+        assert float(c.min()) == 3.0 and float(c.max()) == 3.0
+    # without an explicit join the call itself joins: the result of a trailing side op is visible to whatever the stream runs next
+    for _ in range(5):
+        b.zero_()
+        H.run_ops(H.ops_array(ops[:2]), 2)
+        d = b.clone()                                      # torch, same stream, right behind the call
+        torch.cuda.synchronize()
+        assert float(d.min()) == 3.0
+
+
+def _three_steps(knob, mode):
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from pdae_amd.trainer.fused_step import FusedRLStep
+    knob("PDAE_SIDE_STREAM", mode)
+    g = load_golden("rl_step")
+    cfg = C.CFG_SHIFT_64
+    enc = CELEBA64Encoder(device=DEV, latent_dim=512); enc.load_state_dict(O.synth_state_dict(O.encoder_param_shapes("CELEBA64Encoder", 512), int(g["seed_enc"])))
+    dec = ShiftUNet(device=DEV, latent_dim=512, **cfg); dec.load_state_dict(O.synth_state_dict(O.unet_param_shapes(cfg, shift=True, latent_dim=512), int(g["seed_dec"])))
+    enc.train(); dec.set_train_mode()
+    ema_enc, ema_dec = copy.deepcopy(enc), copy.deepcopy(dec)
+    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, torch.device(DEV))
+    st = FusedRLStep(gd, enc, dec, ema_enc, ema_dec, 2, 64, 64, lr=1e-4, ema_decay=0.9999)
+    x0 = T(g["x0"]).to(DEV)
+    losses = [float(st.step(x0, t=T(g[f"t{s}"]).to(DEV), noise=T(g[f"noise{s}"]).to(DEV))) for s in range(3)]
+    torch.cuda.synchronize()
+    return st, losses, [enc.flat_train.clone(), dec.flat_train.clone(), ema_enc.flat_train.clone(), ema_dec.flat_train.clone()] + [m.clone() for m in st.m] + [v.clone() for v in st.v]
+
+
+def test_training_step_is_bit_identical_with_and_without_the_second_stream(knob):
+    from pdae_amd import hip as H
+    st, l1, s1 = _three_steps(knob, 1)
+    recs = st.plan.recs
+    side = [k for k, o in enumerate(recs) if o.flags & H.OPF_SIDE]
+    wg = [k for k, o in enumerate(recs) if o.kind == H.OP_CONV_WGRAD]
+    assert wg and side == wg, "every convolution weight gradient -- and nothing else -- runs on the second stream"
+    assert all(k < st.n_bwd for k in side)
+    assert st.plan.ws_side is not None and not st.plan.side_parked
+    _, l0, s0 = _three_steps(knob, 0)
+    assert l0 == l1
+    for x, y in zip(s0, s1):
+        assert torch.equal(x, y)
