@@ -10,6 +10,7 @@ and torch autograd) with a plan built once per (network, batch shape, mode):
 Only what the path needs is differentiated: the frozen trunk / eps-branch of ShiftUNet emit no backward.
 """
 import math
+import bisect
 import copy
 import os
 from types import SimpleNamespace as NS
@@ -54,6 +55,9 @@ class Plan:
         self.ws_side = None
         self.ws_patch_side = []
         self.n_side = 0
+        self.side_branch_ws = False
+        self.side_mode = False    # inside `with plan.side():` every emitted op goes to the second stream (a whole branch of the graph)
+        self._spans = []          # sorted (start, end) address ranges of the pool's buffers: which buffer does an op's raw pointer belong to
 
     def tickets(self, n):
         """>= n + 1 zero-initialised ticket words (pdae_gn_stats_coef / pdae_gn_bwd) with PDAE_GN_TICKETS=1, else None (default).
@@ -80,6 +84,7 @@ class Plan:
             t = torch.empty(n, dtype=dtype, device=self.device).view(*shape)
             self.live.append(t)
             self.bytes_alloc += n * t.element_size()
+            bisect.insort(self._spans, (t.data_ptr(), t.data_ptr() + n * t.element_size()))
         if zero:
             self.emit(H.op_memset(t, t.numel() * t.element_size()))
         return t
@@ -128,10 +133,44 @@ class Plan:
         """Appends an op record (built eagerly: records hold raw device pointers, the tensors stay alive in
         `self.live` / the parameter store).  ws_slot / wsb_slot: pointer / int slots that receive the shared
         workspace pointer and its size when the plan is compiled."""
+        if self.side_mode:
+            return self._emit_side_branch(op, ws_slot, wsb_slot)
         self.recs.append(op)
         if ws_slot is not None:
             self.ws_patch.append((len(self.recs) - 1, ws_slot, wsb_slot))
         return len(self.recs) - 1
+
+    def _emit_side_branch(self, op, ws_slot, wsb_slot):
+        """An op of a branch that runs on the second stream as a whole (side()): EVERY pool buffer one of its pointers falls into -- inputs and
+        outputs -- is parked when freed, until the next join: nothing the other stream allocates in the meantime can alias them."""
+        op.flags = H.OPF_SIDE
+        self.recs.append(op)
+        self.n_side += 1
+        for k in range(len(op.p)):
+            a = op.p[k]
+            if a:
+                j = bisect.bisect_right(self._spans, (a, 1 << 62)) - 1
+                if j >= 0 and self._spans[j][0] <= a < self._spans[j][1]:
+                    self.side_busy.add(self._spans[j][0])
+        if ws_slot is not None:
+            self.ws_patch_side.append((len(self.recs) - 1, ws_slot, wsb_slot))
+            self.side_branch_ws = True                       # (sized like the main workspace at compile: need_ws may still grow)
+        return len(self.recs) - 1
+
+    def side(self, on=True):
+        """Context: the ops emitted inside run on the executor's second stream, in their order, beside what the main stream is given next.
+        For a branch of the graph whose inputs are complete when it starts and whose results are read only behind a join (the caller emits
+        it): the shift branch of ShiftUNet beside the frozen trunk's output blocks (model/graph.py)."""
+        plan = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = plan.side_mode
+                plan.side_mode = bool(on)
+
+            def __exit__(self_, *exc):
+                plan.side_mode = self_.prev
+        return _Ctx()
 
     def emit_init(self, op, module):
         """Op that only depends on `module`'s frozen parameters (prepared conv weights): runs once, and again whenever
@@ -145,6 +184,7 @@ class Plan:
         self.join()                                           # (every pdae_run_ops call joins at its end anyway: this returns the parked buffers)
         self.ws = torch.empty(self.ws_bytes // 4 + 64, dtype=torch.float32, device=self.device)
         if self.ws_patch_side:
+            self.ws_side_bytes = max(self.ws_side_bytes, self.ws_bytes if self.side_branch_ws else 0)
             self.ws_side = torch.empty(self.ws_side_bytes // 4 + 64, dtype=torch.float32, device=self.device)
         self.arr = H.ops_array(self.recs)
         self.n = len(self.recs)

@@ -262,9 +262,14 @@ def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shif
     skips = list(hs)
     eps_h, mid_ctx = _run_block(B, cfg, "middle_block", middle, h, None, ea, None, dropout and keep_all)
     shift_h = smid_ctx = None
+    # The shift branch (shift_middle_block, shift_output_blocks, shift_out) and the trunk's middle / output blocks both start from the input blocks'
+    # results and meet only in the caller (loss / sampler update): the shift branch is emitted for the executor's SECOND stream (Plan.side), so the
+    # HBM-bound ops of either branch (1x1 skip convolutions, GroupNorm coefficient / apply launches) run beside the other's MFMA kernels.
+    side_shift = shift and os.environ.get("PDAE_SIDE_SHIFT", "1") != "0"
     if shift:
         B.save = keep_all or train_shift
-        shift_h, smid_ctx = _run_block(B, cfg, "shift_middle_block", middle, h, None, ea, eza, dropout)
+        with pl.side(side_shift):
+            shift_h, smid_ctx = _run_block(B, cfg, "shift_middle_block", middle, h, None, ea, eza, dropout)
         B.save = keep_all
     out_ctx, sout_ctx = [], []
     recycle_skips = not (keep_all or train_shift)
@@ -277,7 +282,8 @@ def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shif
         eps_h = new
         if shift:
             B.save = keep_all or train_shift
-            new, cs = _run_block(B, cfg, f"shift_output_blocks.{i}", layers, shift_h, prev, ea, eza, dropout)
+            with pl.side(side_shift):
+                new, cs = _run_block(B, cfg, f"shift_output_blocks.{i}", layers, shift_h, prev, ea, eza, dropout)
             B.save = keep_all
             sout_ctx.append(cs)
             if recycle_skips and shift_h is not h:
@@ -291,10 +297,12 @@ def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shif
     g_out = shead = None
     if shift:
         B.save = keep_all or train_shift
-        g_out, shead = _head(B, "shift_out", shift_h)
+        with pl.side(side_shift):
+            g_out, shead = _head(B, "shift_out", shift_h)
         B.save = keep_all
         if recycle_skips:
             pl.free(shift_h)
+        pl.join()                                        # both outputs are read next
     return NS(cfg=cfg, tctx=tctx, semb=semb, eza=eza, l_lab=l_lab, in_ctx=in_ctx, mid_ctx=mid_ctx, smid_ctx=smid_ctx, out_ctx=out_ctx,
               sout_ctx=sout_ctx, head=head, shead=shead, eps=eps, shift=g_out, skips=skips, z=z, x=x)
 
