@@ -254,3 +254,41 @@ def test_builder_switch_for_side_stream_weight_gradients(monkeypatch):
     monkeypatch.setenv("PDAE_SIDE_WGRAD", "1")
     b1 = Builder(Plan(torch.device("cpu")), {}, grads={}, save=True)
     assert b0.side_wgrad is False and b1.side_wgrad is True
+
+
+def test_plan_side_branch_parks_inputs_and_outputs_and_shiftunet_uses_it(monkeypatch):
+    """Plan.side(): every op emitted inside carries PDAE_OPF_SIDE and every pool buffer one of its pointers falls into (inputs AND outputs, matched by
+    address range) is parked when freed; ShiftUNet's plan puts exactly its shift branch there and joins behind it (PDAE_SIDE_SHIFT=0: nothing)."""
+    import torch
+    from pdae_amd import hip as H
+    from pdae_amd.engine import Plan
+    p = Plan(torch.device("cpu"))
+    a, b, c = p.buf(16), p.buf(16), p.buf(16)
+    with p.side():
+        k = p.emit(H.make_op(H.OP_COPY, [a[4:], b], [48]))     # a pointer INTO a's buffer, and an output
+    assert p.recs[k].flags == H.OPF_SIDE and not p.side_mode
+    p.emit(H.make_op(H.OP_COPY, [c, c], [64]))
+    assert p.recs[-1].flags == 0
+    p.free(a, b, c)
+    got = {p.buf(16).data_ptr() for _ in range(3)}
+    assert c.data_ptr() in got and a.data_ptr() not in got and b.data_ptr() not in got       # only the main stream's buffer came back
+    p.join()
+    assert {p.buf(16).data_ptr(), p.buf(16).data_ptr()} == {a.data_ptr(), b.data_ptr()}
+
+    from pdae_amd.model.shift_unet import ShiftUNet
+    cfg = dict(input_channel=3, base_channel=32, channel_multiplier=[1, 2], num_residual_blocks_of_a_block=1, attention_resolutions=[],
+               num_heads=1, head_channel=-1, use_new_attention_order=False, dropout=0.0)
+
+    def census(flag):
+        monkeypatch.setenv("PDAE_SIDE_SHIFT", flag)
+        dec = ShiftUNet(device=torch.device("cpu"), latent_dim=64, **cfg)
+        dec.eval()
+        pl = dec.plan(2, 32, 32, False)
+        side = [k for k, o in enumerate(pl.recs) if o.flags & H.OPF_SIDE]
+        joins = [k for k, o in enumerate(pl.recs) if o.kind == H.OP_JOIN]
+        return pl, side, joins
+    pl, side, joins = census("1")
+    assert side and joins and max(side) < max(joins) and not pl.side_parked and not pl.side_busy
+    assert 0.2 < len(side) / len(pl.recs) < 0.6                 # roughly the shift half of what follows the input blocks
+    _, side0, _ = census("0")
+    assert not side0
