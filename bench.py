@@ -516,11 +516,11 @@ def main():
         traffic, traffic_src = None, None
         try:                                          # PMC counters cannot be read from inside the process: committed rocprofv3 --pmc passes
             prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            pmc_file = next(f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof, f)))
+            pmc_file = next(f for f in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json") if os.path.exists(os.path.join(prof, f)))
             pmc = json.load(open(os.path.join(prof, pmc_file)))
             kk = [v for k_, v in pmc["kernels"].items()
                   if k_.startswith("void conv3x3y_kernel<") or k_.startswith("void conv3x3r_kernel<") or (k_.startswith("void conv3x3p_kernel<") and ", 8, false" in k_)]   # every non-pair instantiation
-            wk_pmc = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3w_kernel<") and "false" in k_]
+            wk_pmc = [v for k_, v in pmc["kernels"].items() if k_.startswith("void conv3x3v_kernel<") or (k_.startswith("void conv3x3w_kernel<") and "false" in k_)]
             if kk and pmc.get("math", "bf16x6") == math:
                 traffic = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in kk) / sum(v["dispatches"] for v in kk))
                 traffic_src = f"profiles/{pmc_file}: committed rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE, gfx950 x2 fetch correction) of this command -- PMC counters cannot be read inside the timed process"
@@ -543,7 +543,7 @@ def main():
                 w_tr = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in wk_pmc) / sum(v["dispatches"] for v in wk_pmc)) if wk_pmc else None
             except NameError:
                 pass
-            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv3x3w_kernel (3x3 weight gradient, transposing LDS reads)", "achieved": round(w_fl / w_ms / 1e9, 2),
+            out["roofline_wgrad"] = {"bound": "mfma", "kernel": "conv3x3v_kernel (3x3 weight gradient, producer / consumer waves, transposing LDS reads; conv3x3w_kernel on the 8-pixel-wide and narrow layers)", "achieved": round(w_fl / w_ms / 1e9, 2),
                                      "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s", "frac": round(w_fl / w_ms / 1e9 / (PEAK_BF16_MFMA_TFLOPS / 3), 4),
                                      "launches_per_step": len(wk), "avg_launch_ms": round(w_ms / len(wk), 4), "kernel_ms_per_step": round(w_ms, 3),
                                      "algorithmic_bytes_per_launch": round(w_by / len(wk)), "traffic": w_tr}
@@ -577,7 +577,7 @@ def main():
                            "frac_of_f32_mfma_peak": round(p_fl / p_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
                            "heaviest_launch": {"gflop": round(fl[kbig] / 1e9, 2), "ms": round(durs[kbig], 4),
                                                "tflops": round(fl[kbig] / durs[kbig] / 1e9, 2)},
-                           "family": {"kernels": "conv3x3y + conv3x3r + conv3x3p + conv3x3w + conv1x1 + igemm(_bf) (every conv fwd/dgrad/wgrad and dense GEMM)",
+                           "family": {"kernels": "conv3x3y + conv3x3r + conv3x3p + conv3x3v + conv3x3w + conv1x1 + igemm(_bf) (every conv fwd/dgrad/wgrad and dense GEMM)",
                                       "achieved": round(ig_fl / ig_ms / 1e9, 2), "frac": round(ig_fl / ig_ms / 1e9 / fam_peak, 4), "peak": round(fam_peak, 1),
                                       "launches_per_step": n_ig, "algorithmic_gflop_per_step": round(ig_fl / 1e9, 1),
                                       "ms_per_step": round(ig_ms, 3), "all_ops_ms_per_step": round(sum(durs), 3)}}

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpdae_hip.so")
-SOURCES = ["api.hip", "igemm.hip", "conv3x3p.hip", "conv3x3r.hip", "conv3x3y.hip", "wprep.hip", "conv3x3w.hip", "conv1x1.hip", "convhead.hip", "convedge.hip", "skinny.hip", "norm.hip", "mlp.hip", "elementwise.hip", "metric.hip", "image.hip", "attention.hip", "comm.hip"]
+SOURCES = ["api.hip", "igemm.hip", "conv3x3p.hip", "conv3x3r.hip", "conv3x3y.hip", "wprep.hip", "conv3x3w.hip", "conv3x3v.hip", "conv1x1.hip", "convhead.hip", "convedge.hip", "skinny.hip", "norm.hip", "mlp.hip", "elementwise.hip", "metric.hip", "image.hip", "attention.hip", "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 

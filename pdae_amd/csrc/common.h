@@ -29,7 +29,7 @@ static inline int pdae_launch_status(const char* what) {
 
 // Timing-probe macros compile pieces of a kernel out (WRONG RESULTS by design).  They are only legal in the side builds of tools/probe_build.py,
 // which defines PDAE_PROBE_BUILD: a product build that picks one up by accident does not compile.
-#if (defined(PDAE_C1_PROBE_NOB) || defined(PDAE_C1_PROBE_NOMMA) || defined(PDAE_C1_PROBE_NOCONV) || defined(PDAE_C1_PROBE_NOSTORE) || defined(PDAE_AT_PROBE_NNNOLOAD) || defined(PDAE_AT_PROBE_NNNOMMA) || defined(PDAE_AT_PROBE_NONN) || defined(PDAE_AT_PROBE_NONT) || defined(PDAE_AT_PROBE_NOSCHED) || defined(PDAE_PROBE_NOA) || defined(PDAE_PROBE_NOB) || defined(PDAE_PROBE_NOSTAGE) || defined(PDAE_R_PROBE_24U) || defined(PDAE_R_PROBE_NOA) || defined(PDAE_R_PROBE_NOB) || defined(PDAE_R_PROBE_NOCONV) || defined(PDAE_R_PROBE_NODRAIN) || defined(PDAE_R_PROBE_NOGLOAD) || defined(PDAE_W3_PROBE_6TAPS) || defined(PDAE_W3_PROBE_NOLOAD) || defined(PDAE_W3_PROBE_NOMMA) || defined(PDAE_W3_PROBE_NOSTAGE) || defined(PDAE_Y_PROBE_NOA) || defined(PDAE_Y_PROBE_NOB) || defined(PDAE_Y_PROBE_NOCONV) || defined(PDAE_Y_PROBE_NOEPI) || defined(PDAE_Y_PROBE_NOGLOAD)) && !defined(PDAE_PROBE_BUILD)
+#if (defined(PDAE_C1_PROBE_NOB) || defined(PDAE_C1_PROBE_NOMMA) || defined(PDAE_C1_PROBE_NOCONV) || defined(PDAE_C1_PROBE_NOSTORE) || defined(PDAE_AT_PROBE_NNNOLOAD) || defined(PDAE_AT_PROBE_NNNOMMA) || defined(PDAE_AT_PROBE_NONN) || defined(PDAE_AT_PROBE_NONT) || defined(PDAE_AT_PROBE_NOSCHED) || defined(PDAE_PROBE_NOA) || defined(PDAE_PROBE_NOB) || defined(PDAE_PROBE_NOSTAGE) || defined(PDAE_R_PROBE_24U) || defined(PDAE_R_PROBE_NOA) || defined(PDAE_R_PROBE_NOB) || defined(PDAE_R_PROBE_NOCONV) || defined(PDAE_R_PROBE_NODRAIN) || defined(PDAE_R_PROBE_NOGLOAD) || defined(PDAE_W3_PROBE_6TAPS) || defined(PDAE_W3_PROBE_NOLOAD) || defined(PDAE_W3_PROBE_NOMMA) || defined(PDAE_W3_PROBE_NOSTAGE) || defined(PDAE_V_PROBE_NOSTAGE) || defined(PDAE_V_PROBE_NOLOAD) || defined(PDAE_V_PROBE_NOMMA) || defined(PDAE_Y_PROBE_NOA) || defined(PDAE_Y_PROBE_NOB) || defined(PDAE_Y_PROBE_NOCONV) || defined(PDAE_Y_PROBE_NOEPI) || defined(PDAE_Y_PROBE_NOGLOAD)) && !defined(PDAE_PROBE_BUILD)
 #error "PDAE_*_PROBE_* macros give wrong results by design: build probes with tools/probe_build.py (-DPDAE_PROBE_BUILD), never the product library"
 #endif
 
@@ -58,6 +58,7 @@ enum PdaeKnob {
   KNOB_W1_EFF8,       // PDAE_W1_EFF8: minimum % of the CUs busy in the last round of 8-row tiles when there is more than one round (70)
   KNOB_W1_MIN8,       // PDAE_W1_MIN8: minimum number of 8-row tiles of a launch for that form (160)
   KNOB_SIDE_STREAM,   // PDAE_SIDE_STREAM: ops flagged PDAE_OPF_SIDE run on the library's second stream (1); 0: on the caller's stream, in order
+  KNOB_W3V,           // PDAE_W3V: 3x3 weight gradients in the producer / consumer form conv3x3v.hip where it applies (1); 0: conv3x3w.hip everywhere
   KNOB_COUNT
 };
 int pdae_knob(int id);

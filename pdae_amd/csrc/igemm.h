@@ -77,6 +77,13 @@ size_t conv3x3w_workspace_bytes(int N, int H, int W, int C, int Cout);
 int conv3x3w_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
                     int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part = nullptr, int* db_rows = nullptr,
                     const float* dy_amax = nullptr, float* db = nullptr, const float* x1 = nullptr, int C0 = 0, const float* coef = nullptr, int act = 0);
+// conv3x3v.hip: the producer / consumer form of the same weight gradient (one workgroup per CU: four matrix waves fed by four staging waves);
+// conv3x3w_launch / conv3x3w_workspace_bytes route to it for the shapes it takes (knob PDAE_W3V)
+bool conv3x3v_ok(int math, int C, int H, int W, int N, int Cout);
+size_t conv3x3v_workspace_bytes(int N, int H, int W, int C, int Cout);
+int conv3x3v_launch(int math, const float* x, int N, int Hs, int Ws, int C, int H, int W, int up, const float* dy, int Cout, float* dw,
+                    int accumulate, float* ws, size_t ws_bytes, hipStream_t s, float** db_part, int* db_rows, const float* dy_amax, float* db,
+                    const float* x1, int C0, const float* coef, int act);
 // the same kernel with GroupNorm + SiLU recomputed on the RAW two-source input [x | x1] while it is staged (coef = [mu | a | b], pdae_gn_coef)
 bool conv3x3w_gn_ok(int math, int KH, int KW, int stride, int pad, int C0, int C1, int H, int W, int N, int Cout);
 

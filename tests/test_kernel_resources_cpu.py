@@ -16,7 +16,7 @@ import pytest
 
 from pdae_amd import build as B
 
-HOT = ["conv3x3y.hip", "conv3x3r.hip", "conv3x3p.hip", "conv3x3w.hip", "conv1x1.hip", "attention.hip", "convedge.hip", "norm.hip"]
+HOT = ["conv3x3y.hip", "conv3x3r.hip", "conv3x3p.hip", "conv3x3w.hip", "conv3x3v.hip", "conv1x1.hip", "attention.hip", "convedge.hip", "norm.hip"]
 # kernel-name regex -> why a scratch allocation is tolerated there
 ALLOWED = {
     r"conv3x3y_kernelILi2ELb1E": "three-product bf16 split (PDAE_CONV_MATH=bf16x3) with fused GroupNorm input: 24 bytes, not on the default path",
@@ -73,7 +73,7 @@ def test_hot_kernels_use_no_scratch_memory():
     assert not bad, f"kernels with scratch memory (source, kernel, bytes per lane, spilled VGPRs): {bad}"
     # the instantiations the F128 training / sampling plans launch most (profiles/r03_kernel_stats.txt) must be in the table at all
     names = " ".join(k["name"] for rows in tables.values() for k in rows)
-    for must in ("conv3x3y_kernelILi4ELb1E", "conv3x3y_kernelILi4ELb0E", "conv3x3r_kernelILi4ELb1E", "conv3x3r_kernelILi4ELb0E", "attn_bwd_kv_kernelILi4ELi4E", "conv3x3w_kernelILi4E", "conv1x1_kernelILi4E"):
+    for must in ("conv3x3y_kernelILi4ELb1E", "conv3x3y_kernelILi4ELb0E", "conv3x3r_kernelILi4ELb1E", "conv3x3r_kernelILi4ELb0E", "attn_bwd_kv_kernelILi4ELi4E", "conv3x3w_kernelILi4E", "conv3x3v_kernelILi4ELb0E", "conv3x3v_kernelILi4ELb1E", "conv1x1_kernelILi4E"):
         assert must in names, must
 
 

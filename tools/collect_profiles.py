@@ -49,7 +49,7 @@ for src in HOT:
 # dynamic LDS of the kernels that size it at launch (bytes per workgroup; launch code of the respective .hip file)
 DYN_LDS = {"conv3x3y_kernel<4": 2 * 2 * 31104 + 4 * 2 * 32 * 36 * 4 + 1024, "conv3x3y_kernel<2": 2 * 2 * 31104 + 4 * 2 * 32 * 36 * 4 + 1024, "conv3x3y_kernel<1": 2 * 1 * 31104 + 4 * 2 * 32 * 36 * 4 + 1024,
            "conv3x3r_kernel<4": 2 * 2 * 30720 + 4 * 32 * 36 * 4, "conv3x3r_kernel<1": 2 * 1 * 30720 + 4 * 32 * 36 * 4, "conv3x3r_kernel<2": 2 * 2 * 30720 + 4 * 32 * 36 * 4,
-           "conv3x3p_kernel<4, 8": 2 * 200 * 80, "conv3x3p_kernel<4, 16": 2 * 360 * 80, "conv3x3w_kernel<4, false": (2 * 180 * 32 + 2 * 128 * 64) * 2 + 256 * 16, "conv3x3w_kernel<4, true": (2 * 200 * 32 + 2 * 128 * 64) * 2 + 256 * 16,
+           "conv3x3p_kernel<4, 8": 2 * 200 * 80, "conv3x3p_kernel<4, 16": 2 * 360 * 80, "conv3x3v_kernel<4": 2 * (2 * 2 * (180 * 32 + 32) + 2 * 128 * 64) * 2, "conv3x3w_kernel<4, false": (2 * 180 * 32 + 2 * 128 * 64) * 2 + 256 * 16, "conv3x3w_kernel<4, true": (2 * 200 * 32 + 2 * 128 * 64) * 2 + 256 * 16,
            "conv1x1_kernel<4": 2 * 128 * 72 * 2}
 
 

@@ -4,12 +4,14 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pdae_amd.build import CSRC, LIBDIR, SOURCES, HIPCC, FLAGS
-P3, W3, R3, AT, Y3, C1 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip", "attention.hip", "conv3x3y.hip", "conv1x1.hip"
+P3, W3, R3, AT, Y3, C1, V3 = "conv3x3p.hip", "conv3x3w.hip", "conv3x3r.hip", "attention.hip", "conv3x3y.hip", "conv1x1.hip", "conv3x3v.hip"
 # (the wn_* / x_* variants of round 4 built winograd.hip / conv3x3x.hip, which left the library in round 5: tools/probes/r04_winograd/README.md)
 VARIANTS = {"nob": (P3, ["-DPDAE_PROBE_NOB"]), "noa": (P3, ["-DPDAE_PROBE_NOA"]), "nostage": (P3, ["-DPDAE_PROBE_NOSTAGE"]),
             "mfma": (P3, ["-DPDAE_PROBE_NOB", "-DPDAE_PROBE_NOA", "-DPDAE_PROBE_NOSTAGE"]), "clustered": (P3, ["-DPDAE_P3_CLUSTERED"]),
             "w3_nomma": (W3, ["-DPDAE_W3_PROBE_NOMMA"]), "w3_nostage": (W3, ["-DPDAE_W3_PROBE_NOSTAGE"]), "w3_noload": (W3, ["-DPDAE_W3_PROBE_NOLOAD"]),
             "w3_6taps": (W3, ["-DPDAE_W3_PROBE_6TAPS"]),
+            "v_nomma": (V3, ["-DPDAE_V_PROBE_NOMMA"]), "v_nostage": (V3, ["-DPDAE_V_PROBE_NOSTAGE"]), "v_noload": (V3, ["-DPDAE_V_PROBE_NOLOAD"]),
+            "v_mmaonly": (V3, ["-DPDAE_V_PROBE_NOSTAGE", "-DPDAE_V_PROBE_NOLOAD"]),
             "w3_mmaonly": (W3, ["-DPDAE_W3_PROBE_NOSTAGE", "-DPDAE_W3_PROBE_NOLOAD"]),
             "r_noa": (R3, ["-DPDAE_R_PROBE_NOA"]), "r_nob": (R3, ["-DPDAE_R_PROBE_NOB"]), "r_nogload": (R3, ["-DPDAE_R_PROBE_NOGLOAD"]),
             "r_noconv": (R3, ["-DPDAE_R_PROBE_NOCONV"]), "r_nodrain": (R3, ["-DPDAE_R_PROBE_NODRAIN"]),
