@@ -51,6 +51,8 @@ class Plan:
         self.side_parked = []
         self.side_parked_bytes = 0
         self.side_budget = int(os.environ.get("PDAE_SIDE_BUDGET_MB", "6144")) << 20
+        self.side_branch_budget = int(os.environ.get("PDAE_SIDE_BRANCH_BUDGET_MB", "24576")) << 20      # parked bytes above which a side() branch joins
+        self.side_parked_peak = 0
         self.ws_side_bytes = 0
         self.ws_side = None
         self.ws_patch_side = []
@@ -66,10 +68,14 @@ class Plan:
         one box.  Kept as an opt-in for hosts whose tensors are small enough to sit clean in L2."""
         if os.environ.get("PDAE_GN_TICKETS", "0") != "1":
             return None
-        if self._tickets is None or self._tickets.numel() < n + 1:
-            self._tickets = torch.zeros(max(n + 1, 257), dtype=torch.int32, device=self.device)
-            self.live.append(self._tickets)
-        return self._tickets
+        # ops of a side-stream branch run beside the main stream's: their ticket words are their own (ADVICE r5: one shared array raced)
+        which = "_tickets_side" if self.side_mode else "_tickets"
+        cur = getattr(self, which, None)
+        if cur is None or cur.numel() < n + 1:
+            cur = torch.zeros(max(n + 1, 257), dtype=torch.int32, device=self.device)
+            setattr(self, which, cur)
+            self.live.append(cur)
+        return cur
 
     # ---- memory
     def buf(self, *shape, dtype=torch.float32, zero=False):
@@ -95,6 +101,11 @@ class Plan:
                 if self.side_busy and t.untyped_storage().data_ptr() in self.side_busy:
                     self.side_parked.append(t)                      # a pending side-stream op still reads it: recycled at the next join
                     self.side_parked_bytes += t.numel() * t.element_size()
+                    self.side_parked_peak = max(self.side_parked_peak, self.side_parked_bytes)
+                    # a whole branch on the second stream parks everything it touches: bounded too (a batch-100 sampling plan kept the
+                    # whole shift branch live).  A join inside the branch is legal: the ops behind it fork again from the main stream's position.
+                    if self.side_mode and self.side_parked_bytes > self.side_branch_budget:
+                        self.join()
                 else:
                     self.pool.setdefault((t.numel(), t.dtype), []).append(t)
 
@@ -186,6 +197,11 @@ class Plan:
         if self.ws_patch_side:
             self.ws_side_bytes = max(self.ws_side_bytes, self.ws_bytes if self.side_branch_ws else 0)
             self.ws_side = torch.empty(self.ws_side_bytes // 4 + 64, dtype=torch.float32, device=self.device)
+        # the two-stream schedule is PROVEN hazard-free before the plan can run (plancheck.py): no main-stream op between a side op and its join
+        # writes what the side op touches or reads what it writes
+        if self.n_side and os.environ.get("PDAE_PLAN_CHECK", "1") != "0":
+            from .plancheck import check_plan
+            self.check = check_plan(self)
         self.arr = H.ops_array(self.recs)
         self.n = len(self.recs)
         self.init_arr = H.ops_array(self.init_recs) if self.init_recs else None
@@ -422,9 +438,11 @@ class Builder:
         if self.frozen_of is not None and self.frozen_of.is_frozen_storage(w):
             # frozen weights (the pre-trained trunk of ShiftUNet: never touched by the optimizer / EMA kernels) are prepared once
             # per plan into a persistent buffer; Plan.run refreshes them when the module reports a parameter (re)load
-            key = (w.data_ptr(), tuple(c.fields()), int(transposed))
+            # (the byte count is part of the key: the prepared LAYOUT -- and with it the size -- follows the form knobs PDAE_W1 / W1_EFF / ROWS8,
+            # which may change between two plan builds of one module; a buffer sized for another form must never be reused: ADVICE r5)
+            key = (w.data_ptr(), tuple(c.fields()), int(transposed), int(nbytes))
             wp = self._frozen_wp.get(key)
-            if wp is None or wp.device != self.p.device:
+            if wp is None or wp.device != self.p.device or wp.numel() * 4 < nbytes:
                 wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)
                 self.p.bytes_alloc += wp.numel() * 4
                 self._frozen_wp[key] = wp
@@ -580,7 +598,9 @@ class Builder:
             out.append((y, NS(x=x, wname=wname, Nb=Nb, K=K, out=w.shape[0])))
         it, first, total = H.linear_group_tables(items, self.p.device)
         self.p.live.extend([it, first])                  # the device tables live as long as the plan
-        self.p.emit(H.op_linear_group(it, first, len(items), total, min(Nb, 32), K))
+        gop = H.op_linear_group(it, first, len(items), total, min(Nb, 32), K)
+        gop.rw = ([t for i_ in items for t in i_[:3]], [i_[3] for i_ in items])      # operands live in the device table: plancheck reads them here
+        self.p.emit(gop)
         return out
 
     def prefetch_emb(self, ea, prefixes, eza=None, z_prefixes=()):
@@ -614,7 +634,9 @@ class Builder:
             return
         it, first, total = H.linear_bwd_group_tables(items, Nb, self.p.device)
         self.p.live.extend([it, first])
-        self.p.emit(H.op_linear_bwd_group(it, first, len(items), total, Nb, K))
+        gop = H.op_linear_bwd_group(it, first, len(items), total, Nb, K)
+        gop.rw = ([t for i_ in items for t in i_[:3]], [t for i_ in items for t in i_[3:6]])
+        self.p.emit(gop)
 
     def linear_bwd(self, lx, dy, dx=None, dx_acc=0):
         """dW = dy^T x, db = colsum(dy), optionally dx (+)= dy W."""
@@ -654,9 +676,9 @@ class Builder:
                 c.direct = False                 # (a caller that keeps using c must not lose the Winograd form for nothing)
             return None
         if self.frozen_of is not None and self.frozen_of.is_frozen_storage(ws):
-            key = (ws.data_ptr(), tuple(c.fields()), "skip")
+            key = (ws.data_ptr(), tuple(c.fields()), "skip", int(nbytes))
             wps = self._frozen_wp.get(key)
-            if wps is None or wps.device != self.p.device:
+            if wps is None or wps.device != self.p.device or wps.numel() * 4 < nbytes:
                 wps = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.p.device)
                 self.p.bytes_alloc += wps.numel() * 4
                 self._frozen_wp[key] = wps

@@ -71,6 +71,9 @@ class _FusedStep:
         self._marks = []
         self._build(self.math_name)
         p = self.plan
+        # the optimizer reads every gradient: the side-stream weight gradients are joined IN the op list (the step used to rely on the implicit join
+        # at the end of the backward's pdae_run_ops call: plancheck.py found the unordered pair when it walked the list as a whole)
+        p.join()
         self.n_bwd = len(p.recs)
         guard = H.SaturationGuard.get(p.device)
         self.guard = guard

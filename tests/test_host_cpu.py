@@ -1,9 +1,12 @@
 """CPU: host-side logic of the product that needs no kernel -- schedule tables, respacing and DDIM coefficient rows of
 pdae_amd.diffusion against the vectors the reference emitted (tests/golden/schedules.npz), bucket planning, config loading."""
+import os
+
 import numpy as np
+import pytest
 import torch
 
-from tests.conftest import load_golden
+from tests.conftest import ROOT, load_golden
 
 
 def test_product_schedule_tables_match_reference_vectors():
@@ -292,3 +295,102 @@ def test_plan_side_branch_parks_inputs_and_outputs_and_shiftunet_uses_it(monkeyp
     assert 0.2 < len(side) / len(pl.recs) < 0.6                 # roughly the shift half of what follows the input blocks
     _, side0, _ = census("0")
     assert not side0
+
+
+def test_plan_checker_finds_every_kind_of_two_stream_hazard():
+    """pdae_amd/plancheck.py on hand-made plans (CPU tensors): a main-stream op between a side op and its join that (a) overwrites the side op's
+    input, (b) overwrites its output, (c) reads its output is refused by Plan.compile(); the same ops behind a join, and main-stream ops on
+    unrelated buffers, pass.  Granularity is the pool buffer: a pointer INTO a buffer counts as the buffer."""
+    import pytest
+    import torch
+    from pdae_amd import hip as H
+    from pdae_amd.engine import Plan
+    from pdae_amd.plancheck import PlanHazard, check_plan
+
+    def plan(main_op_of, join_first=False):
+        p = Plan(torch.device("cpu"))
+        a, b, c, d = p.buf(16), p.buf(16), p.buf(16), p.buf(16)
+        p.emit_side(H.make_op(H.OP_COPY, [a, b], [64]), [a])          # side: reads a, writes b
+        if join_first:
+            p.join()
+        p.emit(main_op_of(a, b, c, d))
+        return p
+    bad = {"writes the side op's input": lambda a, b, c, d: H.make_op(H.OP_MEMSET, [a[4:]], [16]),
+           "writes the side op's output": lambda a, b, c, d: H.make_op(H.OP_COPY, [c, b], [64]),
+           "reads the side op's output": lambda a, b, c, d: H.make_op(H.OP_COPY, [b[8:], d], [32])}
+    for why, f in bad.items():
+        with pytest.raises(PlanHazard):
+            plan(f).compile()
+        ok = plan(f, join_first=True).compile()                      # ordered by the join: fine
+        assert ok.check["side_ops"] == 1 and ok.check["joins"] >= 1, why
+    ok = plan(lambda a, b, c, d: H.make_op(H.OP_COPY, [c, d], [64])).compile()      # unrelated buffers beside the side op
+    assert ok.check["pairs"] == 1
+    ok = plan(lambda a, b, c, d: H.make_op(H.OP_COPY, [a, d], [64])).compile()      # two READERS of one buffer do not conflict
+    assert ok.check["pairs"] == 1
+    # an op whose operands sit in a device table must bring them along (Builder.linear_group does): without, the schedule is unprovable
+    p = Plan(torch.device("cpu"))
+    a, b = p.buf(16), p.buf(16)
+    p.emit_side(H.make_op(H.OP_COPY, [a, b], [64]), [a])
+    p.emit(H.op_linear_group(a, b, 1, 1, 1, 8))
+    with pytest.raises(PlanHazard):
+        check_plan(p)
+    p.recs[-1].rw = ([a], [b])                                       # ... and with them the conflict (it writes b) is seen
+    with pytest.raises(PlanHazard):
+        check_plan(p)
+    # every op kind of the library has its write slots declared
+    from pdae_amd import plancheck
+    kinds = {getattr(H, k) for k in dir(H) if k.startswith("OP_") and isinstance(getattr(H, k), int)}
+    assert kinds - set(plancheck.WRITES) - plancheck.TABLE_KINDS == {H.OP_JOIN}
+
+
+@pytest.mark.timeout(900)
+def test_training_and_sampling_plans_are_proven_hazard_free_on_the_cpu(monkeypatch):
+    """Every plan is checked when it is compiled (Plan.compile -> plancheck.check_plan; PDAE_PLAN_CHECK=0 opts out): here the three trainers'
+    step plans and ShiftUNet's sampling plans are BUILT on the CPU at the shipped FFHQ-128 topology (B = 1) and at a small one with dropout and
+    attention, with the default second-stream switches and with a tiny parking budget (joins in the middle of the backward and of the shift
+    branch), and the census of what was proven is non-trivial.  The optimizer ops sit behind an explicit join (found by this check: the
+    step used to rely on the implicit join at the end of the backward's pdae_run_ops call)."""
+    import copy
+    import torch
+    from pdae_amd import hip as H
+    from pdae_amd.utils import load_yaml
+    from pdae_amd.model.shift_unet import ShiftUNet
+    from pdae_amd.model.unet import UNet
+    from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder, FFHQEncoder
+    from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
+    from pdae_amd.trainer.fused_step import FusedRLStep, FusedRegularStep
+    dev = torch.device("cpu")
+    gd = GaussianDiffusion({"timesteps": 1000, "betas_type": "linear"}, dev)
+    small = dict(input_channel=3, base_channel=32, channel_multiplier=[1, 2], num_residual_blocks_of_a_block=1, attention_resolutions=[2],
+                 num_heads=1, head_channel=-1, use_new_attention_order=False, dropout=0.1)
+    f128 = load_yaml(os.path.join(ROOT, load_yaml(os.path.join(ROOT, "config/ffhq_representation_learning.yml"))["trained_ddpm_config"]))["denoise_fn_config"]
+
+    def rl(cfg, Enc, latent, B, S):
+        enc, dec = Enc(device=dev, latent_dim=latent), ShiftUNet(device=dev, latent_dim=latent, **cfg)
+        enc.train(); dec.set_train_mode()
+        st = FusedRLStep(gd, enc, dec, copy.deepcopy(enc), copy.deepcopy(dec), B, S, S)
+        return st, dec
+    for budget in ("6144", "1"):
+        monkeypatch.setenv("PDAE_SIDE_BUDGET_MB", budget)
+        monkeypatch.setenv("PDAE_SIDE_BRANCH_BUDGET_MB", "24576" if budget != "1" else "1")
+        for cfg, Enc, latent, B, S in ((small, CELEBA64Encoder, 64, 2, 64), (f128, FFHQEncoder, 512, 1, 128)):
+            st, dec = rl(cfg, Enc, latent, B, S)
+            pl = st.plan
+            chk = pl.check
+            assert chk["side_ops"] >= 20 and chk["pairs"] > (10 if budget != "1" else 2) * chk["side_ops"] and chk["joins"] >= (2 if budget != "1" else 4), (budget, chk)
+            adam = [k for k, o in enumerate(pl.recs) if o.kind == H.OP_ADAM_EMA]
+            assert pl.recs[min(adam) - 1].kind == H.OP_JOIN and min(adam) == st.n_bwd
+            dec.set_eval_mode()
+            for p2 in (dec.plan(B, S, S, False), dec.plan_eps(B, S, S)):
+                if p2.n_side:
+                    assert p2.check["side_ops"] == p2.n_side and (p2.check["pairs"] > 0 or budget == "1")      # (a 1 MB budget joins behind nearly every side op)
+            if budget == "1":
+                assert dec.plan(B, S, S, False).side_parked_peak <= (2 << 20) + 4 * B * S * S * 4 * max(cfg["channel_multiplier"]) * cfg["base_channel"]
+    un = UNet(device=dev, **dict(small, input_channel=1))
+    un.train()
+    st = FusedRegularStep(gd, un, copy.deepcopy(un), 2, 32, 32)
+    assert st.plan.check["side_ops"] > 0 and st.plan.recs[st.n_bwd - 1].kind == H.OP_JOIN
+    # PDAE_PLAN_CHECK=0 opts out (the attribute is then absent)
+    monkeypatch.setenv("PDAE_PLAN_CHECK", "0")
+    st = FusedRegularStep(gd, un, copy.deepcopy(un), 2, 32, 32)
+    assert not hasattr(st.plan, "check")

@@ -78,3 +78,25 @@ def test_training_step_is_bit_identical_with_and_without_the_second_stream(knob)
     assert l0 == l1
     for x, y in zip(s0, s1):
         assert torch.equal(x, y)
+
+
+@pytest.mark.timeout(1200)
+def test_second_stream_stress_f128_b32_dropout_highest_priority_tiny_budget_and_ddp_segments():
+    """the stress case.  tests/side_stress_worker.py in a fresh process (the side stream's priority is fixed at its creation):
+    FFHQ-128 topology, B = 32, dropout on, side stream at the HIGHEST priority, 64 MB parking budget, plain step and the data-parallel driver's
+    segmented backward -- three optimizer steps bit-identical to the one-stream order; the plan's schedule is proven by plancheck on the way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, PDAE_SIDE_STREAM="3", PDAE_SIDE_BUDGET_MB="64", PDAE_SIDE_BRANCH_BUDGET_MB="64")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "side_stress_worker.py"), "32"], capture_output=True, text=True, env=env, timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for name in ("plain", "native"):
+        o = out[name]
+        assert o["identical"], (name, o)
+        assert o["info"]["side_ops"] > 100 and o["info"]["joins"] > 10 and o["info"]["sat"] == 0, o["info"]
+        assert o["info"]["check"]["pairs"] > 0
+    assert out["native"]["info"]["buckets"] >= 4
