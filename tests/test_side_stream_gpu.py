@@ -93,7 +93,7 @@ def test_second_stream_stress_f128_b32_dropout_highest_priority_tiny_budget_and_
     env = dict(os.environ, PDAE_SIDE_STREAM="3", PDAE_SIDE_BUDGET_MB="64", PDAE_SIDE_BRANCH_BUDGET_MB="64")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "side_stress_worker.py"), "32"], capture_output=True, text=True, env=env, timeout=1100)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out = json.loads(next(ln for ln in r.stdout.splitlines() if ln.startswith('{"plain"')))          # (RCCL prints its banner behind it)
     for name in ("plain", "native"):
         o = out[name]
         assert o["identical"], (name, o)
