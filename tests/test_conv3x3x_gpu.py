@@ -425,3 +425,87 @@ def test_groupnorm_backward_sums_are_refused_where_not_built(H, knob):
     H.run(H.op_conv_wprep(c, w, 1, wp_t))
     with pytest.raises(H.PdaeError):
         H.run(H.op_conv_dgrad(c, x, w, x.clone(), wp_t=wp_t, gnb=(x, 64, None, 0, coef, torch.zeros(4096, device="cuda"))))
+
+
+@pytest.mark.parametrize("form", ["fwd_residual", "fwd_halfres_residual", "dgrad_accumulate", "dgrad_gnb"])
+def test_store_hazard_stress_repeated_launches_are_bit_identical(H, knob, form):
+    """the epilogue instantiations with an operand (EX / GB) -- where the output-store data hazard corrupted ~1.9 % of the outputs of the
+    8-row form, varying from run to run -- launched 24 times back to back on a shape that keeps every CU's vector-memory queue
+    full (several tiles per workgroup, operand loads in front of every block's stores), beside a streaming kernel on a second stream that
+    adds pressure on the same path: every run bit-identical to the first, the first within the gate of the direct form.  Runs under both tile
+    heights (the file's autouse fixture)."""
+    knob("PDAE_W1", WMODE)
+    N, Hh, W, C, Cout = 12, 64, 64, 128, 128
+    x = rn(1, N, C, Hh, W) * 1.3 + 0.2
+    w = rn(2, Cout, C, 3, 3, scale=1.0 / math.sqrt(9 * C)); b = rn(3, Cout, scale=0.2)
+    c = H.Conv(N, Hh, W, C, 0, Cout, k=3, math=4)
+    xd, wd, bd = nhwc(x).cuda(), nhwc(w).cuda(), b.cuda()
+    dy = rn(5, N, Cout, Hh, W) * 2e-3
+    dyd = nhwc(dy).cuda()
+    amax = torch.empty(4, device="cuda")
+    H.run(H.op_amax(dyd, dyd.numel(), amax))
+    res = nhwc(rn(4, N, Cout, Hh, W)).cuda()
+    res_half = nhwc(rn(4, N, Cout, Hh // 2, W // 2)).cuda()
+    base = rn(6, N, Hh, W, C).cuda()
+    wp = torch.empty(c.wprep_bytes(0, force=True) // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 0, wp))
+    wp_t = torch.empty(c.wprep_bytes(1, force=True, f16_grad=True) // 4, device="cuda")
+    H.run(H.op_conv_wprep(c, wd, 1 | 16, wp_t))
+    coef = part = None
+    if form == "dgrad_gnb":
+        G = 32
+        mean = torch.empty(N * G, device="cuda"); rstd = torch.empty(N * G, device="cuda")
+        wsg = torch.empty(H.gn_ws_bytes(N, C) // 4 + 64, device="cuda")
+        H.run(H.op_gn_stats(xd, C, None, 0, N, Hh * W, G, 1e-5, mean, rstd, wsg))
+        coef = torch.empty(3, N, C, device="cuda")
+        H.run(H.op_gn_coef(N, C, G, mean, rstd, (1 + 0.2 * rn(7, C)).cuda(), (0.2 * rn(8, C)).cuda(), None, None, coef))
+        nb, _ = H.conv_gnbwd_bytes(c, f16_grad=True)
+        assert nb > 0
+        part = torch.empty(nb // 4, device="cuda")
+
+    def launch():
+        if form == "fwd_residual":
+            y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
+            H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, res=res, res_mode=1, wp=wp))
+            return [y]
+        if form == "fwd_halfres_residual":
+            y = torch.full((N, Hh, W, Cout), float("nan"), device="cuda")
+            H.run(H.op_conv_fwd(c, xd, None, wd, bd, y, res=res_half, res_mode=2, wp=wp))
+            return [y]
+        if form == "dgrad_accumulate":
+            dx = base.clone()
+            H.run(H.op_conv_dgrad(c, dyd, wd, dx, accumulate=1, wp_t=wp_t, dy_amax=amax))
+            return [dx]
+        dx = torch.full((N, Hh, W, C), float("nan"), device="cuda")
+        part.fill_(float("nan"))
+        H.run(H.op_conv_dgrad(c, dyd, wd, dx, wp_t=wp_t, dy_amax=amax, gnb=(xd, C, None, 0, coef, part)))
+        return [dx, part.clone()]
+    first = launch()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).all() for t in first)
+    # pressure: a copy loop on another stream while the launches repeat
+    side = torch.cuda.Stream()
+    big_a, big_b = torch.empty(1 << 26, device="cuda"), torch.empty(1 << 26, device="cuda")
+    for it in range(24):
+        with torch.cuda.stream(side):
+            big_b.copy_(big_a)
+        got = launch()
+        for a, b_ in zip(first, got):
+            assert torch.equal(a, b_), (form, it, int((a != b_).sum()))
+    torch.cuda.synchronize()
+    # ... and the first run agrees with the direct form on the same operands
+    knob("PDAE_W1", "0")
+    if form.startswith("fwd"):
+        wp0 = torch.empty(c.wprep_bytes(0, force=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 0, wp0))
+        y0 = torch.empty_like(first[0])
+        H.run(H.op_conv_fwd(c, xd, None, wd, bd, y0, res=res if form == "fwd_residual" else res_half, res_mode=1 if form == "fwd_residual" else 2, wp=wp0))
+        assert rel_err(first[0], y0) < 3 * TOL[4]
+    else:
+        wp0 = torch.empty(c.wprep_bytes(1, force=True, f16_grad=True) // 4, device="cuda")
+        H.run(H.op_conv_wprep(c, wd, 1 | 16, wp0))
+        dx0 = base.clone() if form == "dgrad_accumulate" else torch.empty_like(first[0])
+        H.run(H.op_conv_dgrad(c, dyd, wd, dx0, accumulate=int(form == "dgrad_accumulate"), wp_t=wp0, dy_amax=amax))
+        ref = dx0 - base if form == "dgrad_accumulate" else dx0
+        gotd = first[0] - base if form == "dgrad_accumulate" else first[0]
+        assert rel_err(gotd, ref) < 3e-5

@@ -77,87 +77,7 @@ def test_hot_kernels_use_no_scratch_memory():
         assert must in names, must
 
 
-def lds_store_hazard_sites(asm, window=6):
-    """[(kernel, line, store, overwriting instruction)]: a multi-dword LDS store (ds_write2_b32 / _b64 / _b128 ...) whose LAST data register is overwritten by
-    a v_accvgpr_read_b32 within `window` instructions.  On MI355X this stored the NEW register contents for the lanes whose operands leave the
-    register file last (lanes 12-15 of every 16): conv3x3y's epilogue, round 4 -- `ds_write2_b32 v40, v41, v42 offset1:36` followed one instruction later
-    by `v_accvgpr_read_b32 v42, a98`, 0.4 % of the outputs wrong in some instantiations and not in others (it depends on what else the CU's LDS input
-    path carries at that moment).  The compiler's hazard recognizer does not know the case.  tools/isa_hazard.py is the same scan by hand."""
-    def regs(tok):
-        m = re.match(r"v\[(\d+):(\d+)\]", tok)
-        if m:
-            return set(range(int(m.group(1)), int(m.group(2)) + 1))
-        m = re.match(r"v(\d+)$", tok)
-        return {int(m.group(1))} if m else set()
-    ins, kern, hits = [], None, []
-    for i, l in enumerate(asm.split("\n")):
-        if re.match(r"^_Z\w+:", l):
-            kern = l.split(":")[0]
-        t = l.strip().split(";")[0].strip()
-        if t and not t.startswith(".") and not t.endswith(":"):
-            ins.append((i + 1, kern, t))
-    for k, (ln, kern, t) in enumerate(ins):
-        op = t.split()[0]
-        if op not in ("ds_write2_b32", "ds_write2_b64", "ds_write_b64", "ds_write_b128", "ds_write2st64_b32", "ds_write2st64_b64", "ds_write_b96"):
-            continue
-        data = [o.strip().split()[0] for o in t[len(op):].split(",")[1:] if o.strip().startswith("v")]
-        if not data:
-            continue
-        last = regs(data[-1])
-        if op in ("ds_write_b64", "ds_write_b128", "ds_write_b96") and len(last) > 1:
-            last = {max(last)}
-        for j in range(1, window + 1):
-            if k + j >= len(ins):
-                break
-            t2 = ins[k + j][2]
-            op2 = t2.split()[0]
-            # round 4: an accumulator read into the register, up to `window` instructions behind any multi-dword store.  Round 5: behind a TWO-ADDRESS
-            # dword store (ds_write2_b32: the second dword leaves the register file last) an ORDINARY vector write is not interlocked either --
-            # `ds_write2_b32 v157, v174, v176` / `v_add_u32 v176, 0x400, v83` (the next store's address formed in the dead data register) stored the
-            # address in lanes 12-15 of every 16, deterministically, in the 8-row instantiation with an epilogue operand
-            hit = op2 == "v_accvgpr_read_b32" or (op in ("ds_write2_b32", "ds_write2st64_b32") and j <= 3 and op2.startswith("v_") and not op2.startswith("v_cmp")
-                                                 and not op2.startswith("v_accvgpr_write"))
-            if hit and len(t2.split()) > 1 and regs(t2.split()[1].rstrip(",")) & last:
-                hits.append((kern, ln, t, t2))
-    return hits
-
-
-def output_store_hazard_sites(asm, window=2):
-    """[(kernel, line, store, overwriting instruction)]: a multi-dword GLOBAL store (buffer_store_dwordx2..4 / global_store_dwordx2..4) whose data registers a
-    vector instruction overwrites within `window` instructions.  Round 5, conv3x3y<.., RH = 1> with an epilogue operand: `buffer_store_dwordx4 v[162:165]`
-    followed two instructions later by `v_pk_add_f32 v[162:163], ..` stored the NEW values in lanes 12-15 of every 16 for ~1.9 % of the outputs, varying from
-    run to run, while the store sat in the vector-memory queue behind sixteen operand loads (a build with a spacer behind every store was correct)."""
-    def regs(tok):
-        tok = tok.strip()
-        m = re.match(r"v\[(\d+):(\d+)\]", tok)
-        if m:
-            return set(range(int(m.group(1)), int(m.group(2)) + 1))
-        m = re.match(r"v(\d+)$", tok)
-        return {int(m.group(1))} if m else set()
-    ins, kern, hits = [], None, []
-    for i, l in enumerate(asm.split("\n")):
-        if re.match(r"^_Z\w+:", l):
-            kern = l.split(":")[0]
-        t = l.strip().split(";")[0].strip()
-        if t and not t.startswith(".") and not t.endswith(":"):
-            ins.append((i + 1, kern, t))
-    for k, (ln, kern, t) in enumerate(ins):
-        op = t.split()[0]
-        if op.startswith("buffer_store_dwordx"):
-            data = regs(t[len(op):].split(",")[0])
-        elif op.startswith("global_store_dwordx"):
-            data = regs(t[len(op):].split(",")[1])
-        else:
-            continue
-        for j in range(1, window + 1):
-            if k + j >= len(ins):
-                break
-            t2 = ins[k + j][2]
-            op2 = t2.split()[0]
-            if op2.startswith("v_") and not op2.startswith("v_cmp") and len(t2.split()) > 1 and regs(t2.split()[1].rstrip(",")) & data:
-                hits.append((kern, ln, t, t2))
-                break
-    return hits
+from pdae_amd.isa_hazard import lds_store_hazard_sites, output_store_hazard_sites      # noqa: E402  (product-side: the build runs them too)
 
 
 @pytest.mark.timeout(900)
