@@ -506,6 +506,5 @@ def test_store_hazard_stress_repeated_launches_are_bit_identical(H, knob, form):
         H.run(H.op_conv_wprep(c, wd, 1 | 16, wp0))
         dx0 = base.clone() if form == "dgrad_accumulate" else torch.empty_like(first[0])
         H.run(H.op_conv_dgrad(c, dyd, wd, dx0, accumulate=int(form == "dgrad_accumulate"), wp_t=wp0, dy_amax=amax))
-        ref = dx0 - base if form == "dgrad_accumulate" else dx0
-        gotd = first[0] - base if form == "dgrad_accumulate" else first[0]
-        assert rel_err(gotd, ref) < 3e-5
+        # (accumulate: both forms round base + gradient to fp32 -- compared on the sums, where one ulp of the O(1) base is 6e-8)
+        assert rel_err(first[0], dx0) < (1e-6 if form == "dgrad_accumulate" else 3e-5)
