@@ -858,21 +858,34 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
 // guarantee between a side op and the next join: nothing on the caller's stream overwrites its inputs or reads its outputs (engine.py defers
 // the recycling of such buffers to the join).  Used for the weight gradients: they feed nothing in the backward chain, and the chain's
 // HBM-bound passes (GroupNorm backward, 1x1 data gradients, reductions) leave the matrix pipes idle.
-struct SideStream { int dev = -1; hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool dirty = false; };
-static SideStream g_side[16];
-static SideStream* side_of_current_device() {
+// Round 6: one side stream PER (device, calling stream), created under a mutex -- two host threads that issue plans on
+// their own streams (the training thread and an evaluation / autograd thread: SURVEY section 8(b) "re-entrant") share neither the fork / join
+// events nor the pending flag; a partially created entry is torn down and the ops run in order on the caller's stream instead.
+struct SideStream { int dev = -1; hipStream_t caller = nullptr; hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool dirty = false; };
+#define PDAE_MAX_SIDE 64
+static SideStream g_side[PDAE_MAX_SIDE];
+static int g_side_n = 0;
+static std::mutex g_side_mu;
+static SideStream* side_of(pdae_stream_t stream) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  SideStream& q = g_side[dev];
-  if (!q.s) {
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);                    // lo = least priority: the backward chain on the caller's stream goes first
-    const int mode = pdae_knob(KNOB_SIDE_STREAM);                 // 1: least priority, 2: the default priority, 3: highest
-    if (hipStreamCreateWithPriority(&q.s, hipStreamNonBlocking, mode == 2 ? 0 : (mode == 3 ? hi : lo)) != hipSuccess) { q.s = nullptr; return nullptr; }
-    if (hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    q.dev = dev;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  for (int k = 0; k < g_side_n; ++k)
+    if (g_side[k].dev == dev && g_side[k].caller == S(stream)) return &g_side[k];
+  if (g_side_n >= PDAE_MAX_SIDE) return nullptr;                  // (more caller streams than slots: their plans run in order)
+  SideStream q;
+  int lo = 0, hi = 0;
+  hipDeviceGetStreamPriorityRange(&lo, &hi);                      // lo = least priority: the backward chain on the caller's stream goes first
+  const int mode = pdae_knob(KNOB_SIDE_STREAM);                   // 1: least priority, 2: the default priority, 3: highest
+  if (hipStreamCreateWithPriority(&q.s, hipStreamNonBlocking, mode == 2 ? 0 : (mode == 3 ? hi : lo)) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) {
+    if (q.fork) hipEventDestroy(q.fork);
+    hipStreamDestroy(q.s);
+    return nullptr;
   }
-  return &q;
+  q.dev = dev; q.caller = S(stream);
+  g_side[g_side_n] = q;
+  return &g_side[g_side_n++];
 }
 static int side_join(SideStream* q, pdae_stream_t stream) {
   if (!q || !q->dirty) return PDAE_OK;
@@ -889,7 +902,7 @@ extern "C" int pdae_run_ops(const pdae_op* ops, int n, pdae_stream_t stream) {
   for (int k = 0; k < n; ++k) {
     int e;
     if (ops[k].kind == PDAE_OP_JOIN) e = side_join(side, stream);
-    else if ((ops[k].flags & PDAE_OPF_SIDE) && use_side && (side || (side = side_of_current_device()))) {
+    else if ((ops[k].flags & PDAE_OPF_SIDE) && use_side && (side || (side = side_of(stream)))) {
       hipError_t he = hipEventRecord(side->fork, S(stream));
       if (he == hipSuccess) he = hipStreamWaitEvent(side->s, side->fork, 0);
       if (he != hipSuccess) { pdae_set_error("side stream fork: %s", hipGetErrorString(he)); e = (int)he; }

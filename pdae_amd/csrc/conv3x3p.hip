@@ -533,22 +533,32 @@ static size_t prep_bytes(int math, int Nout, int C, int form) {
 // transform taps); a launch in the other form would read garbage and still return 0.  Every preparation (pdae_conv_wprep, or the description of
 // a job of the grouped launch) therefore records the layout it writes under the copy's address, and every launch that takes a copy checks it: a
 // mismatch -- PDAE_W1 changed through pdae_set_knob, or PDAE_MATH_DIRECT present on one side only -- fails with PDAE_EINVAL instead of computing
-// wrong numbers.  Host-side only (no device traffic, no synchronisation); copies of unknown provenance (never seen by this library instance) pass.
+// wrong numbers.  Host-side only (no device traffic, no synchronisation: a tag INSIDE the buffer could only be checked by a device-to-host copy on
+// the launch path or asynchronously by the kernel).  Round 6: the tag is signed with the convolution it was written for
+// (arithmetic, Nout, C) -- a buffer that was freed and re-allocated for ANOTHER convolution no longer inherits a stale tag; only a tag of the same
+// convolution can refuse a launch -- and the table is bounded (oldest half dropped beyond 64 K entries).  Copies of unknown provenance pass.
 #include <mutex>
 #include <unordered_map>
+struct FormTag { int form; unsigned sig; unsigned long long age; };
 static std::mutex g_form_mu;
-static std::unordered_map<const void*, int> g_form_tag;      // wp -> 1 + form
-static void form_note(const void* wp, int form) {
+static std::unordered_map<const void*, FormTag> g_form_tag;
+static unsigned long long g_form_age = 0;
+static unsigned form_sig(int math, int Nout, int C) { return ((unsigned)math * 2654435761u) ^ ((unsigned)Nout * 40503u) ^ ((unsigned)C << 16) ^ 0x9e3779b9u; }
+static void form_note(const void* wp, int form, unsigned sig) {
   std::lock_guard<std::mutex> lk(g_form_mu);
-  g_form_tag[wp] = 1 + form;
+  if (g_form_tag.size() > 65536) {
+    const unsigned long long cut = g_form_age - 32768;
+    for (auto it = g_form_tag.begin(); it != g_form_tag.end();) it = it->second.age < cut ? g_form_tag.erase(it) : ++it;
+  }
+  g_form_tag[wp] = FormTag{form, sig, g_form_age++};
 }
-static int form_check(const void* wp, int form) {
+static int form_check(const void* wp, int form, unsigned sig) {
   std::lock_guard<std::mutex> lk(g_form_mu);
   auto it = g_form_tag.find(wp);
-  if (it == g_form_tag.end() || it->second == 1 + form) return PDAE_OK;
+  if (it == g_form_tag.end() || it->second.sig != sig || it->second.form == form) return PDAE_OK;
   pdae_set_error("conv3x3p: the prepared weights at %p were written in the %s layout but this launch takes the %s form (PDAE_W1 changed between "
                  "pdae_conv_wprep and the launch, or PDAE_MATH_DIRECT is set on one of the two descriptors only)", wp,
-                 it->second == 2 ? "Winograd-along-x" : "direct", form ? "Winograd-along-x" : "direct");
+                 it->second.form ? "Winograd-along-x" : "direct", form ? "Winograd-along-x" : "direct");
   return PDAE_EINVAL;
 }
 
@@ -627,7 +637,7 @@ int conv3x3p_launch(int math, const float* x, int N, int Hs, int Ws, int C, int 
   if (coef && (q.w8 || (x1 && (C0 & 31)))) { pdae_set_error("conv3x3p: fused GroupNorm input needs W %% 16 == 0 and C0 %% 32 == 0"); return PDAE_EINVAL; }
   P.tiles_x = q.tiles_x; P.tiles_y = q.tiles_y; P.tiles_n = q.tiles_n; P.splits = q.splits; P.cps = q.cps;
   const int form = (!q.w8 && conv3x3p_form(math_form, C, H, W, N, Nout)) ? 1 : 0;
-  if (int e = form_check(wp, form)) return e;
+  if (int e = form_check(wp, form, form_sig(math, Nout, C))) return e;
   P.slab = (float*)((char*)wp + prep_bytes(math, Nout, C, form));
   P.stat_part = stat_part;
   P.stat_tpi = q.splits != 1 ? (H * W + reduce_stats_tp(N, H * W) - 1) / reduce_stats_tp(N, H * W) : q.tiles_x * q.tiles_y * (q.th / 8);
@@ -688,7 +698,7 @@ static int wprep_launch(int math, const float* w, int Nout, int C, int transpose
 int conv3x3p_wprep(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, hipStream_t s, int H, int W, int N) {
   const int form = conv3x3p_form(math, C, H, W, N, Nout);
   math &= ~PDAE_MATH_DIRECT_BIT;
-  form_note(wp, form);
+  form_note(wp, form, form_sig(math, Nout, C));
   if (form) return wprep_launch(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, s);
   return wprep_launch(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, s);
 }
@@ -700,7 +710,7 @@ static void fill_job3(int math, const float* w, int Nout, int C, int transposed,
 void conv3x3p_wprep_job(int math, const float* w, int Nout, int C, int transposed, unsigned short* wp, WprepJob* j, int H, int W, int N) {
   const int form = conv3x3p_form(math, C, H, W, N, Nout);
   math &= ~PDAE_MATH_DIRECT_BIT;
-  form_note(wp, form);
+  form_note(wp, form, form_sig(math, Nout, C));
   if (form) fill_job3(math, w, Nout, C, transposed | PDAE_WPREP_FORM_X, conv3x3p_wscale(C), 12, wp, j);
   else fill_job3(math, w, Nout, C, transposed, conv3x3p_wscale(C), 9, wp, j);
 }
