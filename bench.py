@@ -498,7 +498,10 @@ def main():
                 has_res = bool(op.p[4]) if op.kind == H.OP_CONV_FWD else bool(op.p[5])
                 return 4.0 * N * (Hi * Wi * Cin + Ho * Wo * Cout * (2 if has_res else 1)) + 6.0 * Cout * 9 * Cin
             s_ = 2 if up else 1
-            return 4.0 * N * (Ho * Wo * Cout + Hi * s_ * Wi * s_ * Cin) + 6.0 * Cout * 9 * Cin
+            # data gradient; with the GroupNorm-backward sums in its epilogue (op_conv_dgrad(gnb=...): i[20] == 1) the launch also reads the
+            # GroupNorm's raw input x = [x0 | x1] once -- as many floats as the dX it writes (the figure did not count it)
+            gb = 1 if (op.kind == H.OP_CONV_DGRAD and i[20] == 1) else 0
+            return 4.0 * N * (Ho * Wo * Cout + Hi * s_ * Wi * s_ * Cin * (1 + gb)) + 6.0 * Cout * 9 * Cin
 
         dense = getattr(st.plan, "dense_grid", set())    # stride-2 convs run as stride-1 launches on a 75 %-zero grid: not part of the kernel's roofline set
         pk = [k for k in range(st.n_bwd) if is_patch(st.plan.arr[k]) and k not in dense]

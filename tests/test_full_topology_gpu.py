@@ -5,7 +5,7 @@ through the fused-step / planned-network HIP path against the CPU oracle compute
   C64   config/celeba64_representation_learning.yml + pre-trained-dpms/celeba64/config.yml (base 64, [1,2,4,8], 64x64), fp32 and bf16 (enable_amp)
   M32   config/mnist_regular.yml                                                          (base 64, [1,2,2,4], 1x32x32, B=16)
 
-Gates (north_star): z / eps / shift / loss within 1e-4 relative, every trainable gradient within 1e-3 in norm, DDIM x_0 PSNR stated
+Gates (north_star): z / eps / shift / loss within 1e-4 relative, every trainable gradient within 1e-5 in norm (GRAD_TOL: 3x the worst measured), DDIM x_0 PSNR stated
 below; the fp16-window counter must stay zero.  The per-GPU batch of the benchmark (B=32) is covered by a size-independent property:
 16 copies of the B=2 batch give the same mean loss and the same mean gradient.  Dropout is switched off (it is not a size; RNG streams cannot
 match across devices)."""
@@ -74,14 +74,27 @@ def _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise):
     return z.detach(), eps.detach(), shift.detach(), float(loss), grads
 
 
-def _check_grads(got, ref, tol):
+# every gradient gate of this file: worst per-tensor errors measured on MI355X in round 6 (f16x3 arithmetic, conv3x3v weight gradients) were
+# 1.9e-6 ... 3.3e-6 of the tensor's norm across F128 / C64 / M32 / latent; the gate is ~3x the largest (it was 1e-3 through round 5)
+GRAD_TOL = 1e-5
+WORST = {}      # label -> worst per-tensor gradient error observed in this session (printed; the gates below sit ~3x above the round-6 measurements)
+
+
+def _check_grads(got, ref, tol, label="grads"):
+    """Every trainable gradient within `tol` of its oracle norm (+ a floor of 1e-6 of the largest gradient norm for tensors whose gradient is
+    numerically zero).  VERDICT r5 weak #1: the worst per-tensor error is PRINTED and recorded, and each caller's gate is set at about three times
+    the value measured on MI355X in round 6 -- a kernel change that moves a gradient from 2e-5 to 8e-4 no longer passes silently."""
     floor = 1e-6 * max(float(v.double().norm()) for v in ref.values())
-    bad = []
+    bad, worst = [], (0.0, None)
     for k, r in ref.items():
         rn = float(r.double().norm())
         err = float((got[k].detach().double().cpu() - r.double()).norm())
+        if rn > floor and err / rn > worst[0]:
+            worst = (err / rn, k)
         if err > tol * rn + floor:
             bad.append((k, err / max(rn, 1e-30)))
+    WORST[label] = worst
+    print(f"[{label}] worst per-tensor gradient error {worst[0]:.3e} ({worst[1]}) over {len(ref)} tensors; gate {tol:.1e}")
     assert not bad, (len(bad), sorted(bad, key=lambda b: -b[1])[:6])
 
 
@@ -122,7 +135,7 @@ def test_f128_train_step_full_topology_vs_oracle(gd):
     assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
     assert abs(got["loss"] - loss) < 1e-4 * abs(loss), (got["loss"], loss)
     assert set(got["grads"]) == set(grads) and len(grads) > 300
-    _check_grads(got["grads"], grads, 1e-3)
+    _check_grads(got["grads"], grads, GRAD_TOL, "F128 B=2 train step vs oracle")
     # the benchmark's per-GPU batch (B = 32: other split-K plans, image-pair tiles with 16 pairs): 16 copies of the batch above give the
     # same mean loss and mean gradients
     del st
@@ -131,7 +144,7 @@ def test_f128_train_step_full_topology_vs_oracle(gd):
     assert _guard().read()[0] == 0
     assert abs(got32["loss"] - got["loss"]) < 1e-5 * abs(got["loss"])
     assert rel_err(got32["eps"][:2], got["eps"]) < 1e-5 and rel_err(got32["shift"][30:], got["shift"]) < 1e-5
-    _check_grads(got32["grads"], {k: v.cpu() for k, v in got["grads"].items()}, 2e-4)
+    _check_grads(got32["grads"], {k: v.cpu() for k, v in got["grads"].items()}, GRAD_TOL, "F128 B=32 (16 copies) vs B=2")
 
 
 def _plan_census(plan):
@@ -177,7 +190,7 @@ def test_f128_b32_gradients_directly_vs_oracle_and_the_forms_the_plans_launch(gd
     z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise)
     assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
     assert abs(got["loss"] - loss) < 1e-4 * abs(loss), (got["loss"], loss)
-    _check_grads(got["grads"], grads, 1e-3)
+    _check_grads(got["grads"], grads, GRAD_TOL, "F128 B=32 distinct images vs oracle")
     del st
     # the evaluator's sampling batch (sampler/autoencoding_eval.py:125): the plan of one denoising step
     dec.set_eval_mode()
@@ -216,7 +229,7 @@ def test_c64_train_step_full_topology_fp32_and_bf16(gd):
     z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise)
     assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
     assert abs(got["loss"] - loss) < 1e-4 * abs(loss)
-    _check_grads(got["grads"], grads, 1e-3)
+    _check_grads(got["grads"], grads, GRAD_TOL, "C64 B=2 vs oracle")
     # BASELINE config #2 runs in bf16 (optimizer_config.enable_amp -> math "bf16": bf16 operands, fp32 accumulate).  The reference has no
     # bf16 numerics of its own: the stated tolerance is against the fp32-grade path on the same net.
     del st
@@ -256,34 +269,42 @@ def test_m32_regular_step_full_topology_vs_oracle(gd):
     loss.backward()
     assert rel_err(st.eps.permute(0, 3, 1, 2), eps.detach()) < 1e-4
     assert abs(float(st.loss.item()) - float(loss)) < 1e-4 * abs(float(loss))
-    _check_grads(net.grads(), {k: v.grad for k, v in sd.items()}, 1e-3)
+    _check_grads(net.grads(), {k: v.grad for k, v in sd.items()}, GRAD_TOL, "M32 B=16 vs oracle")
     assert abs(sum(p.numel() for p in net.P.values()) - 19.4e6) < 0.1e6                                         # 19.4 M
 
 
-def test_f128_ddim100_decode_vs_oracle_psnr_and_ssim_three_decimals(gd):
-    """The evaluator's decoding protocol at the benchmarked network: 100 DDIM steps of the FFHQ-128 decoder (sampler/autoencoding_eval.py:78,
-    diffusion/ddim.py:110-120), B=1, against the oracle walking the same trajectory on the host cores.  This is the oracle check of the
-    SAMPLING-ONLY kernel paths at real size -- GroupNorm applied inside the conv staging, skip conv inside the K loop, statistics from the
-    producing conv's epilogue (engine.py gn_conv / conv_skip / _stats_buf) -- which no training-step test touches.
-    Stated bounds: PSNR of the decoded image vs the oracle's > 55 dB on [-1,1] images after 100 steps (toy nets: > 80 dB, ddim5+ddim5: > 60 dB);
+@pytest.mark.timeout(1500)
+def test_f128_ddim100_encode_then_decode_round_trip_vs_oracle_psnr_and_ssim_three_decimals(gd):
+    """The evaluator's protocol at the benchmarked network, BOTH halves (the inversion was pinned on toy nets only): 100 DDIM
+    encode steps x_0 -> x_T followed by 100 decode steps x_T -> reconstruction of the FFHQ-128 decoder (sampler/autoencoding_eval.py:63-78,
+    diffusion/ddim.py:110-147; the shipped evaluator inverts with ddim1000 = 999 steps of the same kernel path -- that run is timed once per round,
+    profiles/r06_autoencode_b100.json), B = 1, against the oracle walking the same two trajectories on the host cores (200 decoder passes: ~6 min).
+    This is also the oracle check of the SAMPLING-ONLY kernel paths at real size -- GroupNorm applied inside the conv staging, statistics from
+    the producing conv's epilogue, the eps-only plan of stop_percent (engine.py gn_conv / _stats_buf) -- which no training-step test touches.
+    Stated bounds: PSNR of x_T and of the reconstruction vs the oracle's > 55 dB (on [-1,1] images resp. unit-variance latents scaled the same);
     SSIM and MSE of (x_0, reconstruction) through pdae_ssim_mse equal to 3 decimals for the two reconstructions."""
     from pdae_amd.metric import ssim_mse
     c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml", seed_enc=4, seed_dec=6)
     dec.set_eval_mode()
     x0 = _batch(1, 3, 128, seed=8)[0]
-    xT = torch.randn(1, 3, 128, 128, generator=torch.Generator().manual_seed(21))
     s = O.Schedules()
     with torch.no_grad():
         z = O.encoder_forward(enc_sd, ename, x0)
-        rec_ref = O.shift_ddim_sample_loop(s, "ddim100", dec_sd, dcfg, z, xT)
+        xT_ref = O.shift_ddim_encode_loop(s, "ddim100", dec_sd, dcfg, z, x0)
+        rec_ref = O.shift_ddim_sample_loop(s, "ddim100", dec_sd, dcfg, z, xT_ref)
         _guard().reset()
-        rec = gd.representation_learning_ddim_sample("ddim100", enc, dec, x0.to(DEV), xT.to(DEV))
+        xT = gd.representation_learning_ddim_encode("ddim100", enc, dec, x0.to(DEV))
+        rec = gd.representation_learning_ddim_sample("ddim100", None, dec, None, xT, enc(x0.to(DEV)))
     assert _guard().read()[0] == 0
-    psnr = 10 * math.log10(4.0 / float(((rec.double().cpu() - rec_ref.double()) ** 2).mean()))
+
+    def psnr(a, b):
+        return 10 * math.log10(4.0 / float(((a.double().cpu() - b.double()) ** 2).mean()))
+    p_enc, p_rec = psnr(xT, xT_ref), psnr(rec, rec_ref)
     sg, mg = ssim_mse(x0.to(DEV), rec, denormalize=True)
     sr, mr = ssim_mse(x0.to(DEV), rec_ref.to(DEV), denormalize=True)
-    print(f"[F128 ddim100 decode, B=1] PSNR vs oracle {psnr:.1f} dB; ssim {float(sg):.5f} / {float(sr):.5f}; mse {float(mg):.6f} / {float(mr):.6f}")
-    assert psnr > 55, psnr
+    print(f"[F128 ddim100 encode + ddim100 decode, B=1] PSNR vs oracle: x_T {p_enc:.1f} dB, reconstruction {p_rec:.1f} dB; ssim {float(sg):.5f} / {float(sr):.5f}; "
+          f"mse {float(mg):.6f} / {float(mr):.6f}")
+    assert p_enc > 55 and p_rec > 55, (p_enc, p_rec)
     assert abs(float(sg) - float(sr)) < 5e-4 and abs(float(mg) - float(mr)) < 5e-4, (float(sg), float(sr), float(mg), float(mr))
     assert rel_err(ssim_mse(x0.to(DEV), rec_ref.to(DEV), denormalize=True)[0], O.ssim((x0 + 1) / 2, (rec_ref + 1) / 2)) < 1e-4     # the metric kernel itself, at 128^2
 
@@ -326,7 +347,7 @@ def test_latent_ffhq_yaml_full_topology_step_vs_oracle(gd):
     G = net.grads()
     ref_g = {k: v.grad for k, v in ref_sd.items() if k in G}
     assert len(ref_g) >= 4 * cfg["num_layers"]
-    _check_grads(G, ref_g, 1e-3)
+    _check_grads(G, ref_g, GRAD_TOL, "latent MLPSkipNet B=128 vs oracle")
     # optimizer: AdamW step 1 on the oracle's gradients from the same parameters.  At step 1 the update is lr * sign-like(g): compare where the
     # gradient is well above rounding noise, and bound the rest by one step size
     for k, gr in ref_g.items():
@@ -370,7 +391,7 @@ def test_f128_train_step_with_dropout_on_vs_oracle_with_the_device_masks(gd):
         O.DROP_MASKS.clear()
     assert rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
     assert abs(got["loss"] - loss) < 1e-4 * abs(loss), (got["loss"], loss)
-    _check_grads(got["grads"], grads, 1e-3)
+    _check_grads(got["grads"], grads, GRAD_TOL, "F128 dropout on vs oracle")
 
 
 def test_f128_eval_mode_single_pass_vs_oracle_b2_and_the_sampling_batch_of_100(gd):
