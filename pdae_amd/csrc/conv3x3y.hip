@@ -324,14 +324,23 @@ __global__ void __launch_bounds__(YTHREADS, 1) conv3x3y_kernel(const PatchParams
   // holds the CONVERTED step m (being multiplied), the registers hold the RAW data of step m + 1 (validity bits cv_vm, GroupNorm coefficients
   // loaded), qb[0 .. YRB - 2] hold the U fragments of the first YRB - 1 units of step m.  During the iteration: step m + 1 is converted into the other buffer, step
   // m + 2 (the load position l_*) is loaded into the freed registers, its coefficients at unit 11.
+  // XCD-aware order (round 6): block b runs on XCD b % 8 and each XCD has its own L2, so with tile = block index the two (or more) 128-channel
+  // output tiles of ONE pixel tile -- consecutive tile indices, which read the same input patch -- sat on different XCDs and every input byte was
+  // fetched from HBM once per output tile (profiles/r05_pmc_traffic: 1043 MB per 128 -> 256 data gradient against ~540 MB once).  The bijection
+  // below (conv3x3w's) gives the blocks of an XCD CONSECUTIVE tile indices: output tiles of a pixel tile, and pixel tiles that share halo
+  // columns, meet in one L2.  Bit 16 of `stagger` switches it (knob PDAE_Y_XCD, default on).
   int m_tile = blockIdx.x;
+  if (stagger & 0x10000) {
+    const int q8 = G >> 3, r8 = G & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    m_tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+  }
   if (m_tile >= ntiles) return;
   // Phase stagger: every workgroup has the same work, so without it all 256 reach their (exposed) epilogues together and the output of a whole
   // round -- 16 x 16 x 128 floats per CU, 33 MB -- queues on the HBM write path while every matrix pipe idles.  Four phase groups per XCD, each
   // `stagger` x 1024 cycles behind the previous one: a group drains its quarter of the round while the other three multiply.
-  if (stagger > 0) {
+  if ((stagger & 0xffff) > 0) {
     const int g = (blockIdx.x >> 3) & 3;
-    for (int i = 0; i < g * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    for (int i = 0; i < g * (stagger & 0xffff); ++i) __builtin_amdgcn_s_sleep(16);
   }
   int m_img, m_y0, m_x0, m_n0, m_k = 0;
   Y_DECODE(m_tile, m_img, m_y0, m_x0, m_n0)
@@ -678,7 +687,13 @@ template <int NS, bool GN, bool EX, bool ST, bool GB = false, int RH = 2> static
   auto magic = [](int d) { return (unsigned)((0x100000000ull / (unsigned long long)d) + 1ull); };      // unused for d == 1
   const YDiv D{magic(P.tiles_n), magic(P.tiles_x), magic(P.tiles_y)};
   if (ntiles >= (1ll << 20) || P.tiles_n >= 4096 || P.tiles_x >= 4096 || P.tiles_y >= 4096) { pdae_set_error("conv3x3y: %lld tiles", ntiles); return 1; }
-  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX, ST, GB, RH>), grid, dim3(YTHREADS), smem, s, P, ntiles >= 2 * 256 ? stagger : 0, D);
+  // Multi-GPU remedy for the LDS displacement measured in round 5: a co-resident communication kernel that holds LDS keeps a
+  // persistent workgroup off its CU for the whole launch; with PDAE_Y_GRID_TRIM = k the launch uses 256 - k workgroups, leaving k CUs to the
+  // collective's channels (default 0; bench.py records it in `comm`; only meaningful at world size > 1)
+  const int trim = pdae_knob(KNOB_Y_GRID_TRIM);
+  if (trim > 0 && trim < 128 && ntiles > 256 - trim) grid = dim3((unsigned)(256 - trim));
+  hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX, ST, GB, RH>), grid, dim3(YTHREADS), smem, s, P,
+                     (ntiles >= 2 * 256 ? (stagger & 0xffff) : 0) | (pdae_knob(KNOB_Y_XCD) ? 0x10000 : 0), D);
   return pdae_launch_status("conv3x3y");
 }
 
