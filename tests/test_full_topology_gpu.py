@@ -281,7 +281,7 @@ def test_f128_ddim100_encode_then_decode_round_trip_vs_oracle_psnr_and_ssim_thre
     profiles/r06_autoencode_b100.json), B = 1, against the oracle walking the same two trajectories on the host cores (200 decoder passes: ~6 min).
     This is also the oracle check of the SAMPLING-ONLY kernel paths at real size -- GroupNorm applied inside the conv staging, statistics from
     the producing conv's epilogue, the eps-only plan of stop_percent (engine.py gn_conv / _stats_buf) -- which no training-step test touches.
-    Stated bounds: PSNR of x_T and of the reconstruction vs the oracle's > 55 dB (on [-1,1] images resp. unit-variance latents scaled the same);
+    Stated bounds: PSNR of x_T and of the reconstruction vs the oracle's > 85 dB (peak 2: [-1,1] images; measured 128.5 / 98.5 dB);
     SSIM and MSE of (x_0, reconstruction) through pdae_ssim_mse equal to 3 decimals for the two reconstructions."""
     from pdae_amd.metric import ssim_mse
     c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml", seed_enc=4, seed_dec=6)
@@ -304,7 +304,7 @@ def test_f128_ddim100_encode_then_decode_round_trip_vs_oracle_psnr_and_ssim_thre
     sr, mr = ssim_mse(x0.to(DEV), rec_ref.to(DEV), denormalize=True)
     print(f"[F128 ddim100 encode + ddim100 decode, B=1] PSNR vs oracle: x_T {p_enc:.1f} dB, reconstruction {p_rec:.1f} dB; ssim {float(sg):.5f} / {float(sr):.5f}; "
           f"mse {float(mg):.6f} / {float(mr):.6f}")
-    assert p_enc > 55 and p_rec > 55, (p_enc, p_rec)
+    assert p_enc > 85 and p_rec > 85, (p_enc, p_rec)        # measured on MI355X in round 6: 128.5 / 98.5 dB
     assert abs(float(sg) - float(sr)) < 5e-4 and abs(float(mg) - float(mr)) < 5e-4, (float(sg), float(sr), float(mg), float(mr))
     assert rel_err(ssim_mse(x0.to(DEV), rec_ref.to(DEV), denormalize=True)[0], O.ssim((x0 + 1) / 2, (rec_ref + 1) / 2)) < 1e-4     # the metric kernel itself, at 128^2
 
