@@ -220,7 +220,7 @@ def _head(B, pre, h):
     return y, NS(g=g, c=c)
 
 
-def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shift=False, dropout=False):
+def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shift=False, dropout=False, z_side=False):
     """Emits UNet (shift=False) or ShiftUNet (shift=True) forward.  x: NHWC [N,H,W,Cimg]; t: int64 [N].
     train_shift: keep the shift-branch activations (and every skip tensor) for `shift_backward`.
     When B.save is set by the caller (regular UNet training) everything is kept for `unet_backward`."""
@@ -245,12 +245,21 @@ def unet_forward(B, cfg, x, t, freqs, cond=None, z=None, shift=False, train_shif
         pl.n_const = len(pl.recs)
     tctx = _time_embed(B, cfg, t, freqs, cond)
     ea = tctx.ea
+    # z_side (round 6, training): z arrives from an encoder pass that runs on the SECOND stream beside the input blocks (trainer/fused_step.py);
+    # everything that reads z in the forward pass -- label_emb, its SiLU, the emb_z_layers Linears -- belongs to the shift branch and goes there too,
+    # so the main stream's first reader of anything z-dependent is behind the join at the end of this function
+    z_side = bool(z_side and shift and not hoist and os.environ.get("PDAE_SIDE_SHIFT", "1") != "0")
     if shift and not hoist:
-        semb, l_lab = B.linear(z, "label_emb")
-        eza = B.silu(semb)
+        with pl.side(z_side):
+            semb, l_lab = B.linear(z, "label_emb")
+            eza = B.silu(semb)
     # every ResBlock's emb_layers / emb_z_layers Linear in one launch (they only depend on the embeddings computed above)
     if hoist:
         B.prefetch_emb(ea, plain + shifted)
+    elif z_side:
+        B.prefetch_emb(ea, plain + shifted)
+        with pl.side(True):
+            B.prefetch_emb(None, [], eza, shifted)
     else:
         B.prefetch_emb(ea, plain + shifted, eza, shifted)
     hs, in_ctx = [], []

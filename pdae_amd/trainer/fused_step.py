@@ -333,10 +333,14 @@ class FusedRLStep(_FusedStep):
         Be = Builder(p, encoder.P, encoder.grads(), save=True, acc_grads=acc, math=math)
         Bd = Builder(p, decoder.P, decoder.grads(), save=False, drop_p=drop, acc_grads=acc, math=math, frozen_of=decoder)
         # ---- forward
-        z, ex = G.encoder_forward(Be, encoder.NAME, self.x0)
+        # the encoder pass feeds only the shift branch (through z): it runs on the executor's second stream beside the frozen trunk's input blocks
+        # (PDAE_SIDE_ENC=0: in front of them on the caller's stream, as through round 5); the join at the end of unet_forward covers it
+        side_enc = os.environ.get("PDAE_SIDE_ENC", "1") != "0" and os.environ.get("PDAE_SIDE_SHIFT", "1") != "0"
+        with p.side(side_enc):
+            z, ex = G.encoder_forward(Be, encoder.NAME, self.x0)
         x_t = p.buf(N, Hh, W, Cimg)
         p.emit(H.op_q_sample(self.x0, self.noise, self.t, gd.sqrt_alphas_cumprod, gd.sqrt_one_minus_alphas_cumprod, N, per, x_t))
-        fx = G.unet_forward(Bd, cfg, x_t, self.t, decoder.freqs, z=z, shift=True, train_shift=True, dropout=drop > 0)
+        fx = G.unet_forward(Bd, cfg, x_t, self.t, decoder.freqs, z=z, shift=True, train_shift=True, dropout=drop > 0, z_side=side_enc)
         d_shift = p.buf(N, Hh, W, Cimg)
         p.emit(H.op_loss(self.noise, fx.eps, fx.shift, self.t, gd.shift_coef, gd.weight, N, per, self.loss, None, dg=d_shift,
                          scale=1.0 / self.num_iterations), ws_slot=9)

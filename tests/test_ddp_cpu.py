@@ -27,6 +27,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pdae_amd.utils import set_seed
+        from pdae_amd import hip as H
         from pdae_amd.model.shift_unet import ShiftUNet
         from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
         from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
@@ -60,7 +61,8 @@ def _worker(rank, world, port, q):
             assert ptrs == sorted(ptrs, reverse=True)
         assert enc_b[-1][1].data_ptr() == enc.flat_grad.data_ptr() and enc_b[0][0] < st.n_bwd
         ops_idx = [i for i, _ in st.buckets]
-        assert ops_idx == sorted(ops_idx) and st.n_fwd < ops_idx[0] and ops_idx[-1] == st.n_bwd
+        # (round 6: the backward segment ends with the explicit join in front of the optimizer ops -- the last bucket is final right before it)
+        assert ops_idx == sorted(ops_idx) and st.n_fwd < ops_idx[0] and ops_idx[-1] == st.n_bwd - 1 and st.plan.recs[st.n_bwd - 1].kind == H.OP_JOIN
         # fake "backward": every rank writes rank-dependent gradients, segments are recorded instead of launched
         dec.flat_grad.copy_(torch.arange(dec.flat_grad.numel(), dtype=torch.float32) % 7 + rank)
         enc.flat_grad.fill_(float(rank + 1))
@@ -174,6 +176,7 @@ def _two_rank_retry_worker(rank, world, port, q):
     try:
         import time
         from pdae_amd.utils import set_seed
+        from pdae_amd import hip as H
         from pdae_amd.model.shift_unet import ShiftUNet
         from pdae_amd.model.representation_learning.encoder import CELEBA64Encoder
         from pdae_amd.diffusion.gaussian_diffusion import GaussianDiffusion
