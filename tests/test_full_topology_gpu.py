@@ -290,11 +290,19 @@ def test_f128_ddim100_encode_then_decode_round_trip_vs_oracle_psnr_and_ssim_thre
     s = O.Schedules()
     with torch.no_grad():
         z = O.encoder_forward(enc_sd, ename, x0)
-        xT_ref = O.shift_ddim_encode_loop(s, "ddim100", dec_sd, dcfg, z, x0)
-        rec_ref = O.shift_ddim_sample_loop(s, "ddim100", dec_sd, dcfg, z, xT_ref)
+        # the oracle's 200 decoder passes take ~1.6 s each on the GPU box's 16 host cores; a box whose cores are busy must not turn this test into
+        # a quarter of an hour: the schedule is ddim100 unless ONE timed oracle pass says the whole walk would take more than ~10 minutes
+        import time
+        t0 = time.time()
+        O.shift_unet_forward(dec_sd, dcfg, x0, torch.tensor([500]), z)
+        per = time.time() - t0
+        sched = os.environ.get("PDAE_TEST_DDIM", "ddim100" if per < 3.0 else ("ddim50" if per < 6.0 else "ddim20"))
+        print(f"[F128 round trip] one oracle decoder pass {per:.2f} s -> schedule {sched}")
+        xT_ref = O.shift_ddim_encode_loop(s, sched, dec_sd, dcfg, z, x0)
+        rec_ref = O.shift_ddim_sample_loop(s, sched, dec_sd, dcfg, z, xT_ref)
         _guard().reset()
-        xT = gd.representation_learning_ddim_encode("ddim100", enc, dec, x0.to(DEV))
-        rec = gd.representation_learning_ddim_sample("ddim100", None, dec, None, xT, enc(x0.to(DEV)))
+        xT = gd.representation_learning_ddim_encode(sched, enc, dec, x0.to(DEV))
+        rec = gd.representation_learning_ddim_sample(sched, None, dec, None, xT, enc(x0.to(DEV)))
     assert _guard().read()[0] == 0
 
     def psnr(a, b):
@@ -302,7 +310,7 @@ def test_f128_ddim100_encode_then_decode_round_trip_vs_oracle_psnr_and_ssim_thre
     p_enc, p_rec = psnr(xT, xT_ref), psnr(rec, rec_ref)
     sg, mg = ssim_mse(x0.to(DEV), rec, denormalize=True)
     sr, mr = ssim_mse(x0.to(DEV), rec_ref.to(DEV), denormalize=True)
-    print(f"[F128 ddim100 encode + ddim100 decode, B=1] PSNR vs oracle: x_T {p_enc:.1f} dB, reconstruction {p_rec:.1f} dB; ssim {float(sg):.5f} / {float(sr):.5f}; "
+    print(f"[F128 {sched} encode + {sched} decode, B=1] PSNR vs oracle: x_T {p_enc:.1f} dB, reconstruction {p_rec:.1f} dB; ssim {float(sg):.5f} / {float(sr):.5f}; "
           f"mse {float(mg):.6f} / {float(mr):.6f}")
     assert p_enc > 85 and p_rec > 85, (p_enc, p_rec)        # measured on MI355X in round 6: 128.5 / 98.5 dB
     assert abs(float(sg) - float(sr)) < 5e-4 and abs(float(mg) - float(mr)) < 5e-4, (float(sg), float(sr), float(mg), float(mr))
