@@ -61,7 +61,6 @@ enum PdaeKnob {
   KNOB_W3V,           // PDAE_W3V: 3x3 weight gradients in the producer / consumer form conv3x3v.hip where it applies (1); 0: conv3x3w.hip everywhere
   KNOB_Y_XCD,         // PDAE_Y_XCD: conv3x3y gives the workgroups of an XCD consecutive tile indices (1)
   KNOB_Y_GRID_TRIM,   // PDAE_Y_GRID_TRIM: conv3x3y launches 256 - k workgroups (0): k CUs stay free for a collective's channels at world size > 1
-  KNOB_GN_SERP,       // PDAE_GN_SERP: direction of the GroupNorm-backward streaming passes: bit 1 reduction backwards, bit 0 apply opposite to the reduction (0)
   KNOB_COUNT
 };
 int pdae_knob(int id);

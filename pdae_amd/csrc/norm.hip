@@ -414,11 +414,9 @@ __device__ __forceinline__ float4 compute_dv(float4 da, float4 xm, float4 a, flo
 
 __device__ __forceinline__ void gn_bwd_reduce_body(const Src2& s, int H, int W, int C, int chunk, const float* __restrict__ coef, int N,
                                                    const float* __restrict__ dA, int act, int mode, float drop_p,
-                                                   unsigned long long seed, unsigned long long offset, float* __restrict__ part, int rev = 0) {
+                                                   unsigned long long seed, unsigned long long offset, float* __restrict__ part) {
   __shared__ float red[2 * 1024];
-  // rev: the launch walks the tensor from its END (last image, last chunk first) -- see k_gn_bwd: consecutive streaming passes alternate direction
-  // so that each starts on what the previous one left in the 256 MB Infinity Cache
-  const int n = rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y, sidx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, S = gridDim.x, HW = H * W;
+  const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x, HW = H * W;
   const int NQ = C >> 2, PL = 256 / NQ;
   const int t = threadIdx.x, q = t % NQ, pl = t / NQ, c = q * 4;
   const size_t NC = (size_t)N * C;
@@ -460,8 +458,8 @@ __device__ __forceinline__ void gn_bwd_reduce_body(const Src2& s, int H, int W, 
 }
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(Src2 s, int H, int W, int C, int chunk, const float* __restrict__ coef, int N,
                                                             const float* __restrict__ dA, int act, int mode, float drop_p,
-                                                            unsigned long long seed, unsigned long long offset, float* __restrict__ part, int rev) {
-  gn_bwd_reduce_body(s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part, rev);
+                                                            unsigned long long seed, unsigned long long offset, float* __restrict__ part) {
+  gn_bwd_reduce_body(s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
 }
 
 // one block per sample n.  Writes d(scale,shift) pairs, the per-(n,c) [c1,c2] apply coefficients and
@@ -554,7 +552,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H,
                                                            float drop_p, unsigned long long seed, unsigned long long offset,
                                                            const float* __restrict__ add, float* __restrict__ dx0, int acc0,
                                                            float* __restrict__ dx1, int acc1, unsigned* __restrict__ amax0,
-                                                           const float* __restrict__ pgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_param, int rev) {
+                                                           const float* __restrict__ pgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_param) {
   __shared__ float wmax[4];
   // the gamma / beta gradients (sum over samples of the finalize kernel's per-sample contributions) ride in this launch: the blocks of
   // sample 0 take 256 channels each first -- one launch less per GroupNorm backward (53 per FFHQ-128 step)
@@ -562,8 +560,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H,
     const int cpar = blockIdx.x * 256 + threadIdx.x;
     if (cpar < C) gn_bwd_param_one(cpar, N, C, pgb, dgamma, dbeta, acc_param);
   }
-  const int n = rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y, bx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
-  const int NQ = C >> 2, PL = 256 / NQ, HW = H * W;
+  const int n = blockIdx.y, NQ = C >> 2, PL = 256 / NQ, HW = H * W;
   const int t = threadIdx.x, q = t % NQ, pl = t / NQ, c = q * 4;
   float* dbase = nullptr; int accf = 0, Cd = 0, cd = 0;
   if (pl < PL) {
@@ -580,7 +577,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(Src2 s, int N, int H,
   const float4 b = *reinterpret_cast<const float4*>(coef + 2 * NC + (size_t)n * C + c);
   const float* cp = c12 + ((size_t)n * C + c) * 2;
   const float4 ca = *reinterpret_cast<const float4*>(cp), cb = *reinterpret_cast<const float4*>(cp + 4);   // c1,c2 interleaved
-  const int p0 = bx * chunk, p1 = min(HW, p0 + chunk);
+  const int p0 = blockIdx.x * chunk, p1 = min(HW, p0 + chunk);
   for (int p = p0 + pl; p < p1; p += UNR * PL) {
     float4 x[UNR], da[UNR], ad[UNR], ex[UNR];
 #pragma unroll
@@ -735,11 +732,7 @@ int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int
     hipLaunchKernelGGL(gn_bwd_reduce_fused_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, G, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part,
                        rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am, dgamma, dbeta, acc_param, ticket);
   } else {
-    // PDAE_GN_SERP (round 6): bit 1 = the reduction walks the tensor backwards (its dA was written front to back by the data gradient: the tail is
-    // what the Infinity Cache still holds), bit 0 = the apply pass walks it in the direction OPPOSITE to the reduction (it starts on the images the
-    // reduction read last).  Only tensors larger than the cache care (128^2 at B = 32: x + dA = 537 MB against 256 MB); results are identical.
-    const int serp = pdae_knob(KNOB_GN_SERP);
-    if (!parts) hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part, (serp >> 1) & 1);
+    if (!parts) hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(S, N), dim3(256), 0, st, s, H, W, C, chunk, coef, N, dA, act, mode, drop_p, seed, offset, part);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, N, HW, C, G, S, part, rstd, gamma, beta, ss, zss, dss, dzss, c12, pgb, am);
   }
   int Sa = stream_chunks(HW, C), chunk_a = cdiv(HW, Sa);
@@ -750,8 +743,7 @@ int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, N, C, pgb, dgamma, dbeta, acc_param);
   if (dx0 || dx1) {
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(Sa, N), dim3(256), 0, st, s, N, H, W, C, chunk_a, coef, c12, dA, act, mode, drop_p, seed, offset,
-                       add, dx0, acc0, dx1, acc1, am, pgb, ride ? dgamma : nullptr, dbeta, acc_param,
-                       (parts || ticket) ? (pdae_knob(KNOB_GN_SERP) & 1) : (((pdae_knob(KNOB_GN_SERP) >> 1) ^ pdae_knob(KNOB_GN_SERP)) & 1));
+                       add, dx0, acc0, dx1, acc1, am, pgb, ride ? dgamma : nullptr, dbeta, acc_param);
   }
   return pdae_launch_status("gn_bwd");
 }
