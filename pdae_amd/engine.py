@@ -285,7 +285,10 @@ class Builder:
         self.fuse_gn = os.environ.get("PDAE_FUSE_GN", "1") != "0"      # forward-only GN+SiLU+conv3x3 stages run fused (gn_conv)
         # TRAINED in_layers stages (GroupNorm -> SiLU -> conv3x3, no dropout) run the same fused forward and their weight gradient recomputes
         # the activation while it stages X (gn_conv_saved): the activated tensor is never written, saved or re-read
-        self.fuse_gn_train = os.environ.get("PDAE_FUSE_GN_TRAIN", "1") != "0"
+        # Round 6: OFF by default.  With the producer / consumer weight gradient (conv3x3v) the plain launch is 0.858 ms against 1.055 ms for the
+        # recomputing one (128^2 256 -> 128), and the step measured 46.5 / 46.7 ms without against 46.9 / 47.0 with it (same box): the form is now a
+        # MEMORY switch (-2.5 GiB of plan buffers at B = 32), not the default
+        self.fuse_gn_train = os.environ.get("PDAE_FUSE_GN_TRAIN", "0") != "0"
         # ... where it pays: the weight gradient stages (and now maps) X once per 64 output channels, the forward once per 128, while the pass it
         # replaces costs two tensor passes whatever the width -- so the form is taken up to this many output channels (measured)
         self.fuse_gn_train_max_cout = int(os.environ.get("PDAE_FUSE_GN_TRAIN_MAXCOUT", "128"))

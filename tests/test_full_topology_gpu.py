@@ -172,7 +172,7 @@ def _plan_census(plan):
     return n
 
 
-def test_f128_b32_gradients_directly_vs_oracle_and_the_forms_the_plans_launch(gd):
+def test_f128_b32_gradients_directly_vs_oracle_and_the_forms_the_plans_launch(gd, monkeypatch):
     """the per-GPU batch of the benchmark (B = 32, 32 DISTINCT images) against the oracle directly -- this is the only batch at which the
     F128 step runs the Winograd-form kernels (conv3x3y, 16- and 8-row tiles), the data gradients that leave the GroupNorm-backward sums and the
     weight gradients that recompute their GroupNorm input -- and an assertion on WHICH forms the training plan and the B = 100 sampling plan launch, so
@@ -186,12 +186,26 @@ def test_f128_b32_gradients_directly_vs_oracle_and_the_forms_the_plans_launch(gd
     print("[F128 B=32 training plan]", n)
     assert n["wino_fwd"] >= 60 and n["wino_dgrad"] >= 25, n                # the 128^2 / 64^2 / wide 32^2 layers (16-row tiles) + the 16^2 layers (8-row tiles)
     assert n["gnb"] >= 8 and n["gnb"] == n["gn_bwd_parts"], n            # in_layers GroupNorms of the shift branch (dropout is 0 here: out_layers too)
-    assert n["wgrad_gn"] >= 6, n                                             # in_layers stages up to 128 output channels (PDAE_FUSE_GN_TRAIN_MAXCOUT)
+    assert n["wgrad_gn"] == 0, n                                             # round 6 default (PDAE_FUSE_GN_TRAIN=0): the in_layers activation is materialised, plain weight gradients
     z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise)
     assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
     assert abs(got["loss"] - loss) < 1e-4 * abs(loss), (got["loss"], loss)
     _check_grads(got["grads"], grads, GRAD_TOL, "F128 B=32 distinct images vs oracle")
     del st
+    # the memory-saving form (PDAE_FUSE_GN_TRAIN=1: fused-GN forward + weight gradients that recompute the activation, -2.5 GiB at B = 32) against the same
+    # oracle numbers: it stays a supported switch and this is its topology-level check
+    monkeypatch.setenv("PDAE_FUSE_GN_TRAIN", "1")
+    for m_ in (enc, dec):
+        m_.invalidate_plans()
+    st, got1 = _run_rl(gd, enc, dec, 32, 128, x0, t, noise)
+    monkeypatch.delenv("PDAE_FUSE_GN_TRAIN")
+    n1 = _plan_census(st.plan)
+    assert n1["wgrad_gn"] >= 6, n1                                           # in_layers stages up to 128 output channels (PDAE_FUSE_GN_TRAIN_MAXCOUT)
+    assert rel_err(got1["eps"], eps) < 1e-4 and rel_err(got1["shift"], shift) < 1e-4 and abs(got1["loss"] - loss) < 1e-4 * abs(loss)
+    _check_grads(got1["grads"], grads, GRAD_TOL, "F128 B=32, PDAE_FUSE_GN_TRAIN=1 vs oracle")
+    del st
+    for m_ in (enc, dec):
+        m_.invalidate_plans()
     # the evaluator's sampling batch (sampler/autoencoding_eval.py:125): the plan of one denoising step
     dec.set_eval_mode()
     ns = _plan_census(dec.plan(100, 128, 128, False))
