@@ -9,7 +9,7 @@ O=$R/gpurun_out
 mkdir -p $O
 for s in $stages; do
   case $s in
-    tests) timeout 1200 python -m pytest tests -m gpu -q --durations=15 ${PYTEST_ARGS} > $O/${tag}_tests.txt 2>&1; echo "tests rc=$?"; tail -25 $O/${tag}_tests.txt ;;
+    tests) timeout 2000 python -m pytest tests -m gpu -q --durations=15 ${PYTEST_ARGS} > $O/${tag}_tests.txt 2>&1; echo "tests rc=$?"; tail -25 $O/${tag}_tests.txt ;;
     bench) timeout 900 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.log; echo "bench rc=$?"; tail -3 $O/${tag}_bench.log; cat $O/${tag}_bench.json ;;
     stats) (cd /tmp && timeout 240 rocprofv3 --output-format csv --kernel-trace --stats -d $O/${tag}_stats -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ddim --no-legs > $O/${tag}_stats.log 2>&1); echo "stats rc=$?" ;;
     pmc)
