@@ -29,8 +29,7 @@ extern "C" {
 typedef void* pdae_stream_t; /* hipStream_t */
 
 const char* pdae_last_error(void);
-/* ABI history.  11 (round 6): + pdae_gn_apply_from_conv_stats / PDAE_OP_GN_APPLY_STATS; knobs PDAE_W3V, PDAE_Y_XCD, PDAE_Y_GRID_TRIM.
- * 10 (round 5): pdae_op.reserved became pdae_op.flags (PDAE_OPF_SIDE: the executor's second stream) + PDAE_OP_JOIN + knob
+/* ABI history.  10 (round 5): pdae_op.reserved became pdae_op.flags (PDAE_OPF_SIDE: the executor's second stream) + PDAE_OP_JOIN + knob
  *   PDAE_SIDE_STREAM; arrays written for ABI 9 (flags = 0) run unchanged.
  * 9 (round 5): - pdae_wino_* (the gated 2-D Winograd probe left the library: tools/probes/r04_winograd/); + pdae_set_knob / pdae_get_knob
  *   (the library no longer reads its environment per call); + pdae_conv_gn_input_arm / pdae_conv2d_wgrad_gn_ok (weight gradient that recomputes a fused
@@ -153,15 +152,6 @@ int pdae_conv_stats_arm(float* part);
 int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G, float eps, const float* part0, int tpi0, const float* part1, int tpi1,
                                  const float* gamma, const float* beta, const float* ss, const float* zss, float* mean, float* rstd, float* coef,
                                  pdae_stream_t stream);
-/* (ABI 11) The same coefficients AND the apply pass y = act(a (x - mu) + b) [* dropout mask] of pdae_gn_apply (mode 0) in ONE launch: every block
- * combines the partial sums of its image before it streams its pixels, so a GroupNorm behind such a producer costs one launch in front of its
- * consumer instead of two dependent ones (module.py:241, 257-265: GroupNorm -> [AdaGN] -> SiLU -> [Dropout]).  mean / rstd / coef are written as by
- * pdae_gn_coef_from_conv_stats (the backward pass reads them).  pdae_op PDAE_OP_GN_APPLY_STATS: p = x0, x1, part0, part1, gamma, beta, ss, zss, mean,
- * rstd, coef, y; i = C0, C1, N, H, W, G, tpi0, tpi1, act, seed, offset; f = eps, drop_p. */
-int pdae_gn_apply_from_conv_stats(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, float eps, const float* part0,
-                                  int tpi0, const float* part1, int tpi1, const float* gamma, const float* beta, const float* ss, const float* zss,
-                                  float* mean, float* rstd, float* coef, int act, float* y, float drop_p, uint64_t seed, uint64_t offset,
-                                  pdae_stream_t stream);
 /* dx[N,Hl,Wl,ci_cnt] (+)= dL/d(conv input channels ci_off..ci_off+ci_cnt) on the LOGICAL input grid (Hl = 2*Hi when up).
  * wp_t: NULL or pdae_conv_wprep(d, w, PDAE_WPREP_TRANSPOSED): the data gradient then runs as a forward convolution of dy (3x3: the
  * whole channel range only; 1x1: any 32-aligned ci_off). */
@@ -359,8 +349,7 @@ enum {
   PDAE_OP_AXPBY_ROWS, PDAE_OP_DDIM_STEP_ROWS, PDAE_OP_DDPM_STEP_ROWS, PDAE_OP_LINEAR_GROUP,
   PDAE_OP_ATTN_FWD, PDAE_OP_ATTN_BWD, PDAE_OP_LINEAR_BWD_GROUP, PDAE_OP_GN_COEF_FROM_CONV_STATS, PDAE_OP_CONV_WPREP_GROUP,
   PDAE_OP_SUBSAMPLE2, PDAE_OP_ZERO_INSERT2, PDAE_OP_GN_STATS_QUADS,
-  PDAE_OP_JOIN,    /* (ABI 10) the caller's stream waits for every PDAE_OPF_SIDE op issued so far; no arguments */
-  PDAE_OP_GN_APPLY_STATS      /* (ABI 11) pdae_gn_apply_from_conv_stats */
+  PDAE_OP_JOIN     /* (ABI 10) the caller's stream waits for every PDAE_OPF_SIDE op issued so far; no arguments */
 };
 /* pdae_op.flags (ABI 10; the field was `reserved`, always 0).  PDAE_OPF_SIDE: issue this op on the executor's second (low-priority) stream.
  * It starts when the ops in front of it in the array have finished, and runs beside the ops behind it until the next PDAE_OP_JOIN or the end

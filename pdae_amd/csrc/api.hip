@@ -20,7 +20,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 11; }
+extern "C" int pdae_abi_version(void) { return 10; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -329,22 +329,6 @@ extern "C" int pdae_gn_coef_from_conv_stats(int N, int HW, int C0, int C1, int G
   PDAE_CHECK_ARG(G > 0 && G <= 64 && (C0 + C1) % G == 0 && (((C0 + C1) / G) & 3) == 0 && (C0 & 3) == 0,
                  "gn_coef_from_conv_stats: groups must be whole channel quads (C / G and C0 multiples of 4)");
   return k_gn_coef_from_conv_stats(N, HW, C0, C1, G, eps, part0, tpi0, C1 ? part1 : nullptr, tpi1, gamma, beta, ss, zss, mean, rstd, coef, S(stream));
-}
-
-// GroupNorm coefficients from the producers' partial statistics AND the apply pass in one launch (ABI 11; norm.hip: gn_apply_stream_stats_kernel):
-// the arguments of pdae_gn_coef_from_conv_stats followed by those of pdae_gn_apply (mode 0, no pooled copy).  mean / rstd / coef are still
-// written (the backward pass and a recomputing weight gradient read them).
-extern "C" int pdae_gn_apply_from_conv_stats(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, float eps, const float* part0,
-                                             int tpi0, const float* part1, int tpi1, const float* gamma, const float* beta, const float* ss,
-                                             const float* zss, float* mean, float* rstd, float* coef, int act, float* y, float drop_p, uint64_t seed,
-                                             uint64_t offset, pdae_stream_t stream) {
-  PDAE_CHECK_ARG(x0 && (C1 == 0 || x1) && y && part0 && tpi0 > 0 && (C1 == 0 || (part1 && tpi1 > 0)) && gamma && beta && mean && rstd && coef,
-                 "gn_apply_from_conv_stats: null pointer");
-  PDAE_CHECK_ARG(N > 0 && H > 0 && W > 0 && G > 0 && G <= 64 && (C0 + C1) % G == 0 && (((C0 + C1) / G) & 3) == 0 && (C0 & 3) == 0,
-                 "gn_apply_from_conv_stats: groups must be whole channel quads (C / G and C0 multiples of 4)");
-  PDAE_CHECK_ARG(act == 0 || act == 1, "gn_apply_from_conv_stats: act must be 0 or 1");
-  return k_gn_apply_from_conv_stats(x0, C0, C1 ? x1 : nullptr, C1, N, H, W, G, eps, part0, tpi0, C1 ? part1 : nullptr, tpi1, gamma, beta, ss, zss, mean, rstd,
-                                    coef, act, y, drop_p, seed, offset, S(stream));
 }
 
 // ---- GroupNorm-backward sums from the data gradient that produces dA (conv3x3y.hip, GB instantiation): the reduction pass of pdae_gn_bwd over
@@ -787,10 +771,6 @@ static int run_one(const pdae_op& o, pdae_stream_t st) {
     case PDAE_OP_GN_COEF_FROM_CONV_STATS:
       return pdae_gn_coef_from_conv_stats((int)i[0], (int)i[1], (int)i[2], (int)i[3], (int)i[4], (float)f[0], F(0), (int)i[5], F(1), (int)i[6], F(2), F(3),
                                           F(4), F(5), FM(6), FM(7), FM(8), st);
-    case PDAE_OP_GN_APPLY_STATS:      // p: x0, x1, part0, part1, gamma, beta, ss, zss, mean, rstd, coef, y;  i: C0, C1, N, H, W, G, tpi0, tpi1, act, seed, offset;  f: eps, drop_p
-      return pdae_gn_apply_from_conv_stats(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], (int)i[5], (float)f[0], F(2), (int)i[6], F(3),
-                                           (int)i[7], F(4), F(5), F(6), F(7), FM(8), FM(9), FM(10), (int)i[8], FM(11), (float)f[1], (uint64_t)i[9],
-                                           (uint64_t)i[10], st);
     case PDAE_OP_GN_COEF: return pdae_gn_coef((int)i[0], (int)i[1], (int)i[2], F(0), F(1), F(2), F(3), F(4), F(5), FM(6), st);
     case PDAE_OP_GN_APPLY:
       return pdae_gn_apply(F(0), (int)i[0], F(1), (int)i[1], (int)i[2], (int)i[3], (int)i[4], F(2), (int)i[5], (int)i[6], FM(3), FM(4), (float)f[0],

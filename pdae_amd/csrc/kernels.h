@@ -13,10 +13,6 @@ int k_gn_stats_coef(const float* x0, int C0, const float* x1, int C1, int N, int
                     const float* ss, const float* zss, float* mean, float* rstd, float* coef, float* ws, hipStream_t st, unsigned* ticket = nullptr);
 int k_gn_coef(int N, int C, int G, const float* mean, const float* rstd, const float* gamma, const float* beta, const float* ss, const float* zss,
               float* coef, hipStream_t st);
-int k_gn_apply_from_conv_stats(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, float eps, const float* part0, int tpi0,
-                               const float* part1, int tpi1, const float* gamma, const float* beta, const float* ss, const float* zss, float* mean,
-                               float* rstd, float* coef, int act, float* y, float drop_p, unsigned long long seed, unsigned long long offset,
-                               hipStream_t st);
 int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, const float* coef, int act, int mode, float* y, float* xpool,
                float drop_p, unsigned long long seed, unsigned long long offset, hipStream_t st);
 int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd, const float* gamma,

@@ -385,85 +385,6 @@ __global__ void __launch_bounds__(256) gn_apply_stream_kernel(Src2 s, int HW, in
   }
 }
 
-// Round 6: gn_apply_stream with the coefficient kernel folded into its prologue (pdae_gn_apply_from_conv_stats).  A GroupNorm whose input
-// carries the producers' partial statistics used to cost two dependent launches in front of its consumer -- gn_coef_from_conv_stats (N x 4
-// blocks, all latency) and this streaming pass; here every block first combines the partial sums of ITS image (fp64, eight lanes per group:
-// tpi x quads-per-group float2 loads per lane, L2 resident), keeps the coefficients of its own channel quad in registers, and the blocks of chunk 0
-// write mean / rstd / [mu | a | b] for the backward pass.  Same formulas as gn_coef_from_conv_stats_kernel (the fp64 sums are taken in another
-// order: the float results agree to the last bit or differ by one ulp of the mean).
-__global__ void __launch_bounds__(256) gn_apply_stream_stats_kernel(Src2 s, int HW, int C, int N, int chunk, int G, float eps,
-                                                                    const float2* __restrict__ part0, int tpi0, const float2* __restrict__ part1, int tpi1,
-                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                    const float* __restrict__ ss, const float* __restrict__ zss,
-                                                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ coef, int act,
-                                                                    float* __restrict__ y, float drop_p, unsigned long long seed, unsigned long long offset) {
-  __shared__ float smean[64], srstd[64];
-  const int n = blockIdx.y, NQ = C >> 2, PL = 256 / NQ;
-  const int t = threadIdx.x, C0 = s.C0, cg = C / G, qg = cg >> 2, nq0 = C0 >> 2, nq1 = (C - C0) >> 2;
-  const bool writer = blockIdx.x == 0;
-  for (int g0 = 0; g0 < G; g0 += 32) {              // 32 groups per sweep, 8 lanes each (G <= 64)
-    const int g = g0 + (t >> 3), j = t & 7;
-    double a = 0.0, b = 0.0;
-    if (g < G)
-      for (int q = 0; q < qg; ++q) {
-        const int cq = g * qg + q;
-        const bool first = cq < nq0;
-        const float2* src = first ? part0 + (size_t)n * tpi0 * nq0 + cq : part1 + (size_t)n * tpi1 * nq1 + (cq - nq0);
-        const int tpi = first ? tpi0 : tpi1, nq = first ? nq0 : nq1;
-#pragma unroll 4
-        for (int k = j; k < tpi; k += 8) { const float2 v = src[(size_t)k * nq]; a += v.x; b += v.y; }
-      }
-#pragma unroll
-    for (int off = 4; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-    if (j == 0 && g < G) {
-      const double cnt = (double)cg * HW, m = a / cnt;
-      double var = b / cnt - m * m;
-      if (var < 0.0) var = 0.0;
-      smean[g] = (float)m; srstd[g] = (float)(1.0 / sqrt(var + (double)eps));
-      if (writer) { mean[n * G + g] = smean[g]; rstd[n * G + g] = srstd[g]; }
-    }
-  }
-  __syncthreads();
-  const int q = t % NQ, pl = t / NQ, c = q * 4;
-  if (pl >= PL) return;
-  const size_t NC = (size_t)N * C, base = (size_t)n * HW;
-  float4 mu, a, b;
-  {
-    const int gi = c / cg;                          // cg % 4 == 0: the quad lies in one group
-    const float m = smean[gi], r = srstd[gi];
-    float kk[4], bb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      kk[e] = gamma[c + e] * r; bb[e] = beta[c + e];
-      if (ss) { const float sc = 1.0f + ss[(size_t)n * 2 * C + c + e]; kk[e] *= sc; bb[e] = bb[e] * sc + ss[(size_t)n * 2 * C + C + c + e]; }
-      if (zss) { const float sc = 1.0f + zss[(size_t)n * 2 * C + c + e]; kk[e] *= sc; bb[e] = bb[e] * sc + zss[(size_t)n * 2 * C + C + c + e]; }
-    }
-    mu = make_float4(m, m, m, m); a = make_float4(kk[0], kk[1], kk[2], kk[3]); b = make_float4(bb[0], bb[1], bb[2], bb[3]);
-    if (writer && pl == 0) {
-      *reinterpret_cast<float4*>(coef + (size_t)n * C + c) = mu;
-      *reinterpret_cast<float4*>(coef + NC + (size_t)n * C + c) = a;
-      *reinterpret_cast<float4*>(coef + 2 * NC + (size_t)n * C + c) = b;
-    }
-  }
-  const float dscale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-  const int p0 = blockIdx.x * chunk, p1 = min(HW, p0 + chunk);
-  for (int p = p0 + pl; p < p1; p += UNR * PL) {
-    float4 x[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) if (p + u * PL < p1) x[u] = ld4(s, base + p + u * PL, c);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (p + u * PL >= p1) break;
-      const size_t pix = base + p + u * PL;
-      float4 o;
-      o.x = a.x * (x[u].x - mu.x) + b.x; o.y = a.y * (x[u].y - mu.y) + b.y; o.z = a.z * (x[u].z - mu.z) + b.z; o.w = a.w * (x[u].w - mu.w) + b.w;
-      if (act) { o.x = siluf(o.x); o.y = siluf(o.y); o.z = siluf(o.z); o.w = siluf(o.w); }
-      if (drop_p > 0.f) { float4 m = drop_mask(seed, offset, pix * NQ + q, drop_p, dscale); o.x *= m.x; o.y *= m.y; o.z *= m.z; o.w *= m.w; }
-      *reinterpret_cast<float4*>(y + pix * C + c) = o;
-    }
-  }
-}
-
 // gradient wrt the activated tensor at input-resolution pixel (n,py,px):
 //   mode 0: dA[pix]; mode 1 (y was pooled): dA[pool pix]/4; mode 2 (consumer read y nearest-upsampled): sum of the 4 children
 __device__ __forceinline__ float4 fetch_da(const float* __restrict__ dA, int mode, int n, int py, int px, int H, int W, int C, int c) {
@@ -788,20 +709,6 @@ int k_gn_apply(const float* x0, int C0, const float* x1, int C1, int N, int H, i
   size_t total = (size_t)N * (mode ? (H / 2) * (W / 2) : H * W) * (C / 4);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, s, N, H, W, C, coef, act, mode, y, xpool, drop_p, seed, offset);
   return pdae_launch_status("gn_apply");
-}
-
-int k_gn_apply_from_conv_stats(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, float eps, const float* part0, int tpi0,
-                               const float* part1, int tpi1, const float* gamma, const float* beta, const float* ss, const float* zss, float* mean,
-                               float* rstd, float* coef, int act, float* y, float drop_p, unsigned long long seed, unsigned long long offset,
-                               hipStream_t st) {
-  if (int e = check_c(C0, C1, G)) return e;
-  const int C = C0 + C1, HW = H * W;
-  Src2 s{x0, x1, C0, C1};
-  int S = stream_chunks(HW, C), chunk = cdiv(HW, S);
-  S = cdiv(HW, chunk);
-  hipLaunchKernelGGL(gn_apply_stream_stats_kernel, dim3(S, N), dim3(256), 0, st, s, HW, C, N, chunk, G, eps, reinterpret_cast<const float2*>(part0), tpi0,
-                     reinterpret_cast<const float2*>(part1), tpi1, gamma, beta, ss, zss, mean, rstd, coef, act, y, drop_p, seed, offset);
-  return pdae_launch_status("gn_apply_from_conv_stats");
 }
 
 int k_gn_bwd(const float* x0, int C0, const float* x1, int C1, int N, int H, int W, int G, const float* coef, const float* rstd,

@@ -300,8 +300,6 @@ class Builder:
         # forward 3x3 convolutions leave the GroupNorm partial statistics of their output behind (pdae_conv_stats_arm); the GroupNorm that
         # reads such a tensor takes them instead of a statistics pass over it
         self.fuse_stats = os.environ.get("PDAE_FUSE_GN_STATS", "1") != "0"
-        # ... and where such a GroupNorm is an apply pass (not a fused-GN convolution input) the coefficient launch is folded into it (pdae_gn_apply_from_conv_stats)
-        self.fuse_coef_apply = os.environ.get("PDAE_FUSE_COEF_APPLY", "1") != "0"
         # stride-2 3x3 convolutions (encoder) in the dense-grid form: backward always, forward up to s2_fwd_max output pixels
         self.s2_dense = os.environ.get("PDAE_S2_DENSE", "1") != "0"
         self.s2_fwd_max = int(os.environ.get("PDAE_S2_FWD_M", "8192"))
@@ -797,24 +795,15 @@ class Builder:
         Ho, Wo = (Hh // 2, W // 2) if mode == 1 else (Hh, W)
         y = pl.buf(N, Ho, Wo, C)
         xpool = pl.buf(N, Ho, Wo, C) if (mode == 1 and want_xpool) else None
+        self._gn_stats_coef(x0, C0, x1, C1, N, Hh * W, gamma, beta, ss, zss, mean, rstd, coef)
         dp = self.drop_p if dropout else 0.0
         layer = 0
         if dp > 0:
             self.drop_layers += 1
             layer = self.drop_layers
-        s0, s1 = self._stats_of(x0), self._stats_of(x1)
-        if (self.fuse_coef_apply and mode == 0 and xpool is None and s0 is not None and (x1 is None or s1 is not None)
-                and (C // GROUPS) % 4 == 0 and C0 % 4 == 0):
-            # round 6: the coefficient launch rides in the apply launch (one dependent launch less in front of the consumer)
-            idx = pl.emit(H.op_gn_apply_stats(x0, C0, x1, C1, N, Hh, W, GROUPS, GN_EPS, s0[0], s0[1], s1[0] if s1 else None, s1[1] if s1 else 0,
-                                              gamma, beta, ss, zss, mean, rstd, coef, act, y, drop_p=dp, seed=layer, offset=0))
-            if dp > 0:
-                pl.drop_ops.append((idx, 9, 10))
-        else:
-            self._gn_stats_coef(x0, C0, x1, C1, N, Hh * W, gamma, beta, ss, zss, mean, rstd, coef)
-            idx = pl.emit(H.op_gn_apply(x0, C0, x1, C1, N, Hh, W, coef, act, mode, y, xpool=xpool, drop_p=dp, seed=layer, offset=0))
-            if dp > 0:
-                pl.drop_ops.append((idx, 7, 8))
+        idx = pl.emit(H.op_gn_apply(x0, C0, x1, C1, N, Hh, W, coef, act, mode, y, xpool=xpool, drop_p=dp, seed=layer, offset=0))
+        if dp > 0:
+            pl.drop_ops.append((idx, 7, 8))
         ctx = NS(x0=x0, x1=x1, C0=C0, C1=C1, N=N, H=Hh, W=W, gname=gname, ss=ss, zss=zss, act=act, mode=mode, mean=mean, rstd=rstd,
                  coef=coef, y=y, xpool=xpool, drop_p=dp, layer=layer)
         if not self.save:

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PDAE_HIP_LIB") or os.path.join(_HERE, "lib", "libpdae
  OP_SILU_BWD, OP_AXPBY, OP_EMBEDDING, OP_EMBEDDING_BWD, OP_TO_NHWC, OP_FROM_NHWC, OP_Q_SAMPLE, OP_LOSS, OP_DDIM_STEP,
  OP_DDPM_STEP, OP_ADAM_EMA, OP_SOFTMAX, OP_SOFTMAX_BWD, OP_COLSUM, OP_MEMSET, OP_COPY, OP_CONV_WPREP, OP_MLP_MODLN_FWD, OP_MLP_MODLN_BWD, OP_CONV_FWD_GN, OP_CONV_FWD_SKIP, OP_GN_STATS_COEF, OP_CONV_SKIP_WPREP, OP_AMAX,
  OP_AXPBY_ROWS, OP_DDIM_STEP_ROWS, OP_DDPM_STEP_ROWS, OP_LINEAR_GROUP, OP_ATTN_FWD, OP_ATTN_BWD, OP_LINEAR_BWD_GROUP, OP_GN_COEF_FROM_CONV_STATS, OP_CONV_WPREP_GROUP, OP_SUBSAMPLE2,
- OP_ZERO_INSERT2, OP_GN_STATS_QUADS, OP_JOIN, OP_GN_APPLY_STATS) = range(1, 49)
+ OP_ZERO_INSERT2, OP_GN_STATS_QUADS, OP_JOIN) = range(1, 48)
 OPF_SIDE = 1            # PdaeOp.flags: issue on the executor's second stream (pdae_hip.h)
 
 
@@ -112,7 +112,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_knob", "pdae_get_knob", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv_gnbwd_bytes", "pdae_conv_gnbwd_arm", "pdae_gn_bwd_parts_arm", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv2d_wgrad_gn_ok", "pdae_conv_gn_input_arm", "pdae_conv_wprep_bytes", "pdae_conv3x3_form", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_stats_quads", "pdae_gn_coef_from_conv_stats", "pdae_gn_apply_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv2d_wgrad_gn_ok", "pdae_conv_gn_input_arm", "pdae_conv_wprep_bytes", "pdae_conv3x3_form", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_stats_quads", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_subsample2", "pdae_zero_insert2", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_bwd_group", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
@@ -486,11 +486,6 @@ def op_gn_coef(N, C, G, mean, rstd, gamma, beta, ss, zss, coef):
 
 def op_gn_apply(x0, C0, x1, C1, N, H, W, coef, act, mode, y, xpool=None, drop_p=0.0, seed=0, offset=0):
     return make_op(OP_GN_APPLY, [x0, x1, coef, y, xpool], [C0, C1, N, H, W, act, mode, seed, offset], [drop_p])
-
-
-def op_gn_apply_stats(x0, C0, x1, C1, N, H, W, G, eps, part0, tpi0, part1, tpi1, gamma, beta, ss, zss, mean, rstd, coef, act, y, drop_p=0.0, seed=0, offset=0):
-    """pdae_gn_apply_from_conv_stats: op_gn_coef_from_conv_stats + op_gn_apply (mode 0) in one launch."""
-    return make_op(OP_GN_APPLY_STATS, [x0, x1, part0, part1, gamma, beta, ss, zss, mean, rstd, coef, y], [C0, C1, N, H, W, G, tpi0, tpi1, act, seed, offset], [eps, drop_p])
 
 
 def op_gn_bwd(x0, C0, x1, C1, N, H, W, G, coef, rstd, gamma, beta, ss, zss, dA, act, mode, ws, add=None, dx0=None, acc0=0,

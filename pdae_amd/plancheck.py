@@ -22,7 +22,7 @@ from . import hip as H
 _W = {
     "OP_CONV_FWD": (5, 19), "OP_CONV_FWD_GN": (6, 19), "OP_CONV_FWD_SKIP": (9, 19), "OP_CONV_SKIP_WPREP": (1,), "OP_CONV_DGRAD": (2, 8),
     "OP_AMAX": (1,), "OP_CONV_WPREP": (1,), "OP_CONV_WGRAD": (3, 4, 5), "OP_GEMM": (2,), "OP_ATTN_FWD": (1, 2), "OP_ATTN_BWD": (4, 5),
-    "OP_GN_STATS": (2, 3, 4), "OP_GN_STATS_COEF": (6, 7, 8, 9, 10), "OP_GN_COEF_FROM_CONV_STATS": (6, 7, 8), "OP_GN_APPLY_STATS": (8, 9, 10, 11), "OP_GN_STATS_QUADS": (1,),
+    "OP_GN_STATS": (2, 3, 4), "OP_GN_STATS_COEF": (6, 7, 8, 9, 10), "OP_GN_COEF_FROM_CONV_STATS": (6, 7, 8), "OP_GN_STATS_QUADS": (1,),
     "OP_GN_COEF": (6,), "OP_GN_APPLY": (3, 4), "OP_GN_BWD": (10, 11, 12, 13, 14, 15, 16, 17, 18), "OP_MLP_MODLN_FWD": (4, 5, 6),
     "OP_MLP_MODLN_BWD": (7, 8, 9, 10), "OP_TEMB": (2,), "OP_SILU": (1,), "OP_SUBSAMPLE2": (1,), "OP_ZERO_INSERT2": (1,), "OP_SILU_BWD": (2,),
     "OP_AXPBY": (1,), "OP_EMBEDDING": (2,), "OP_EMBEDDING_BWD": (2,), "OP_TO_NHWC": (1,), "OP_FROM_NHWC": (1,), "OP_Q_SAMPLE": (5,),

@@ -24,7 +24,7 @@ def test_header_symbols_exported(L):
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.pdae_abi_version() == 11
+    assert L.pdae_abi_version() == 10
 
 
 def test_struct_layout_matches_header():

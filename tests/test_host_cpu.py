@@ -70,12 +70,7 @@ def test_plans_take_groupnorm_statistics_from_the_producing_convolution(monkeypa
     off, armed_off = kinds("0")
     assert armed_off == 0 and off[H.OP_GN_COEF_FROM_CONV_STATS] == 0
     assert armed_on > 0 and on[H.OP_GN_COEF_FROM_CONV_STATS] > 0
-    # every GroupNorm is still there (round 6: where the GroupNorm is an APPLY pass the coefficient launch rides in it -- pdae_gn_apply_from_conv_stats)
-    assert on[H.OP_GN_STATS_COEF] + on[H.OP_GN_COEF_FROM_CONV_STATS] + on[H.OP_GN_APPLY_STATS] == off[H.OP_GN_STATS_COEF]
-    assert on[H.OP_GN_APPLY_STATS] >= 1 and off[H.OP_GN_APPLY_STATS] == 0
-    monkeypatch.setenv("PDAE_FUSE_COEF_APPLY", "0")
-    on2, _ = kinds("1")
-    assert on2[H.OP_GN_APPLY_STATS] == 0 and on2[H.OP_GN_COEF_FROM_CONV_STATS] == on[H.OP_GN_COEF_FROM_CONV_STATS] + on[H.OP_GN_APPLY_STATS]
+    assert on[H.OP_GN_STATS_COEF] + on[H.OP_GN_COEF_FROM_CONV_STATS] == off[H.OP_GN_STATS_COEF]       # every GroupNorm is still there
     assert on[H.OP_GN_STATS_COEF] >= 1                                                               # e.g. the tensor behind the stem convolution
 
 
