@@ -310,7 +310,7 @@ def test_f128_ddim100_encode_then_decode_round_trip_vs_oracle_psnr_and_ssim_thre
         t0 = time.time()
         O.shift_unet_forward(dec_sd, dcfg, x0, torch.tensor([500]), z)
         per = time.time() - t0
-        sched = os.environ.get("PDAE_TEST_DDIM", "ddim100" if per < 3.0 else ("ddim50" if per < 6.0 else "ddim20"))
+        sched = os.environ.get("PDAE_TEST_DDIM", "ddim100" if per < 2.4 else ("ddim50" if per < 5.0 else "ddim20"))
         print(f"[F128 round trip] one oracle decoder pass {per:.2f} s -> schedule {sched}")
         xT_ref = O.shift_ddim_encode_loop(s, sched, dec_sd, dcfg, z, x0)
         rec_ref = O.shift_ddim_sample_loop(s, sched, dec_sd, dcfg, z, xT_ref)
