@@ -35,7 +35,7 @@ static inline hipStream_t S(pdae_stream_t s) { return (hipStream_t)s; }
 static const struct { const char* name; int def; } g_knob_def[KNOB_COUNT] = {
     {"PDAE_W1", 1}, {"PDAE_W1_EFF", 85}, {"PDAE_P3R", 1}, {"PDAE_P3R_MIN", 512}, {"PDAE_P3R_EFF", 85}, {"PDAE_EDGE", 1}, {"PDAE_P3_TH", 0},
     {"PDAE_SPLIT_STATS", 1}, {"PDAE_W3_STAGGER", 0}, {"PDAE_Y_STAGGER", 0}, {"PDAE_C1_SLAB", 1}, {"PDAE_C1_BF16", 0}, {"PDAE_NO_SKINNY", 0},
-    {"PDAE_C1_ROT", 1}, {"PDAE_W1_ROWS8", 1}, {"PDAE_W1_EFF8", 70}, {"PDAE_W1_MIN8", 160}, {"PDAE_SIDE_STREAM", 1}, {"PDAE_W3V", 1}, {"PDAE_Y_XCD", 1}, {"PDAE_Y_GRID_TRIM", 0}};
+    {"PDAE_C1_ROT", 1}, {"PDAE_W1_ROWS8", 1}, {"PDAE_W1_EFF8", 70}, {"PDAE_W1_MIN8", 160}, {"PDAE_SIDE_STREAM", 1}, {"PDAE_W3V", 1}, {"PDAE_Y_XCD", 0}, {"PDAE_Y_GRID_TRIM", 0}};
 #include <atomic>
 static std::atomic<int> g_knob_val[KNOB_COUNT];
 static std::atomic<bool> g_knob_set[KNOB_COUNT];

@@ -59,7 +59,7 @@ enum PdaeKnob {
   KNOB_W1_MIN8,       // PDAE_W1_MIN8: minimum number of 8-row tiles of a launch for that form (160)
   KNOB_SIDE_STREAM,   // PDAE_SIDE_STREAM: ops flagged PDAE_OPF_SIDE run on the library's second stream (1); 0: on the caller's stream, in order
   KNOB_W3V,           // PDAE_W3V: 3x3 weight gradients in the producer / consumer form conv3x3v.hip where it applies (1); 0: conv3x3w.hip everywhere
-  KNOB_Y_XCD,         // PDAE_Y_XCD: conv3x3y gives the workgroups of an XCD consecutive tile indices (1)
+  KNOB_Y_XCD,         // PDAE_Y_XCD: conv3x3y gives the workgroups of an XCD consecutive tile indices: 1 launches with >= 2 output-channel tiles, 2 all, 0 none (default: measured slower)
   KNOB_Y_GRID_TRIM,   // PDAE_Y_GRID_TRIM: conv3x3y launches 256 - k workgroups (0): k CUs stay free for a collective's channels at world size > 1
   KNOB_COUNT
 };

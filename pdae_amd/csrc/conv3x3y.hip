@@ -693,7 +693,7 @@ template <int NS, bool GN, bool EX, bool ST, bool GB = false, int RH = 2> static
   const int trim = pdae_knob(KNOB_Y_GRID_TRIM);
   if (trim > 0 && trim < 128 && ntiles > 256 - trim) grid = dim3((unsigned)(256 - trim));
   hipLaunchKernelGGL((conv3x3y_kernel<NS, GN, EX, ST, GB, RH>), grid, dim3(YTHREADS), smem, s, P,
-                     (ntiles >= 2 * 256 ? (stagger & 0xffff) : 0) | (pdae_knob(KNOB_Y_XCD) ? 0x10000 : 0), D);
+                     (ntiles >= 2 * 256 ? (stagger & 0xffff) : 0) | ((pdae_knob(KNOB_Y_XCD) == 2 || (pdae_knob(KNOB_Y_XCD) == 1 && P.tiles_n >= 2)) ? 0x10000 : 0), D);
   return pdae_launch_status("conv3x3y");
 }
 

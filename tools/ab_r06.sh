@@ -9,5 +9,5 @@ run $R5
 run PDAE_W3V=1 PDAE_SIDE_ENC=0 PDAE_FUSE_GN_TRAIN=1 PDAE_Y_XCD=0
 run PDAE_W3V=1 PDAE_SIDE_ENC=1 PDAE_FUSE_GN_TRAIN=1 PDAE_Y_XCD=0
 run PDAE_W3V=1 PDAE_SIDE_ENC=1 PDAE_FUSE_GN_TRAIN=0 PDAE_Y_XCD=0
-run PDAE_W3V=1 PDAE_SIDE_ENC=1 PDAE_FUSE_GN_TRAIN=0 PDAE_Y_XCD=1
+run PDAE_W3V=1 PDAE_SIDE_ENC=1 PDAE_FUSE_GN_TRAIN=0 PDAE_Y_XCD=2
 done
