@@ -175,7 +175,13 @@ class _FusedStep:
         import time
         try:
             store = dist.distributed_c10d._get_default_store()
-            key = f"pdae_amd/comm_fallback/step{self.step_count}"
+            #  the key names the process group and counts the retries of this step: a second failure in the same step, or a step of a
+            # sub-group, must not meet the counter of an earlier rendezvous
+            try:
+                gid = "-".join(str(r) for r in dist.get_process_group_ranks(self.pg)) if self.pg is not None else "world"
+            except Exception:                     # noqa: BLE001
+                gid = "world"
+            key = f"pdae_amd/comm_fallback/{gid}/step{self.step_count}/try{getattr(self, 'comm_retries', 0)}"
             n = store.add(key, 1)
             deadline = time.time() + float(os.environ.get("PDAE_COMM_TIMEOUT_S", "300")) + 60.0
             while n < n_ranks:
