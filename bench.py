@@ -426,13 +426,13 @@ def main():
                         allreduce_bus_gbps=round(2 * (world - 1) / world * comm["grad_bytes_per_step"] / max(alone, 1e-9) / 1e6, 1))
 
     from pdae_amd import hip as H
-    if comm is not None and not dry and world > 1:
+    if comm is not None and world > 1:
         # A/B of the LDS-displacement remedy: the persistent conv3x3y launches with 256 - k workgroups
         # (knob PDAE_Y_GRID_TRIM) leave k CUs to the collective's channels.  Outside the timed region, after it: 4 steps per setting, MAX over ranks;
         # the headline number above is the default (k = 0).  A driver run on a real multi-GPU node thereby measures what this builder never could.
         ab = {}
         try:
-            for k in (0, 8, 16, 32):
+            for k in ((0, 8) if dry else (0, 8, 16, 32)):      # (the dry run only exercises the control flow: no kernels)
                 H.set_knob("PDAE_Y_GRID_TRIM", k)
                 st.step(x0); sync(); dist.barrier()
                 t0 = time.perf_counter()
@@ -442,11 +442,13 @@ def main():
                 tt = torch.tensor([(time.perf_counter() - t0) / 4 * 1e3], device=dev, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 ab[str(k)] = round(float(tt.item()), 3)
+        except Exception as e:                       # noqa: BLE001  (an A/B aid behind the timed region must never cost the run its JSON line)
+            comm["y_grid_trim_error"] = f"{type(e).__name__}: {str(e)[:200]}"
         finally:
             H.set_knob("PDAE_Y_GRID_TRIM", 0)
         comm["y_grid_trim_ms_per_step"] = ab
     if comm is not None:
-        comm["y_grid_trim"] = int(H.get_knob("PDAE_Y_GRID_TRIM")) if not dry else 0
+        comm["y_grid_trim"] = int(H.get_knob("PDAE_Y_GRID_TRIM"))
 
     wl = "config/ffhq_representation_learning.yml: PDAE representation learning, FFHQ-128 [ASSUMED denoise_fn_config], encoder FFHQEncoder + ShiftUNet, " \
          f"Adam lr {oc['lr']}, EMA {rc['ema_decay']}, dropout {ddpm_cfg['dropout']}"

@@ -53,6 +53,8 @@ def test_bench_self_launches_two_ranks_dry():
     assert len(c["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in c["per_rank_ms_per_step"]) and c["exchange_path"].startswith("bucketed")
     assert abs(out["ms_per_step"] - max(c["per_rank_ms_per_step"])) < 1e-2
     assert out["config"]["global_batch"] == 2 * out["config"]["per_gpu_batch"]
+    # round 6: the A/B of the conv3x3y grid trim behind the timed region (PDAE_Y_GRID_TRIM; control flow only in a dry run), knob restored to 0
+    assert set(c["y_grid_trim_ms_per_step"]) == {"0", "8"} and c["y_grid_trim"] == 0 and "y_grid_trim_error" not in c
     # --bucket-mb 0: the sweep over 16 / 48 / 96 MB runs first
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry", "--steps", "1", "--warmup", "1", "--bucket-mb", "0"], cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
