@@ -331,6 +331,47 @@ def test_f128_ddim100_encode_then_decode_round_trip_vs_oracle_psnr_and_ssim_thre
     assert rel_err(ssim_mse(x0.to(DEV), rec_ref.to(DEV), denormalize=True)[0], O.ssim((x0 + 1) / 2, (rec_ref + 1) / 2)) < 1e-4     # the metric kernel itself, at 128^2
 
 
+@pytest.mark.timeout(1200)
+def test_f128_ddim1000_inversion_checked_in_windows_along_its_own_trajectory(gd):
+    """The evaluator's ACTUAL inversion (sampler/autoencoding_eval.py:74: `ddim1000` = 999 steps, diffusion/ddim.py:140-147) at the benchmarked network,
+    B = 1.  Walking all 999 steps on the oracle would take half an hour of host time, and it is not needed: the loop is a chain of deterministic
+    maps x_{i+1} = F_i(x_i), so the HIP path runs the WHOLE inversion once (trajectory kept on the device) and the oracle re-computes windows of K
+    consecutive steps starting from the HIP state at the window's first step -- at the start, the middle and the very end of the schedule (where
+    sqrt(1/ac - 1) is largest and the clamp is active).  Every window end must agree to > 85 dB PSNR; a wrong timestep map, coefficient row or
+    shift term at any of these 3 K steps would show as a different map.  Together with the ddim100 round trip above this pins both halves of the
+    protocol at F128 (VERDICT r5 weak #2)."""
+    c, dcfg, ename, enc_sd, dec_sd, enc, dec = _rl_setup("config/ffhq_representation_learning.yml", seed_enc=4, seed_dec=6)
+    dec.set_eval_mode()
+    x0 = _batch(1, 3, 128, seed=9)[0]
+    s = O.Schedules()
+    d = O.DDIMTables(s, "ddim1000")
+    T, K = d.timesteps, 6
+    assert T == 999
+    traj = []
+    with torch.no_grad():
+        _guard().reset()
+        z_dev = enc(x0.to(DEV))
+        xT = gd._ddim("ddim1000").shift_ddim_encode_loop(dec, z_dev, x0.to(DEV), trajectory=traj)
+        assert _guard().read()[0] == 0 and len(traj) == T and torch.equal(traj[-1], xT)
+        z = O.encoder_forward(enc_sd, ename, x0)
+        assert rel_err(z_dev, z) < 1e-4
+
+        def psnr(a, b):
+            return 10 * math.log10(4.0 / max(float(((a.double().cpu() - b.double()) ** 2).mean()), 1e-30))
+        worst = 1e9
+        for first in (0, T // 2, T - K):
+            x = x0 if first == 0 else traj[first - 1].cpu().float()           # state in front of step `first` (trajectory[i] = state after step i)
+            for i in range(first, first + K):
+                t = torch.full((1,), i, dtype=torch.long)
+                eps, g = O.shift_unet_forward(dec_sd, dcfg, x, d.timestep_map[t], z)
+                x = O.ddim_update(d, x, t, eps, g, encode=True)
+            p = psnr(traj[first + K - 1], x)
+            print(f"[F128 ddim1000 inversion] steps {first}..{first + K - 1}: PSNR vs oracle {p:.1f} dB (|x| max {float(x.abs().max()):.2f})")
+            worst = min(worst, p)
+    assert worst > 85, worst
+    assert torch.isfinite(xT).all() and 0.5 < float(xT.std()) < 2.0              # the inversion ends near unit-variance noise
+
+
 def test_latent_ffhq_yaml_full_topology_step_vs_oracle(gd):
     """BASELINE config #5 exactly as shipped: config/ffhq_latent.yml -> MLPSkipNet 10 x 2048 with skip-concats, per-GPU batch 128, L1 loss,
     AdamW(1e-3, wd 0.01) + EMA -- through FusedLatentStep (model/mlp_skip_net.py:55-141, gaussian_diffusion.py:373-398,
