@@ -138,3 +138,41 @@ def test_weight_gradient_with_fused_groupnorm_input_producer_consumer_form(H, kn
     knob("PDAE_W3V", 0)
     dw_w, _ = _wgrad(H, c, x0, x1, dyd, amx, gn_coef=coef, gn_act=act)
     assert rel_err(dw, dw_w) < (2e-6 if math_mode == 4 else tol)
+
+
+@pytest.mark.parametrize("shape", [(32, 128, 128, 128, 128), (32, 64, 64, 256, 256), (32, 16, 16, 384, 384)])
+def test_full_size_properties_at_the_benchmark_batch(H, knob, shape):
+    """BASELINE sizes (B = 32, the step's own layers), where an fp64 reference would take minutes of host time: size-independent properties instead.
+    (a) the two kernels agree on the same operands (conv3x3w is pinned against fp64 at small sizes: 2e-6 of max |dW|); (b) linearity in dY --
+    dW(dY1 + dY2) = dW(dY1) + dW(dY2), each launch with its own dynamic fp16 scale; (c) a dY that is zero outside one image gives the dW of that image
+    alone (the pixel-tile partition over splits cannot leak between images); (d) bit-identical repeat."""
+    N, Hh, W, Cin, Cout = shape
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(N, Hh, W, Cin, device="cuda", generator=g)
+    dy1 = torch.randn(N, Hh, W, Cout, device="cuda", generator=g) * 1e-3
+    dy2 = torch.randn(N, Hh, W, Cout, device="cuda", generator=g) * 3e-4
+    c = H.Conv(N, Hh, W, Cin, 0, Cout, k=3, math=4)
+
+    def run(dy, v):
+        knob("PDAE_W3V", v)
+        am = torch.empty(4, device="cuda")
+        H.run(H.op_amax(dy, dy.numel(), am))
+        return _wgrad(H, c, x, None, dy, am)
+    dw1, db1 = run(dy1, 1)
+    dw1w, db1w = run(dy1, 0)
+    assert rel_err(dw1, dw1w) < 2e-6 and rel_err(db1, db1w) < 1e-6
+    dw2, _ = run(dy2, 1)
+    dw12, _ = run(dy1 + dy2, 1)
+    assert rel_err(dw12, dw1 + dw2) < 5e-6
+    one = torch.zeros_like(dy1)
+    one[N // 2] = dy1[N // 2]
+    dwo, _ = run(one, 1)
+    c1 = H.Conv(1, Hh, W, Cin, 0, Cout, k=3, math=4)
+    if Hh * W >= 64 * 128:                       # one image alone is still a launch of >= 64 pixel tiles: the same kernel on the single image
+        knob("PDAE_W3V", 1)
+        am = torch.empty(4, device="cuda")
+        H.run(H.op_amax(one, one.numel(), am))
+        dws, _ = _wgrad(H, c1, x[N // 2:N // 2 + 1].contiguous(), None, dy1[N // 2:N // 2 + 1].contiguous(), am)
+        assert rel_err(dwo, dws) < 2e-6
+    dw1b, db1b = run(dy1, 1)
+    assert torch.equal(dw1, dw1b) and torch.equal(db1, db1b)
