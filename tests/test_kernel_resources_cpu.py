@@ -155,3 +155,56 @@ def test_conv1x1_stage_loop_does_not_drain_its_prefetch():
         planes = {"1": 1, "2": 2, "4": 2, "3": 3}[re.search(r"ILi(\d)E", k).group(1)]
         # a step's wait: the 8 prefetch loads + the refills of the three other ring slots (the compiler may issue a slot's refill before or after the wait)
         assert w and min(w) >= 3 * planes and sum(v >= 8 + 3 * planes - 1 for v in w) >= 3, (k, w)
+
+
+def mfma_loop_bodies(asm, kernel_re):
+    """{kernel: [instruction lists of its innermost loops that contain MFMAs]} (same walk as mfma_loop_waits)."""
+    out, kern, body, label, last_label = {}, None, None, None, None
+    for line in asm.split("\n"):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kern = m.group(1) if re.search(kernel_re, m.group(1)) else None
+            body = None
+            continue
+        if kern is None:
+            continue
+        m = re.match(r"^(\.LBB\w+):", line)
+        if m:
+            last_label = m.group(1)
+        if "Inner Loop Header" in line:
+            body, label = [], last_label
+            continue
+        t = line.strip().split(";")[0].strip()
+        if body is None or not t:
+            continue
+        body.append(t)
+        if t.startswith("s_cbranch") and t.split()[-1] == label:
+            if any(b.startswith("v_mfma") for b in body):
+                out.setdefault(kern, []).append(body)
+            body = None
+    return out
+
+
+@pytest.mark.timeout(900)
+def test_conv3x3v_matrix_waves_issue_nothing_but_mfmas_and_lds_reads():
+    """conv3x3v.hip (round 6): the design property that makes the producer / consumer split worth having, pinned in the compiled kernel.  The tile loop
+    of a matrix wave (one per tap half: two MFMA loops per instantiation) holds exactly the tile's MFMAs -- 216 for the two-plane formats (36 tap
+    steps x 2 output-channel tiles x 3 products), 72 for one plane -- and their 208 / 104 transposing LDS reads, ONE barrier, and no vector-memory
+    instruction, no vmcnt wait and at most a handful of VALU instructions (the three buffer-base adds): everything else lives in the staging waves'
+    loop, which in turn holds no MFMA."""
+    if "conv3x3v.hip" not in _ASM:
+        resource_table("conv3x3v.hip")
+    loops = mfma_loop_bodies(_ASM["conv3x3v.hip"], r"conv3x3v_kernel")
+    assert len(loops) == 6, sorted(loops)                                  # NS in {1, 2, 4} x GN in {0, 1}
+    for kern, bodies in loops.items():
+        ns = int(re.search(r"kernelILi(\d)E", kern).group(1))
+        n_mfma, n_read = (72, 104) if ns == 1 else (216, 208)
+        assert len(bodies) == 2, (kern, len(bodies))                       # tap halves 0 and 1
+        for b in bodies:
+            assert sum(1 for t in b if t.startswith("v_mfma")) == n_mfma, kern
+            assert sum(1 for t in b if t.startswith("ds_read")) == n_read, kern
+            assert sum(1 for t in b if t.startswith("s_barrier")) == 1, kern
+            assert not [t for t in b if t.startswith(("buffer_", "global_", "flat_", "scratch_", "ds_write"))], kern
+            assert not [t for t in b if t.startswith("s_waitcnt") and "vmcnt" in t], kern
+            valu = [t for t in b if t.startswith("v_") and not t.startswith("v_mfma")]
+            assert len(valu) <= 8, (kern, valu)
