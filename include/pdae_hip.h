@@ -29,7 +29,8 @@ extern "C" {
 typedef void* pdae_stream_t; /* hipStream_t */
 
 const char* pdae_last_error(void);
-/* ABI history.  10 (round 5): pdae_op.reserved became pdae_op.flags (PDAE_OPF_SIDE: the executor's second stream) + PDAE_OP_JOIN + knob
+/* ABI history.  11 (round 6): + pdae_conv2d_wgrad_form (which kernel a weight gradient runs on); knobs PDAE_W3V, PDAE_Y_XCD, PDAE_Y_GRID_TRIM.
+ * 10 (round 5): pdae_op.reserved became pdae_op.flags (PDAE_OPF_SIDE: the executor's second stream) + PDAE_OP_JOIN + knob
  *   PDAE_SIDE_STREAM; arrays written for ABI 9 (flags = 0) run unchanged.
  * 9 (round 5): - pdae_wino_* (the gated 2-D Winograd probe left the library: tools/probes/r04_winograd/); + pdae_set_knob / pdae_get_knob
  *   (the library no longer reads its environment per call); + pdae_conv_gn_input_arm / pdae_conv2d_wgrad_gn_ok (weight gradient that recomputes a fused
@@ -179,6 +180,11 @@ int pdae_gn_bwd_parts_arm(const float* part, int tiles_per_image);
 /* dw[Cout][KH][KW][Cin] (+)= sum over pixels; split-K over pixels through the workspace, reduced in fixed order.
  * db (optional) [Cout] (+)= column sums of dy = the bias gradient; the 3x3 kernel takes them from its own dY staging (no second read of dy). */
 size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d);
+/* (ABI 11, informational) the kernel pdae_conv2d_wgrad(d, ...) runs on: 3 = conv3x3v (3x3, producer / consumer waves: whole 64-channel blocks on both
+ * sides, 16-pixel-wide tiles, >= 64 pixel tiles, a two-plane format), 2 = conv3x3w (the other 3x3 / stride-1 / pad-1 layers), 1 = another dedicated
+ * kernel (1x1 weight gradient, 3-channel edge / head layers), 0 = the generic implicit GEMM.  with_dy_amax / with_gn_input describe the launch
+ * (the fp16 format needs the dY scale; pdae_conv_gn_input_arm joins the two sources).  Follows the knob PDAE_W3V as the launch does. */
+int pdae_conv2d_wgrad_form(const pdae_conv_desc* d, int with_dy_amax, int with_gn_input);
 int pdae_conv2d_wgrad(const pdae_conv_desc* d, const float* x0, const float* x1, const float* dy, float* dw, float* db, int accumulate, void* ws,
                       size_t ws_bytes, const float* dy_amax, pdae_stream_t stream);
 /* Weight gradient of a convolution whose FORWARD applied GroupNorm / AdaGN (+ SiLU) to its raw two-source input inside the staging

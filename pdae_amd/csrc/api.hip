@@ -20,7 +20,7 @@ void pdae_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pdae_last_error(void) { return g_err; }
-extern "C" int pdae_abi_version(void) { return 10; }
+extern "C" int pdae_abi_version(void) { return 11; }
 
 // fp16-window saturation counter (common.h): one device word per process (one process drives one GPU)
 static unsigned int* g_sat = nullptr;
@@ -452,6 +452,28 @@ static size_t wgrad_path_bytes(const pdae_conv_desc* d) {
     }
   }
   return (b + 255) & ~(size_t)255;
+}
+
+// (ABI 11, informational) which kernel pdae_conv2d_wgrad(d, ...) runs on: 3 = conv3x3v (producer / consumer form), 2 = conv3x3w, 1 = another
+// dedicated kernel (1x1 weight gradient, edge / head layers), 0 = the generic implicit GEMM.  with_dy_amax / with_gn_input: as the launch will be
+// made (the fp16 format needs the dY scale; a fused GroupNorm input joins the two sources).  Follows the knob PDAE_W3V like the launch does.
+extern "C" int pdae_conv2d_wgrad_form(const pdae_conv_desc* d, int with_dy_amax, int with_gn_input) {
+  PDAE_DESC_NORM(d)
+  (void)d_dflag;
+  if (!d || check_desc(d)) return 0;
+  const long long Mpix = (long long)d->N * d->Ho * d->Wo;
+  if (!with_gn_input) {
+    if (edge_on() && edge_head_wgrad_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout)) return 1;
+    if (convhead_ok(d->KH, d->KW, d->stride, d->pad, d->up, d->C1, d->C0, d->Cout)) return 1;
+  }
+  const bool three = with_gn_input ? wgrad_gn_ok(d) : conv3x3w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->C1, d->C0, d->Ho, d->Wo, d->N, d->Cout);
+  if (three) {
+    int math = d->math;
+    if (math == 4 && !with_dy_amax) math = 3;
+    return (pdae_knob(KNOB_W3V) && conv3x3v_ok(math, d->C0 + d->C1, d->Ho, d->Wo, d->N, d->Cout)) ? 3 : 2;
+  }
+  if (conv1x1w_ok(d->math, d->KH, d->KW, d->stride, d->pad, d->up, d->C0, d->C1, Mpix, d->Cout) && d->math != 3 && (d->math != 4 || with_dy_amax)) return 1;
+  return 0;
 }
 
 extern "C" size_t pdae_conv2d_wgrad_workspace_bytes(const pdae_conv_desc* d) {

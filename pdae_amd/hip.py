@@ -112,7 +112,7 @@ def lib():
 
 
 EXPORTS = ["pdae_last_error", "pdae_abi_version", "pdae_set_knob", "pdae_get_knob", "pdae_set_saturation_counter", "pdae_conv2d_fwd", "pdae_conv_gnbwd_bytes", "pdae_conv_gnbwd_arm", "pdae_gn_bwd_parts_arm", "pdae_conv2d_dgrad", "pdae_conv2d_wgrad_workspace_bytes",
-           "pdae_conv2d_wgrad", "pdae_conv2d_wgrad_gn_ok", "pdae_conv_gn_input_arm", "pdae_conv_wprep_bytes", "pdae_conv3x3_form", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_stats_quads", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
+           "pdae_conv2d_wgrad", "pdae_conv2d_wgrad_form", "pdae_conv2d_wgrad_gn_ok", "pdae_conv_gn_input_arm", "pdae_conv_wprep_bytes", "pdae_conv3x3_form", "pdae_conv_wprep", "pdae_conv2d_fwd_gn", "pdae_conv2d_fwd_skip_ok", "pdae_conv_skip_wprep_bytes", "pdae_conv_skip_wprep", "pdae_conv_wprep_job", "pdae_conv_skip_wprep_job", "pdae_conv_wprep_group", "pdae_conv2d_fwd_skip", "pdae_conv_stats_bytes", "pdae_conv_stats_arm", "pdae_gn_stats_quads", "pdae_gn_coef_from_conv_stats", "pdae_gemm", "pdae_gn_workspace_bytes", "pdae_gn_stats", "pdae_gn_stats_coef", "pdae_gn_coef", "pdae_gn_apply", "pdae_gn_bwd",
            "pdae_mlp_modln_fwd", "pdae_mlp_modln_bwd", "pdae_timestep_embedding", "pdae_amax", "pdae_silu", "pdae_silu_bwd", "pdae_subsample2", "pdae_zero_insert2", "pdae_axpby", "pdae_embedding", "pdae_embedding_bwd", "pdae_to_nhwc",
            "pdae_from_nhwc", "pdae_softmax", "pdae_softmax_bwd", "pdae_colsum_workspace_bytes", "pdae_colsum", "pdae_linear_bwd_group", "pdae_comm_unique_id", "pdae_comm_init", "pdae_allreduce_bucket", "pdae_comm_destroy", "pdae_linear_group", "pdae_attn_fused_ok", "pdae_attn_fwd", "pdae_attn_bwd", "pdae_q_sample", "pdae_loss",
            "pdae_ddim_step", "pdae_ddpm_step", "pdae_axpby_rows", "pdae_ddim_step_rows", "pdae_ddpm_step_rows", "pdae_adam_ema", "pdae_run_ops",
@@ -401,6 +401,12 @@ def op_conv_wgrad(c, x0, x1, dy, dw, ws, ws_bytes, accumulate=0, db=None, dy_ama
     gn_coef: (x0, x1) are the RAW sources of a fused-GroupNorm forward (op_conv_fwd_gn); the kernel recomputes act(a (x - mu) + b) while it
     stages X (pdae_conv_gn_input_arm; conv_wgrad_gn_ok(c) must hold)."""
     return make_op(OP_CONV_WGRAD, [x0, x1, dy, dw, ws, db, dy_amax, gn_coef], c.fields() + [accumulate, ws_bytes, gn_act if gn_coef is not None else 0])
+
+
+def conv_wgrad_form(c, with_dy_amax=True, with_gn_input=False):
+    """3 = conv3x3v, 2 = conv3x3w, 1 = another dedicated kernel, 0 = generic implicit GEMM (pdae_conv2d_wgrad_form)."""
+    d = c.cdesc()
+    return int(lib().pdae_conv2d_wgrad_form(ctypes.byref(d), int(with_dy_amax), int(with_gn_input)))
 
 
 def conv_wgrad_gn_ok(c):

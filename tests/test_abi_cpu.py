@@ -24,7 +24,7 @@ def test_header_symbols_exported(L):
     assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.pdae_abi_version() == 10
+    assert L.pdae_abi_version() == 11
 
 
 def test_struct_layout_matches_header():
@@ -119,3 +119,27 @@ def test_winograd_form_routing_is_a_pure_function_of_descriptor_and_switch(knob)
     assert not big.winograd_form(0) and H.conv_fwd_skip_ok(big, cs)
     knob("PDAE_W1", 2)
     assert big.winograd_form(0) and not small.winograd_form(0)                          # 2 = every ELIGIBLE shape; a split-K plan stays direct
+
+
+def test_weight_gradient_form_query(L):
+    """pdae_conv2d_wgrad_form (ABI 11): which kernel a weight gradient runs on -- host logic only, so the routing of the round-6 producer / consumer
+    kernel (conv3x3v) is observable without a GPU: whole 64-channel blocks on both sides, 16-pixel-wide tiles, >= 64 pixel tiles, two-plane formats;
+    everything else of the 3x3 / stride-1 family stays on conv3x3w; the knob PDAE_W3V switches it off."""
+    from pdae_amd import hip
+    C = hip.Conv
+    assert hip.conv_wgrad_form(C(32, 128, 128, 128, 0, 128, math=4)) == 3
+    assert hip.conv_wgrad_form(C(32, 16, 16, 384, 0, 384, math=4)) == 3                 # 64 pixel tiles: just enough
+    assert hip.conv_wgrad_form(C(32, 64, 64, 128, 128, 128, math=4), with_gn_input=True) == 3
+    assert hip.conv_wgrad_form(C(32, 128, 128, 128, 0, 128, math=4), with_dy_amax=False) == 2     # no dY scale -> three-plane format -> conv3x3w
+    assert hip.conv_wgrad_form(C(32, 8, 8, 512, 0, 512, math=4)) == 2                   # 8-pixel-wide level: image-pair tiles
+    assert hip.conv_wgrad_form(C(32, 32, 32, 96, 0, 128, math=4)) == 2                  # 96 input channels: not whole 64-channel blocks
+    assert hip.conv_wgrad_form(C(8, 16, 16, 384, 0, 384, math=4)) == 0                  # 16 pixel tiles: too few for either 3x3 kernel -> generic
+    assert hip.conv_wgrad_form(C(32, 16, 16, 384, 0, 1152, k=1, pad=0, math=4)) == 1    # 1x1: its own kernel
+    assert hip.conv_wgrad_form(C(32, 128, 128, 128, 0, 3, math=4)) == 1                 # image head
+    assert hip.conv_wgrad_form(C(32, 128, 128, 128, 0, 128, math=0)) == 0               # f32 mode: generic implicit GEMM
+    old = hip.get_knob("PDAE_W3V")
+    try:
+        hip.set_knob("PDAE_W3V", 0)
+        assert hip.conv_wgrad_form(C(32, 128, 128, 128, 0, 128, math=4)) == 2
+    finally:
+        hip.set_knob("PDAE_W3V", old)

@@ -167,6 +167,8 @@ def _plan_census(plan):
                 n["wino_fwd"] += int(c.winograd_form(0, gn=op.kind == H.OP_CONV_FWD_GN))
         elif op.kind == H.OP_CONV_WGRAD:
             n["wgrad_gn"] += int(bool(op.p[7]))
+            cw = H.Conv(i[0], i[1], i[2], i[3], i[4], i[7], k=i[8], stride=i[10], pad=i[11], up=bool(i[12]), math=i[13])
+            n["wgrad_v"] = n.get("wgrad_v", 0) + int(H.conv_wgrad_form(cw, with_dy_amax=bool(op.p[6]), with_gn_input=bool(op.p[7])) == 3)
         elif op.kind == H.OP_GN_BWD:
             n["gn_bwd_parts"] += int(bool(op.p[19]))
     return n
@@ -186,6 +188,7 @@ def test_f128_b32_gradients_directly_vs_oracle_and_the_forms_the_plans_launch(gd
     print("[F128 B=32 training plan]", n)
     assert n["wino_fwd"] >= 60 and n["wino_dgrad"] >= 25, n                # the 128^2 / 64^2 / wide 32^2 layers (16-row tiles) + the 16^2 layers (8-row tiles)
     assert n["gnb"] >= 8 and n["gnb"] == n["gn_bwd_parts"], n            # in_layers GroupNorms of the shift branch (dropout is 0 here: out_layers too)
+    assert n["wgrad_v"] >= 30, n                                             # round 6: the producer / consumer weight gradient takes every 3x3 layer above the 8 x 8 level
     assert n["wgrad_gn"] == 0, n                                             # round 6 default (PDAE_FUSE_GN_TRAIN=0): the in_layers activation is materialised, plain weight gradients
     z, eps, shift, loss, grads = _oracle_rl(enc_sd, ename, dec_sd, dcfg, x0, t, noise)
     assert rel_err(got["z"], z) < 1e-4 and rel_err(got["eps"], eps) < 1e-4 and rel_err(got["shift"], shift) < 1e-4
